@@ -1,0 +1,217 @@
+"""Pin the CPU oracle (oracle/ccsd_oracle.py) against vectors captured from the real reference.
+
+The fixtures under tests/golden/ were produced by tools/make_golden.py, which imports the
+upstream reference in the build container.  These tests run anywhere (no GPU, no reference).
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ccsd_oracle as O
+from tests.helpers import load_ckpt_np, load_golden, rng_matches
+
+torch.set_num_threads(8)
+
+
+def _close(out, ref, err_msg=""):
+    """The oracle reproduces the reference bit-for-bit in the container the fixtures were made in
+    (same ATen kernels).  On another host CPU the sgemm blocking may differ in the last bits, so
+    fall back to a tight tolerance there instead of failing."""
+    if np.array_equal(out, ref):
+        return
+    np.testing.assert_allclose(out, ref, rtol=2e-5, atol=2e-5, err_msg=err_msg)
+
+
+CC = ["ccsd_qm9_CC", "ccsd_community_small_CC", "ccsd_enzymes_small_CC"]
+GRAPH = ["gdss_community_small", "gdss_zinc250k"]
+
+
+def masked_state(seed, B, N, Fd, is_cc, d_min, d_max, flags, scale):
+    torch.manual_seed(seed)
+    x = O.mask_x(torch.randn(B, N, Fd) * scale, flags)
+    a = torch.randn(B, N, N).triu(1) * scale
+    adj = O.mask_adjs(a + a.transpose(-1, -2), flags)
+    if not is_cc:
+        return x, adj, None
+    E, K = O.get_rank2_dim(N, d_min, d_max)
+    return x, adj, O.mask_rank2(torch.randn(B, E, K) * scale, N, d_min, d_max, flags)
+
+
+def nets_from_ckpt(name):
+    meta, parts = load_ckpt_np(name)
+    is_cc = meta["is_cc"]
+    names = ["x", "adj"] + (["rank2"] if is_cc else [])
+    nets = []
+    for p in names:
+        params, w = meta[f"params_{p}"], parts[p]
+        if is_cc:
+            nets.append(lambda x, a, r, f, params=params, w=w: O.run_network(params, w, x, a, r, f))
+        else:
+            nets.append(lambda x, a, f, params=params, w=w: O.run_network(params, w, x, a, None, f))
+    return meta, nets
+
+
+@pytest.mark.parametrize("name", CC + GRAPH)
+def test_g1_network_forward_and_score_fn(name):
+    g = load_golden(f"g1_{name}.npz")
+    assert rng_matches(g), "torch CPU RNG stream differs from the one the fixtures were made with"
+    meta, nets = nets_from_ckpt(name)
+    cfg, is_cc = meta["config"], meta["is_cc"]
+    N, Fd = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
+    d_min, d_max = (cfg["data"]["d_min"], cfg["data"]["d_max"]) if is_cc else (None, None)
+    flags = torch.from_numpy(g["flags"])
+    B = flags.shape[0]
+    parts = ["x", "adj"] + (["rank2"] if is_cc else [])
+    for tag, scale in (("unit", 1.0), ("small", 0.3)):
+        x, adj, rank2 = masked_state(int(g["seed"]), B, N, Fd, is_cc, d_min, d_max, flags, scale)
+        assert np.array_equal(x.numpy(), g[f"{tag}/x"]) and np.array_equal(adj.numpy(), g[f"{tag}/adj"])
+        args = (x, adj, rank2, flags) if is_cc else (x, adj, flags)
+        with torch.no_grad():
+            for p, net in zip(parts, nets):
+                out = net(*args).numpy()
+                ref = g[f"{tag}/net_{p}"]
+                _close(out, ref, f"{name} {tag} {p}")
+            if tag == "unit":
+                sdes = [O.load_sde(cfg["sde"][p]) for p in parts]
+                for ti, tval in enumerate([1.0, 0.5, 1e-4]):
+                    t = torch.ones(B) * tval
+                    for p, net, s in zip(parts, nets, sdes):
+                        key = f"{tag}/score_{p}_t{ti}"
+                        if key not in g.files:
+                            continue
+                        out = O.make_score_fn(s, net)(*args, t).numpy()
+                        _close(out, g[key], key)
+
+
+def test_g3_sde_tables_bit_exact():
+    g = load_golden("g3_sde_tables.npz")
+    ts = torch.linspace(1, 1e-4, 1000)
+    assert np.array_equal(ts.numpy(), g["timesteps"])
+    for kind, (k, bmin, bmax) in {"VP": ("VP", 0.1, 1.0), "VE": ("VE", 0.1, 1.0), "VE2": ("VE", 0.2, 1.0),
+                                  "subVP": ("subVP", 0.1, 1.0)}.items():
+        s = O.SDE(k, bmin, bmax, 1000)
+        v = torch.ones(1000, 1, 1) * 0.5
+        assert np.array_equal((ts * (s.N - 1) / s.T).long().numpy(), g[f"{kind}/timestep_idx"])
+        drift, diff = s.sde(v, ts)
+        assert np.array_equal(drift.numpy(), g[f"{kind}/sde_drift"])
+        assert np.array_equal(diff.numpy(), g[f"{kind}/sde_diffusion"])
+        assert np.array_equal(s.marginal_std(ts).numpy(), g[f"{kind}/marginal_std"])
+        f, G = s.discretize(v, ts)
+        assert np.array_equal(f.numpy(), g[f"{kind}/disc_f"])
+        assert np.array_equal(G.numpy(), g[f"{kind}/disc_G"])
+        if k != "VE":
+            assert np.array_equal(s.alphas.numpy(), g[f"{kind}/alphas"])
+        else:
+            assert np.array_equal(s.discrete_sigmas.numpy(), g[f"{kind}/discrete_sigmas"])
+        if k != "subVP":
+            m, std = s.transition(v, ts, -0.5 / 1000)
+            assert np.array_equal(m.numpy(), g[f"{kind}/trans_mean"])
+            assert np.array_equal(std.numpy(), g[f"{kind}/trans_std"], equal_nan=True)
+
+
+def test_g6_masks_and_utils_bit_exact():
+    g = load_golden("g6_masks_utils.npz")
+    for (N, d_min, d_max) in [(9, 3, 9), (20, 3, 3), (5, 3, 4), (12, 3, 4)]:
+        tag = f"{N}_{d_min}_{d_max}"
+        edges, inc = O.cell_tables(N, d_min, d_max)
+        assert np.array_equal(inc.numpy().astype(np.uint8), g[f"{tag}/cell_incidence"])
+        assert tuple(g[f"{tag}/dims"]) == O.get_rank2_dim(N, d_min, d_max) == (edges.shape[0], inc.shape[0])
+        flags = torch.from_numpy(g[f"{tag}/flags"])
+        fl, fr = O.rank2_flags(flags, N, d_min, d_max)
+        assert np.array_equal(fl.numpy(), g[f"{tag}/fl"]) and np.array_equal(fr.numpy(), g[f"{tag}/fr"])
+        assert np.array_equal(O.hodge_adj_flags(flags).numpy(), g[f"{tag}/fh"])
+    a = torch.from_numpy(g["util/adj"])
+    assert np.array_equal(O.adj_to_hodgedual(a).numpy(), g["util/hodgedual"])
+    assert np.array_equal(O.hodgedual_to_adj(torch.from_numpy(g["util/hodge_in"])).numpy(), g["util/hodge_to_adj"])
+    r = torch.from_numpy(g["util/rank2"])
+    assert np.array_equal(O.pow_tensor_cc(r, 3, O._nodiag_mask(15)).numpy(), g["util/pow_cc"])
+    assert np.array_equal(O.pow_tensor(a[:, 0], 3).numpy(), g["util/pow_adj"])
+    q = torch.from_numpy(g["util/q_in"])
+    assert np.array_equal(O.quantize(q).numpy(), g["util/quantize"])
+    assert np.array_equal(O.quantize_mol(q), g["util/quantize_mol"])
+    assert O.quantize_mol(q).dtype == np.int64
+
+
+def test_kat_small_models_general_path():
+    """Small nets built by the reference constructors, incl. num_linears_h=2 / num_layers_mlp=2."""
+    g = load_golden("kat_small_models.npz")
+    meta = json.loads(str(g["meta"]))
+    flags, x, adj, rank2 = (torch.from_numpy(g[k]) for k in ("flags", "x", "adj", "rank2"))
+    for tag, params in meta.items():
+        w = {k[len(tag) + 3:]: torch.from_numpy(g[k]).requires_grad_(True) for k in g.files if k.startswith(f"{tag}/w/")}
+        with torch.no_grad():
+            out = O.run_network(params, w, x, adj, rank2, flags)
+        _close(out.numpy(), g[f"{tag}/out"], tag)
+
+
+G5 = [
+    ("ccsd_qm9_CC", "ccsd_qm9_CC", ["k10", "k50", "n1000_first3"]),
+    ("ccsd_community_small_CC", "ccsd_community_small_CC", ["k5", "n1000_first2"]),
+    ("gdss_community_small", "gdss_community_small", ["k10", "n1000_first3"]),
+    ("gdss_zinc250k", "gdss_zinc250k", ["k5"]),
+    ("ccsd_qm9_CC_nsteps2_none", "ccsd_qm9_CC", ["k6"]),
+    ("ccsd_qm9_CC_langevin2", "ccsd_qm9_CC", ["k4"]),
+]
+
+
+def oracle_sampler_from_golden(g, ckpt, case, noise=None):
+    meta, nets = nets_from_ckpt(ckpt)
+    cfg, is_cc = meta["config"], meta["is_cc"]
+    sm = json.loads(str(g["sampler"]))
+    N, Fd = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
+    flags = torch.from_numpy(g["flags"])
+    B = flags.shape[0]
+    num_scales, max_steps = None, None
+    if case.startswith("k"):
+        num_scales = int(case[1:])
+    else:
+        max_steps = int(case.split("first")[1])
+    parts = ["x", "adj"] + (["rank2"] if is_cc else [])
+    sdes = []
+    for p in parts:
+        c = dict(cfg["sde"][p])
+        if num_scales is not None:
+            c["num_scales"] = num_scales
+        sdes.append(O.load_sde(c))
+    kw = dict(sde_x=sdes[0], sde_adj=sdes[1], shape_x=(B, N, Fd), shape_adj=(B, N, N), predictor=sm["predictor"],
+              corrector=sm["corrector"], snr=sm["snr"], scale_eps=sm["scale_eps"], n_steps=sm["n_steps"],
+              probability_flow=False, continuous=True, denoise=True, eps=1e-4, n_diff_steps=max_steps, noise=noise)
+    if is_cc:
+        d_min, d_max = cfg["data"]["d_min"], cfg["data"]["d_max"]
+        kw.update(is_cc=True, sde_rank2=sdes[2], shape_rank2=(B, *O.get_rank2_dim(N, d_min, d_max)), d_min=d_min, d_max=d_max)
+    return O.get_pc_sampler(**kw), nets, flags, parts
+
+
+@pytest.mark.parametrize("gname,ckpt,cases", G5)
+def test_g5_pc_sampler_identical_seed(gname, ckpt, cases):
+    """End-to-end sampler: same seed -> same prior and noise stream -> reference outputs."""
+    g = load_golden(f"g5_{gname}.npz")
+    assert rng_matches(g)
+    for case in cases:
+        fn, nets, flags, parts = oracle_sampler_from_golden(g, ckpt, case)
+        torch.manual_seed(int(g["seed"]))
+        res = fn(*nets, flags)
+        for p, v in zip(parts, res):
+            _close(v.numpy(), g[f"{case}/{p}"], f"{gname} {case} {p}")
+        assert int(res[len(parts)]) == int(g[f"{case}/nfe"])
+        assert len(res[-1]) == int(g[f"{case}/traj_len"])
+        _close(res[-1][-1][1].numpy(), g[f"{case}/traj_last_adj"])
+        # integer outputs: bit-exact
+        assert np.array_equal(O.quantize(res[1]).numpy(), g[f"{case}/quantize_adj"])
+        assert np.array_equal(O.quantize_mol(res[1]), g[f"{case}/quantize_mol_adj"])
+        if "rank2" in parts:
+            assert np.array_equal(O.quantize(res[2]).numpy().astype(np.uint8), g[f"{case}/quantize_rank2"])
+
+
+def test_registry_errors_match_reference():
+    s = O.SDE("VE", 0.1, 1.0, 10)
+    with pytest.raises(NotImplementedError):
+        O.get_pc_sampler(s, s, (1, 3, 2), (1, 3, 3), predictor="Heun", continuous=True)
+    with pytest.raises(NotImplementedError):
+        O.get_pc_sampler(s, s, (1, 3, 2), (1, 3, 3), corrector="MALA", continuous=True)
+    with pytest.raises(NotImplementedError):
+        O.SDE("foo", 0.1, 1.0, 10)
+    with pytest.raises(ValueError):
+        O.run_network({"model_type": "nope"}, {}, None, None, None, None)

@@ -1,0 +1,366 @@
+"""Generate the committed fixtures from the real reference (build container only).
+
+Runs the upstream reference (imported read-only from /root/reference through
+tools/refshim.py) and writes
+
+  ccsd_amd/checkpoints/<name>.npz + <name>.json   neutral-format copies of the shipped
+                                                  checkpoints (weights are data, not source)
+  tests/golden/*.npz                              golden input/output vectors
+
+Nothing here is imported by the product or by the tests; the tests only read the
+.npz/.json files.  Re-run with:  python tools/make_golden.py
+"""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import refshim  # noqa: E402
+
+refshim.install()
+import torch  # noqa: E402
+
+from ccsd.src import solver as ref_solver  # noqa: E402
+from ccsd.src import sde as ref_sde  # noqa: E402
+from ccsd.src import losses as ref_losses  # noqa: E402
+from ccsd.src.utils import loader as ref_loader  # noqa: E402
+from ccsd.src.utils import cc_utils as ref_cc  # noqa: E402
+from ccsd.src.utils import graph_utils as ref_gu  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+CKPT = os.path.join(ROOT, "ccsd_amd", "checkpoints")
+os.makedirs(GOLD, exist_ok=True)
+os.makedirs(CKPT, exist_ok=True)
+
+CHECKPOINTS = {
+    # name -> (relative path, is_cc, sampler yaml)
+    "ccsd_qm9_CC": ("checkpoints/QM9/ccsd_qm9_CC.pth", True),
+    "ccsd_community_small_CC": ("checkpoints/community_small_CC/ccsd_community_small_CC.pth", True),
+    "ccsd_enzymes_small_CC": ("checkpoints/ENZYMES_small_CC/ccsd_enzymes_small_CC.pth", True),
+    "gdss_community_small": ("checkpoints/community_small/gdss_community_small.pth", False),
+    "gdss_zinc250k": ("checkpoints/ZINC250k/gdss_zinc250k.pth", False),
+}
+
+
+def plain(o):
+    """EasyDict / numpy scalars -> plain JSON-able python."""
+    if isinstance(o, dict):
+        return {str(k): plain(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [plain(v) for v in o]
+    if isinstance(o, (np.integer,)):
+        return int(o)
+    if isinstance(o, (np.floating,)):
+        return float(o)
+    return o
+
+
+def export_checkpoint(name):
+    rel, is_cc = CHECKPOINTS[name]
+    ck = refshim.load_reference_ckpt(rel)
+    arrays = {}
+    meta = {"name": name, "source": rel, "is_cc": is_cc, "config": plain(ck["model_config"])}
+    for part in ["x", "adj"] + (["rank2"] if is_cc else []):
+        meta[f"params_{part}"] = plain(ck[f"params_{part}"])
+        sd = ck[f"{part}_state_dict"]
+        for k, v in sd.items():
+            k = k[7:] if k.startswith("module.") else k
+            arrays[f"{part}/{k}"] = v.detach().cpu().numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(CKPT, name + ".npz"), **arrays)
+    with open(os.path.join(CKPT, name + ".json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    return ck
+
+
+def build_models(ck, is_cc):
+    ms = [ref_loader.load_model_from_ckpt(ck["params_x"], ck["x_state_dict"], "cpu"),
+          ref_loader.load_model_from_ckpt(ck["params_adj"], ck["adj_state_dict"], "cpu")]
+    if is_cc:
+        ms.append(ref_loader.load_model_from_ckpt(ck["params_rank2"], ck["rank2_state_dict"], "cpu"))
+    for m in ms:
+        m.eval()
+    return ms
+
+
+def make_flags(B, N, counts):
+    f = torch.zeros(B, N)
+    for b in range(B):
+        f[b, : counts[b % len(counts)]] = 1.0
+    return f
+
+
+def rng_probe(seed):
+    torch.manual_seed(seed)
+    return torch.randn(8).numpy()
+
+
+def masked_state(seed, B, N, Fdim, is_cc, d_min, d_max, flags, scale=1.0):
+    torch.manual_seed(seed)
+    x = ref_gu.mask_x(torch.randn(B, N, Fdim) * scale, flags)
+    a = torch.randn(B, N, N).triu(1) * scale
+    adj = ref_gu.mask_adjs(a + a.transpose(-1, -2), flags)
+    if not is_cc:
+        return x, adj, None
+    E, K = ref_cc.get_rank2_dim(N, d_min, d_max)
+    rank2 = ref_cc.mask_rank2(torch.randn(B, E, K) * scale, N, d_min, d_max, flags)
+    return x, adj, rank2
+
+
+def g1_network_forwards(name, ck, is_cc, B, counts, seed=1234):
+    """G1/G2: per-network forward + score-fn scaling at three t."""
+    cfg = ck["model_config"]
+    N, Fd = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
+    d_min, d_max = (cfg["data"]["d_min"], cfg["data"]["d_max"]) if is_cc else (None, None)
+    models = build_models(ck, is_cc)
+    flags = make_flags(B, N, counts)
+    out = {"flags": flags.numpy(), "seed": seed, "rng_probe": rng_probe(seed)}
+    for tag, scale in (("unit", 1.0), ("small", 0.3)):
+        x, adj, rank2 = masked_state(seed, B, N, Fd, is_cc, d_min, d_max, flags, scale)
+        out[f"{tag}/x"], out[f"{tag}/adj"] = x.numpy(), adj.numpy()
+        if is_cc:
+            out[f"{tag}/rank2_checksum"] = np.array([rank2.double().sum().item(), rank2.abs().double().sum().item()])
+        with torch.no_grad():
+            args = (x, adj, rank2, flags) if is_cc else (x, adj, flags)
+            for part, m in zip(["x", "adj", "rank2"], models):
+                out[f"{tag}/net_{part}"] = m(*args).numpy()
+            # G2 score functions
+            sdes = [ref_loader.load_sde(cfg["sde"][p]) for p in (["x", "adj"] + (["rank2"] if is_cc else []))]
+            for ti, tval in enumerate([1.0, 0.5, 1e-4]):
+                t = torch.ones(B) * tval
+                for part, m, s in zip(["x", "adj", "rank2"], models, sdes):
+                    if tag != "unit" or (part == "rank2" and ti != 1):
+                        continue
+                    fn = (ref_losses.get_score_fn_cc if is_cc else ref_losses.get_score_fn)(s, m, train=False, continuous=True)
+                    out[f"{tag}/score_{part}_t{ti}"] = fn(*args, t).numpy()
+    np.savez_compressed(os.path.join(GOLD, f"g1_{name}.npz"), **out)
+    print("g1", name, {k: v.shape for k, v in out.items() if hasattr(v, "shape") and v.ndim > 1 and "net" in k})
+
+
+def g3_sde_tables():
+    out = {}
+    ts = torch.linspace(1, 1e-4, 1000)
+    out["timesteps"] = ts.numpy()
+    for kind, (bmin, bmax) in {"VP": (0.1, 1.0), "VE": (0.1, 1.0), "VE2": (0.2, 1.0), "subVP": (0.1, 1.0)}.items():
+        k = kind.rstrip("2")
+        s = ref_loader.load_sde(refshim.EasyDict(type=k, beta_min=bmin, beta_max=bmax, num_scales=1000))
+        v = torch.ones(1000, 1, 1) * 0.5
+        out[f"{kind}/timestep_idx"] = (ts * (s.N - 1) / s.T).long().numpy()
+        drift, diff = s.sde(v, ts)
+        out[f"{kind}/sde_drift"], out[f"{kind}/sde_diffusion"] = drift.numpy(), diff.numpy()
+        out[f"{kind}/marginal_std"] = s.marginal_prob(torch.zeros_like(v), ts)[1].numpy()
+        f, G = s.discretize(v, ts)
+        out[f"{kind}/disc_f"], out[f"{kind}/disc_G"] = f.numpy(), G.numpy()
+        if k in ("VP", "subVP"):
+            out[f"{kind}/alphas"] = s.alphas.numpy()
+            out[f"{kind}/discrete_betas"] = s.discrete_betas.numpy()
+        else:
+            out[f"{kind}/discrete_sigmas"] = s.discrete_sigmas.numpy()
+        if k != "subVP":
+            m, std = s.transition(v, ts, -0.5 / 1000)
+            out[f"{kind}/trans_mean"], out[f"{kind}/trans_std"] = m.numpy(), std.numpy()
+    np.savez_compressed(os.path.join(GOLD, "g3_sde_tables.npz"), **out)
+
+
+def g6_masks():
+    out = {}
+    for (N, d_min, d_max) in [(9, 3, 9), (20, 3, 3), (5, 3, 4), (12, 3, 4)]:
+        E, K = ref_cc.get_rank2_dim(N, d_min, d_max)
+        cells = ref_cc.get_cells(N, d_min, d_max)[0]
+        inc = np.zeros((K, N), dtype=np.uint8)
+        for c, s in enumerate(cells):
+            inc[c, sorted(s)] = 1
+        tag = f"{N}_{d_min}_{d_max}"
+        out[f"{tag}/cell_incidence"] = inc
+        out[f"{tag}/dims"] = np.array([E, K])
+        flags = torch.ones(5, N)
+        flags[1, N - 1] = 0
+        flags[2, N - 2:] = 0
+        flags[3, 0] = 0
+        flags[4, 1:N - 1] = 0
+        fl, fr = ref_cc.get_rank2_flags(torch.zeros(5, E, K), N, d_min, d_max, flags)
+        fh = ref_cc.get_hodge_adj_flags(torch.zeros(5, E, E), flags)
+        out[f"{tag}/flags"], out[f"{tag}/fl"], out[f"{tag}/fr"], out[f"{tag}/fh"] = flags.numpy(), fl.numpy(), fr.numpy(), fh.numpy()
+    # small tensor utils
+    torch.manual_seed(7)
+    a = torch.randn(2, 3, 6, 6)
+    a = a + a.transpose(-1, -2)
+    h = ref_cc.adj_to_hodgedual(a)
+    out["util/adj"], out["util/hodgedual"] = a.numpy(), h.numpy()
+    hh = torch.randn(2, 3, 15, 15)
+    out["util/hodge_in"], out["util/hodge_to_adj"] = hh.numpy(), ref_cc.hodgedual_to_adj(hh).numpy()
+    r = torch.randn(2, 15, 20)
+    out["util/rank2"] = r.numpy()
+    out["util/pow_cc"] = ref_cc.pow_tensor_cc(r, 3, ref_cc.default_mask(15)).numpy()
+    out["util/pow_adj"] = ref_gu.pow_tensor(a[:, 0], 3).numpy()
+    q = torch.tensor([[-0.2, 0.49, 0.5, 1.49], [1.5, 2.49, 2.5, 7.0]])
+    out["util/q_in"], out["util/quantize"], out["util/quantize_mol"] = q.numpy(), ref_gu.quantize(q).numpy(), ref_gu.quantize_mol(q)
+    np.savez_compressed(os.path.join(GOLD, "g6_masks_utils.npz"), **out)
+
+
+def g5_pc_runs(name, ck, is_cc, B, counts, sampler_cfg, cases, seed):
+    """G4/G5: end-to-end sampler runs; inputs are regenerated from the seed by the consumer
+    (prior + every in-loop draw come from torch's global CPU generator in reference order)."""
+    cfg = ck["model_config"]
+    N, Fd = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
+    d_min, d_max = (cfg["data"]["d_min"], cfg["data"]["d_max"]) if is_cc else (None, None)
+    models = build_models(ck, is_cc)
+    flags = make_flags(B, N, counts)
+    out = {"flags": flags.numpy(), "seed": seed, "rng_probe": rng_probe(seed),
+           "sampler": json.dumps(sampler_cfg)}
+    for case, (num_scales, max_steps) in cases.items():
+        sdes = []
+        for p in ["x", "adj"] + (["rank2"] if is_cc else []):
+            c = dict(cfg["sde"][p])
+            if num_scales is not None:
+                c["num_scales"] = num_scales
+            sdes.append(ref_loader.load_sde(refshim.EasyDict(c)))
+        kw = dict(sde_x=sdes[0], sde_adj=sdes[1], shape_x=(B, N, Fd), shape_adj=(B, N, N),
+                  predictor=sampler_cfg["predictor"], corrector=sampler_cfg["corrector"], snr=sampler_cfg["snr"],
+                  scale_eps=sampler_cfg["scale_eps"], n_steps=sampler_cfg["n_steps"], probability_flow=False,
+                  continuous=True, denoise=True, eps=1e-4, device="cpu")
+        if is_cc:
+            E, K = ref_cc.get_rank2_dim(N, d_min, d_max)
+            kw.update(is_cc=True, sde_rank2=sdes[2], shape_rank2=(B, E, K), d_min=d_min, d_max=d_max)
+        fn = ref_solver.get_pc_sampler(**kw)
+        orig = ref_solver.trange
+        if max_steps is not None:
+            ref_solver.trange = lambda a, b, **k: range(a, min(b, max_steps))
+        else:
+            ref_solver.trange = lambda a, b, **k: range(a, b)
+        try:
+            torch.manual_seed(seed)
+            res = fn(*models, flags)
+        finally:
+            ref_solver.trange = orig
+        parts = ["x", "adj"] + (["rank2"] if is_cc else [])
+        res = [r.clone() if isinstance(r, torch.Tensor) else r for r in res]  # quantize_mol mutates CPU inputs
+        for p, v in zip(parts, res):
+            out[f"{case}/{p}"] = v.numpy().copy()
+        out[f"{case}/nfe"] = np.array(res[len(parts)])
+        traj = res[-1]
+        out[f"{case}/traj_len"] = np.array(len(traj))
+        out[f"{case}/traj_last_adj"] = traj[-1][1].numpy()
+        out[f"{case}/quantize_adj"] = ref_gu.quantize(res[1]).numpy()
+        out[f"{case}/quantize_mol_adj"] = ref_gu.quantize_mol(res[1].clone())
+        if is_cc:
+            out[f"{case}/quantize_rank2"] = ref_gu.quantize(res[2]).numpy().astype(np.uint8)
+        # distance of the final adjacency to the nearest quantisation threshold (bit-exactness margin)
+        thr = torch.tensor([0.5, 1.5, 2.5])
+        out[f"{case}/min_thr_dist"] = np.array((res[1][..., None] - thr).abs().min().item())
+        print("g5", name, case, "adj absmax", float(res[1].abs().max()), "min thr dist", float(out[f"{case}/min_thr_dist"]))
+    np.savez_compressed(os.path.join(GOLD, f"g5_{name}.npz"), **out)
+
+
+def kat_small_models():
+    """Small randomly initialised networks built by the reference's own constructors (the same
+    hyper-parameter family as its known-answer tests, tests/models/test_ScoreNetwork_A_CC.py:88-115,
+    test_ScoreNetwork_F.py:45-66) including num_linears_h = 2 / num_layers_mlp = 2 (general, non-affine path)."""
+    from ccsd.src.models.ScoreNetwork_A_CC import ScoreNetworkA_CC
+    from ccsd.src.models.ScoreNetwork_F import ScoreNetworkF
+    from ccsd.src.models.ScoreNetwork_X import ScoreNetworkX
+    from ccsd.src.models.ScoreNetwork_A import ScoreNetworkA
+
+    out = {}
+    N, Fd, d_min, d_max = 5, 10, 3, 4
+    pa = dict(max_feat_num=Fd, max_node_num=N, d_min=d_min, d_max=d_max, nhid=4, num_layers=2, num_linears=2,
+              c_init=2, c_hid=2, c_final=2, adim=2, num_heads=2, conv="GCN", conv_hodge="HCN", use_bn=False,
+              is_cc=True, nhid_h=2, num_layers_h=2, num_linears_h=2, c_hid_h=2, c_final_h=2, adim_h=2, num_heads_h=2)
+    pf = dict(num_layers_mlp=2, num_layers=2, num_linears=2, nhid=2, c_hid=3, c_final=2, cnum=2, max_node_num=N,
+              d_min=d_min, d_max=d_max, use_hodge_mask=True, use_bn=False, is_cc=True)
+    px = dict(max_feat_num=Fd, depth=2, nhid=4, use_bn=False, is_cc=True)
+    pg = dict(max_feat_num=Fd, max_node_num=N, nhid=4, num_layers=3, num_linears=2, c_init=2, c_hid=3, c_final=2,
+              adim=4, num_heads=2, conv="GCN", use_bn=False, is_cc=False)
+    torch.manual_seed(42)
+    nets = {"adj": (ScoreNetworkA_CC(**pa), dict(pa, model_type="ScoreNetworkA_CC")),
+            "rank2": (ScoreNetworkF(**pf), dict(pf, model_type="ScoreNetworkF")),
+            "x": (ScoreNetworkX(**px), dict(px, model_type="ScoreNetworkX")),
+            "gadj": (ScoreNetworkA(**pg), dict(pg, model_type="ScoreNetworkA"))}
+    # biases are zero-initialised by the reference; perturb them so bias handling is exercised
+    for m, _ in nets.values():
+        for k, p in m.named_parameters():
+            if k.endswith("bias"):
+                p.data.normal_(0, 0.2)
+        m.eval()
+    B = 3
+    flags = make_flags(B, N, [5, 4, 3])
+    x, adj, rank2 = masked_state(99, B, N, Fd, True, d_min, d_max, flags)
+    out["flags"], out["x"], out["adj"], out["rank2"] = flags.numpy(), x.numpy(), adj.numpy(), rank2.numpy()
+    meta = {}
+    with torch.no_grad():
+        for tag, (m, p) in nets.items():
+            for k, v in m.state_dict().items():
+                out[f"{tag}/w/{k}"] = v.numpy()
+            meta[tag] = p
+            args = (x, adj, flags) if tag == "gadj" else (x, adj, rank2, flags)
+            out[f"{tag}/out"] = m(*args).numpy()
+            # also with unmasked inputs and flags=None semantics (flags all ones)
+    out["meta"] = json.dumps(meta)
+    np.savez_compressed(os.path.join(GOLD, "kat_small_models.npz"), **out)
+
+
+def reference_kat_status():
+    """Run the reference's own known-answer tests for the path in this container and record the result."""
+    files = ["tests/models", "tests/utils/test_graph_utils.py", "tests/utils/test_cc_utils.py",
+             "tests/utils/test_models_utils.py"]
+    code = ("import sys; sys.path.insert(0, %r); import refshim; refshim.install(); import pytest; "
+            "sys.exit(pytest.main(['-q','-p','no:cacheprovider','--no-header','-k',"
+            "'(ScoreNetwork or hodge or mask or noise or quantize or pow_tensor or get_cells or rank2_dim or get_ones or hodgedual or hodge_laplacian or default_mask) and not spectrum',"
+            " *%r]))" % (HERE, files))
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-c", code], cwd=refshim.REFERENCE_ROOT, env=env, capture_output=True, text=True)
+    tail = (r.stdout.strip().splitlines() or [""])[-1]
+    with open(os.path.join(GOLD, "reference_kat_status.json"), "w") as f:
+        json.dump({"returncode": r.returncode, "summary": tail}, f, indent=1)
+    print("reference KATs:", r.returncode, tail)
+
+
+def main():
+    only = set(sys.argv[1:])
+    cks = {}
+    for name in CHECKPOINTS:
+        cks[name] = export_checkpoint(name)
+        print("exported", name)
+    if not only or "g3" in only:
+        g3_sde_tables()
+    if not only or "g6" in only:
+        g6_masks()
+    if not only or "kat" in only:
+        kat_small_models()
+    if not only or "g1" in only:
+        g1_network_forwards("ccsd_qm9_CC", cks["ccsd_qm9_CC"], True, 4, [9, 8, 7, 5])
+        g1_network_forwards("ccsd_community_small_CC", cks["ccsd_community_small_CC"], True, 2, [20, 14])
+        g1_network_forwards("ccsd_enzymes_small_CC", cks["ccsd_enzymes_small_CC"], True, 2, [12, 9])
+        g1_network_forwards("gdss_community_small", cks["gdss_community_small"], False, 4, [20, 18, 14, 12])
+        g1_network_forwards("gdss_zinc250k", cks["gdss_zinc250k"], False, 2, [38, 23])
+    if not only or "g5" in only:
+        g5_pc_runs("ccsd_qm9_CC", cks["ccsd_qm9_CC"], True, 4, [9, 8, 7, 5],
+                   dict(predictor="Reverse", corrector="Langevin", snr=0.2, scale_eps=0.7, n_steps=1),
+                   {"k10": (10, None), "k50": (50, None), "n1000_first3": (None, 3)}, seed=42)
+        g5_pc_runs("ccsd_community_small_CC", cks["ccsd_community_small_CC"], True, 2, [20, 14],
+                   dict(predictor="Euler", corrector="Langevin", snr=0.05, scale_eps=0.7, n_steps=1),
+                   {"k5": (5, None), "n1000_first2": (None, 2)}, seed=12)
+        g5_pc_runs("gdss_community_small", cks["gdss_community_small"], False, 4, [20, 18, 14, 12],
+                   dict(predictor="Euler", corrector="Langevin", snr=0.05, scale_eps=0.7, n_steps=1),
+                   {"k10": (10, None), "n1000_first3": (None, 3)}, seed=12)
+        g5_pc_runs("gdss_zinc250k", cks["gdss_zinc250k"], False, 2, [38, 23],
+                   dict(predictor="Reverse", corrector="Langevin", snr=0.2, scale_eps=0.9, n_steps=1),
+                   {"k5": (5, None)}, seed=42)
+        g5_pc_runs("ccsd_qm9_CC_nsteps2_none", cks["ccsd_qm9_CC"], True, 2, [9, 6],
+                   dict(predictor="Euler", corrector="None", snr=0.2, scale_eps=0.7, n_steps=1),
+                   {"k6": (6, None)}, seed=5)
+        g5_pc_runs("ccsd_qm9_CC_langevin2", cks["ccsd_qm9_CC"], True, 2, [9, 6],
+                   dict(predictor="Reverse", corrector="Langevin", snr=0.2, scale_eps=0.7, n_steps=2),
+                   {"k4": (4, None)}, seed=6)
+    if not only or "refkat" in only:
+        reference_kat_status()
+
+
+if __name__ == "__main__":
+    main()
