@@ -1,0 +1,130 @@
+"""ctypes binding of libccsd_hip.so (include/ccsd_hip.h).
+
+The product path has exactly one backend: the hand-written HIP library built in-tree by
+`__graft_entry__.build()`.  If it is missing, or no MI355X is visible, everything that needs
+compute raises -- there is no CPU or eager-PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(HERE, "libccsd_hip.so")
+
+ABI_VERSION = 1
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_WEIGHTS, ERR_RUNTIME, ERR_WORKSPACE = range(6)
+SDE_VP, SDE_VE, SDE_SUBVP = 0, 1, 2
+PRED_EULER, PRED_REVERSE = 0, 1
+CORR_NONE, CORR_LANGEVIN = 0, 1
+TARGET_X, TARGET_ADJ, TARGET_RANK2 = 0, 1, 2
+
+EXPORTS = [
+    "ccsd_plan_create", "ccsd_plan_destroy", "ccsd_weight_count", "ccsd_rank2_dims", "ccsd_workspace_bytes",
+    "ccsd_last_error", "ccsd_score", "ccsd_init_state", "ccsd_corrector_norms", "ccsd_corrector_apply",
+    "ccsd_predictor", "ccsd_sampler_run", "ccsd_quantize",
+]
+
+
+class StepCoef(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("sscale", "alpha", "pa", "pb", "pc")]
+
+
+class Config(C.Structure):
+    _fields_ = (
+        [(n, C.c_int32) for n in (
+            "abi_version", "N", "F", "is_cc", "d_min", "d_max",
+            "x_depth", "x_nhid",
+            "a_num_layers", "a_num_linears", "a_c_init", "a_c_hid", "a_c_final", "a_nhid", "a_adim", "a_num_heads",
+            "a_is_cc_net", "h_num_layers", "h_num_linears", "h_nhid", "h_adim", "h_c_hid", "h_c_final", "h_num_heads",
+            "f_num_layers", "f_num_linears", "f_nhid", "f_c_hid", "f_c_final", "f_cnum", "f_num_layers_mlp",
+            "f_use_hodge_mask",
+            "predictor", "corrector", "n_corr_steps", "probability_flow", "denoise")]
+        + [("snr", C.c_float), ("scale_eps", C.c_float), ("diff_steps", C.c_int32)]
+    )
+
+
+class State(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("adj", C.c_void_p), ("rank2", C.c_void_p)]
+
+
+class Noise(C.Structure):
+    _fields_ = [("zx", C.c_void_p), ("zadj", C.c_void_p), ("zrank2", C.c_void_p)]
+
+
+class CcsdError(RuntimeError):
+    pass
+
+
+def raise_status(lib, status: int):
+    """Map status codes onto the exception types the reference raises on this path."""
+    if status == OK:
+        return
+    msg = lib.ccsd_last_error().decode("utf-8", "replace")
+    if status == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if status in (ERR_INVALID, ERR_WEIGHTS, ERR_WORKSPACE):
+        raise ValueError(msg)
+    raise CcsdError(msg)
+
+
+class Library:
+    """A loaded C-ABI library with typed entry points."""
+
+    def __init__(self, path: str, is_hip: bool):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.path = path
+        self.is_hip = is_hip
+        L = self.c = C.CDLL(path)
+        vp, i32, i64, u64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
+        P = C.POINTER
+        L.ccsd_plan_create.argtypes = [P(Config), P(C.c_float), sz, P(StepCoef), P(vp)]
+        L.ccsd_plan_create.restype = C.c_int
+        L.ccsd_plan_destroy.argtypes = [vp]
+        L.ccsd_plan_destroy.restype = None
+        L.ccsd_weight_count.argtypes = [P(Config)]
+        L.ccsd_weight_count.restype = sz
+        L.ccsd_rank2_dims.argtypes = [P(Config), P(i32), P(i64)]
+        L.ccsd_rank2_dims.restype = None
+        L.ccsd_workspace_bytes.argtypes = [vp, i32]
+        L.ccsd_workspace_bytes.restype = sz
+        L.ccsd_last_error.argtypes = []
+        L.ccsd_last_error.restype = C.c_char_p
+        L.ccsd_score.argtypes = [vp, i32, i32, P(State), vp, f32, vp, vp, sz, vp]
+        L.ccsd_score.restype = C.c_int
+        L.ccsd_init_state.argtypes = [vp, i32, vp, P(Noise), u64, i64, P(State), vp]
+        L.ccsd_init_state.restype = C.c_int
+        L.ccsd_corrector_norms.argtypes = [vp, i32, i32, i32, P(State), P(State), vp, P(Noise), u64, i64, vp, vp, sz, vp]
+        L.ccsd_corrector_norms.restype = C.c_int
+        L.ccsd_corrector_apply.argtypes = [vp, i32, i32, i32, P(State), vp, P(Noise), u64, i64, vp, P(State), vp, sz, vp]
+        L.ccsd_corrector_apply.restype = C.c_int
+        L.ccsd_predictor.argtypes = [vp, i32, i32, P(State), vp, P(Noise), u64, i64, P(State), P(State), vp, sz, vp]
+        L.ccsd_predictor.restype = C.c_int
+        L.ccsd_sampler_run.argtypes = [vp, i32, vp, u64, i64, i32, i32, P(State), P(State), P(State), vp, vp, sz, vp]
+        L.ccsd_sampler_run.restype = C.c_int
+        L.ccsd_quantize.argtypes = [vp, i64, f32, vp, vp]
+        L.ccsd_quantize.restype = C.c_int
+
+    def __getattr__(self, name):
+        return getattr(self.c, name)
+
+    def check(self, status: int):
+        raise_status(self.c, status)
+
+
+_hip: Optional[Library] = None
+
+
+def get_library() -> Library:
+    """The HIP library.  Fails loudly when it has not been built (python __graft_entry__.py)."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise CcsdError(
+                f"{HIP_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  ccsd_amd has no CPU fallback."
+            )
+        _hip = Library(HIP_LIB_PATH, is_hip=True)
+    return _hip

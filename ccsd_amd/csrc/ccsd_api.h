@@ -1,0 +1,465 @@
+// ccsd_api.h -- host side of the C ABI declared in include/ccsd_hip.h: plan construction,
+// workspace carve-up and the launch sequences of one corrector / predictor half-step.
+// Included once by ccsd_hip.hip (product) and by tests/emu/ccsd_emu.cpp (CPU emulation of the same
+// kernels, test infrastructure only).
+#pragma once
+#include "ccsd_kernels.h"
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_last_error;
+static int set_err(int st, const std::string& m) { g_last_error = m; return st; }
+
+struct ccsd_plan {
+    ccsd_config_t cfg;
+    PlanD h;                    // host copy
+    PlanD* d = nullptr;         // device copy
+    float* w = nullptr;         // device weights
+    unsigned char* edges = nullptr;
+    unsigned long long* cells = nullptr;
+    std::vector<ccsd_step_coef_t> coef;  // [diff_steps][3]
+    size_t nweights = 0;
+};
+
+#define RT_CHECK(expr)                                                                    \
+    do {                                                                                  \
+        rtError_t _e = (expr);                                                            \
+        if (_e != RT_OK) return set_err(CCSD_ERR_RUNTIME, std::string(#expr) + ": " + rt_error_string(_e)); \
+    } while (0)
+#define LAUNCH_CHECK()                                                                    \
+    do {                                                                                  \
+        rtError_t _e = rt_last_error();                                                   \
+        if (_e != RT_OK) return set_err(CCSD_ERR_RUNTIME, std::string("kernel launch: ") + rt_error_string(_e)); \
+    } while (0)
+
+extern "C" const char* ccsd_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" void ccsd_rank2_dims(const ccsd_config_t* cfg, int32_t* E, int64_t* K) {
+    int e = 0; int64_t k = 0;
+    if (cfg) ccsd_dims(cfg, &e, &k);
+    if (E) *E = e;
+    if (K) *K = k;
+}
+
+extern "C" size_t ccsd_weight_count(const ccsd_config_t* cfg) {
+    PlanD p; PlanBuilder pb;
+    size_t n = ccsd_build_plan(cfg, &p, pb);
+    if (pb.status != CCSD_OK) { set_err(pb.status, pb.err); return 0; }
+    return n;
+}
+
+extern "C" void ccsd_plan_destroy(ccsd_plan_t* plan) {
+    if (!plan) return;
+    if (plan->d) (void)rt_free(plan->d);
+    if (plan->w) (void)rt_free(plan->w);
+    if (plan->edges) (void)rt_free(plan->edges);
+    if (plan->cells) (void)rt_free(plan->cells);
+    delete plan;
+}
+
+extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, size_t n_weights,
+                                const ccsd_step_coef_t* step_coef, ccsd_plan_t** out) {
+    if (!cfg || !weights || !step_coef || !out) return set_err(CCSD_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    ccsd_plan* pl = new ccsd_plan();
+    pl->cfg = *cfg;
+    PlanBuilder pb;
+    pl->nweights = ccsd_build_plan(cfg, &pl->h, pb);
+    if (pb.status != CCSD_OK) { delete pl; return set_err(pb.status, pb.err); }
+    if (pl->nweights != n_weights) {
+        delete pl;
+        return set_err(CCSD_ERR_WEIGHTS, "weight blob has " + std::to_string(n_weights) + " floats, config needs " +
+                                             std::to_string(pl->nweights));
+    }
+    if (cfg->predictor != CCSD_PRED_EULER && cfg->predictor != CCSD_PRED_REVERSE) { delete pl; return set_err(CCSD_ERR_UNSUPPORTED, "unknown predictor"); }
+    if (cfg->corrector != CCSD_CORR_NONE && cfg->corrector != CCSD_CORR_LANGEVIN) { delete pl; return set_err(CCSD_ERR_UNSUPPORTED, "unknown corrector"); }
+    if (cfg->diff_steps < 1 || cfg->n_corr_steps < 0) { delete pl; return set_err(CCSD_ERR_INVALID, "bad step counts"); }
+    ccsd_fold_fnet(&pl->h, weights);
+    pl->coef.assign(step_coef, step_coef + (size_t)cfg->diff_steps * 3);
+    // enumeration tables (get_cells, cc_utils.py:72-94): edges = combinations(range(N),2) row-major;
+    // cells = combinations(range(N),k) for k = d_min..d_max, lexicographic, as node bitmasks
+    const int N = cfg->N, E = pl->h.E, K = pl->h.K;
+    std::vector<unsigned char> edges((size_t)2 * E + 2);
+    {
+        int e = 0;
+        for (int i = 0; i < N; ++i)
+            for (int j = i + 1; j < N; ++j) { edges[2 * e] = (unsigned char)i; edges[2 * e + 1] = (unsigned char)j; ++e; }
+    }
+    std::vector<unsigned long long> cells((size_t)K + 1);
+    if (cfg->is_cc) {
+        size_t c = 0;
+        std::vector<int> idx;
+        for (int k = cfg->d_min; k <= cfg->d_max; ++k) {
+            idx.resize(k);
+            for (int i = 0; i < k; ++i) idx[i] = i;
+            while (true) {
+                unsigned long long m = 0;
+                for (int i = 0; i < k; ++i) m |= 1ull << idx[i];
+                cells[c++] = m;
+                int i = k - 1;
+                while (i >= 0 && idx[i] == N - k + i) --i;
+                if (i < 0) break;
+                ++idx[i];
+                for (int j = i + 1; j < k; ++j) idx[j] = idx[j - 1] + 1;
+            }
+        }
+        if ((int)c != K) { delete pl; return set_err(CCSD_ERR_INVALID, "cell enumeration mismatch"); }
+    }
+#define PC(expr) do { rtError_t _e = (expr); if (_e != RT_OK) { ccsd_plan_destroy(pl); return set_err(CCSD_ERR_RUNTIME, std::string(#expr) + ": " + rt_error_string(_e)); } } while (0)
+    PC(rt_malloc((void**)&pl->d, sizeof(PlanD)));
+    PC(rt_h2d(pl->d, &pl->h, sizeof(PlanD)));
+    PC(rt_malloc((void**)&pl->w, n_weights * sizeof(float)));
+    PC(rt_h2d(pl->w, weights, n_weights * sizeof(float)));
+    PC(rt_malloc((void**)&pl->edges, edges.size()));
+    PC(rt_h2d(pl->edges, edges.data(), edges.size()));
+    PC(rt_malloc((void**)&pl->cells, cells.size() * sizeof(unsigned long long)));
+    PC(rt_h2d(pl->cells, cells.data(), cells.size() * sizeof(unsigned long long)));
+#ifndef CCSD_EMU
+    if ((size_t)pl->h.xa_lds_floats * 4 > 64 * 1024) PC(rt_set_max_dyn_smem((const void*)k_xa, (size_t)pl->h.xa_lds_floats * 4));
+#endif
+#undef PC
+    *out = pl;
+    return CCSD_OK;
+}
+
+// ---------------- workspace ----------------
+struct Workspace {
+    unsigned long long* offbits;
+    float *H, *P0, *P1, *acoef, *net_x, *net_adj, *net_r, *norm2, *part, *sums;
+    int ntiles;
+    size_t bytes;
+};
+static Workspace carve_ws(const ccsd_plan* pl, int B, void* base) {
+    const PlanD& p = pl->h;
+    Workspace w{};
+    size_t o = 0;
+    auto take = [&](size_t nbytes) { size_t r = o; o += (nbytes + 255) / 256 * 256; return base ? (char*)base + r : (char*)nullptr; };
+    w.offbits = (unsigned long long*)take((size_t)B * 8);
+    const size_t E = p.E, K = p.K;
+    w.H = (float*)take(p.is_cc ? (size_t)B * E * E * 4 : 0);
+    w.P0 = (float*)take(p.h_L > 0 ? (size_t)B * E * p.hl[0].wc * 4 : 0);
+    w.P1 = (float*)take(p.h_L > 1 ? (size_t)B * E * p.hl[1].wc * 4 : 0);
+    w.acoef = (float*)take(p.h_L > 1 ? (size_t)B * p.a_cinit * E * 4 : 0);
+    w.net_x = (float*)take((size_t)B * p.N * p.F * 4);
+    w.net_adj = (float*)take((size_t)B * p.N * p.N * 4);
+    w.net_r = (float*)take(p.is_cc ? (size_t)B * E * K * 4 : 0);
+    w.norm2 = (float*)take((size_t)B * 4 * 4);
+    w.ntiles = p.is_cc ? ((p.K + T_BN - 1) / T_BN) * ((p.E + T_BM - 1) / T_BM) : 0;
+    w.part = (float*)take((size_t)B * (w.ntiles ? w.ntiles : 1) * 2 * 4);
+    w.sums = (float*)take(64);
+    w.bytes = o;
+    return w;
+}
+extern "C" size_t ccsd_workspace_bytes(const ccsd_plan_t* plan, int32_t B) {
+    if (!plan || B < 1) return 0;
+    return carve_ws(plan, B, nullptr).bytes;
+}
+
+static int grid_for(long long n, int block) {
+    long long g = (n + block - 1) / block;
+    if (g > 2048) g = 2048;   // grid-stride the rest
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+static int check_common(const ccsd_plan* pl, int B, const void* flags, const void* ws, size_t ws_bytes) {
+    if (!pl) return set_err(CCSD_ERR_INVALID, "NULL plan");
+    if (B < 1) return set_err(CCSD_ERR_INVALID, "B must be >= 1");
+    if (!flags) return set_err(CCSD_ERR_INVALID, "NULL flags");
+    if (!ws || ws_bytes < carve_ws(pl, B, nullptr).bytes) return set_err(CCSD_ERR_WORKSPACE, "workspace too small");
+    return CCSD_OK;
+}
+static int check_state(const ccsd_plan* pl, const ccsd_state_t* s, const char* what) {
+    if (!s || !s->x || !s->adj || (pl->h.is_cc && !s->rank2)) return set_err(CCSD_ERR_INVALID, std::string("NULL tensor in ") + what);
+    return CCSD_OK;
+}
+
+static int launch_flagbits(const ccsd_plan* pl, int B, const float* flags, Workspace& w, void* stream) {
+    CCSD_LAUNCH(k_flagbits, dim3(grid_for(B, 256)), dim3(CCSD_NTHREADS), 0, stream, flags, w.offbits, B, pl->h.N);
+    LAUNCH_CHECK();
+    return CCSD_OK;
+}
+
+// H = F F^T (ScoreNetworkF) from `rank2`
+static int launch_h(const ccsd_plan* pl, int B, const float* rank2, Workspace& w, void* stream) {
+    const PlanD& p = pl->h;
+    if (!p.is_cc || p.f_cnum < 2) return CCSD_OK;
+    dim3 g((p.E + T_BN - 1) / T_BN, (p.E + T_BM - 1) / T_BM, B);
+    CCSD_LAUNCH(k_gemm_h, g, dim3(CCSD_NTHREADS), 0, stream, rank2, w.H, p.E, p.K, p.f_hmask);
+    LAUNCH_CHECK();
+    return CCSD_OK;
+}
+// hodge projections for ScoreNetworkA_CC from (adj, rank2)
+static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* rank2, Workspace& w, void* stream) {
+    const PlanD& p = pl->h;
+    if (p.h_L < 1) return CCSD_OK;
+    const int rows = B * p.E;
+    {
+        const HodgeLayerD& h = p.hl[0];
+        dim3 g((h.wc + T_BN - 1) / T_BN, (rows + T_BM - 1) / T_BM, 1);
+        CCSD_LAUNCH(k_gemm_p, g, dim3(CCSD_NTHREADS), 0, stream, rank2, (const float*)pl->w, w.P0, rows, p.E, p.K, h.wc,
+                    h.wcat, 0, h.mval, h.cin, (const float*)nullptr, (const unsigned long long*)w.offbits,
+                    (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells);
+        LAUNCH_CHECK();
+    }
+    if (p.h_L > 1) {
+        CCSD_LAUNCH(k_edgecoef, dim3(B), dim3(CCSD_NTHREADS), (size_t)3 * p.N * p.N * 4, stream, adj, w.acoef, p.N, p.E,
+                    p.a_cinit, (const unsigned char*)pl->edges);
+        LAUNCH_CHECK();
+        const HodgeLayerD& h0 = p.hl[0];
+        const HodgeLayerD& h = p.hl[1];
+        dim3 g((h.wc + T_BN - 1) / T_BN, (rows + T_BM - 1) / T_BM, 1);
+        CCSD_LAUNCH(k_gemm_p, g, dim3(CCSD_NTHREADS), 0, stream, rank2, (const float*)pl->w, w.P1, rows, p.E, p.K, h.wc,
+                    h.wcat, 1, h0.mval, h0.cin, (const float*)w.acoef, (const unsigned long long*)w.offbits,
+                    (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells);
+        LAUNCH_CHECK();
+    }
+    return CCSD_OK;
+}
+static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Workspace& w, void* stream) {
+    xa.P0 = w.P0; xa.P1 = w.P1;
+    CCSD_LAUNCH(k_xa, dim3(B), dim3(CCSD_NTHREADS), (size_t)pl->h.xa_lds_floats * 4, stream, (const PlanD*)pl->d,
+                (const float*)pl->w, (const unsigned char*)pl->edges, xa, na);
+    LAUNCH_CHECK();
+    return CCSD_OK;
+}
+static int launch_hf(const ccsd_plan* pl, int B, const float* rank2, RankEpi& ep, NoiseArgs& na, Workspace& w, void* stream) {
+    const PlanD& p = pl->h;
+    dim3 g((p.K + T_BN - 1) / T_BN, (p.E + T_BM - 1) / T_BM, B);
+    CCSD_LAUNCH(k_hf_score, g, dim3(CCSD_NTHREADS), 0, stream, (const PlanD*)pl->d, (const float*)pl->w, rank2,
+                (const float*)w.H, (const unsigned long long*)w.offbits, (const unsigned char*)pl->edges,
+                (const unsigned long long*)pl->cells, ep, na);
+    LAUNCH_CHECK();
+    return CCSD_OK;
+}
+
+static unsigned int draw_base(const ccsd_plan* pl, int step, int phase) {
+    return 3u + (unsigned)((step * (pl->cfg.n_corr_steps + 1) + phase) * 3);
+}
+static NoiseArgs make_noise(const ccsd_noise_t* n, uint64_t seed, int64_t off, unsigned int base) {
+    NoiseArgs na{};
+    if (n) { na.zx = n->zx; na.zadj = n->zadj; na.zr = n->zrank2; }
+    na.seed = seed; na.b_off = off;
+    na.draw_x = base; na.draw_adj = base + 1; na.draw_r = base + 2;
+    return na;
+}
+
+// ---------------- API ----------------
+extern "C" int ccsd_score(ccsd_plan_t* pl, int32_t target, int32_t B, const ccsd_state_t* in, const float* flags,
+                          float sscale, float* out, void* workspace, size_t ws_bytes, void* stream) {
+    int st = check_common(pl, B, flags, workspace, ws_bytes);
+    if (st) return st;
+    if ((st = check_state(pl, in, "in"))) return st;
+    if (!out) return set_err(CCSD_ERR_INVALID, "NULL out");
+    Workspace w = carve_ws(pl, B, workspace);
+    if ((st = launch_flagbits(pl, B, flags, w, stream))) return st;
+    NoiseArgs na{};
+    if (target == CCSD_TARGET_X || target == CCSD_TARGET_ADJ) {
+        XaArgs xa{};
+        xa.xX = xa.xA = in->x; xa.adjX = xa.adjA = in->adj; xa.flags = flags;
+        xa.do_x = target == CCSD_TARGET_X; xa.do_a = !xa.do_x; xa.mode = MODE_SCORE;
+        xa.ss_x = xa.ss_a = sscale; xa.out_x = xa.out_a = out;
+        if (xa.do_a && (st = launch_p(pl, B, in->adj, in->rank2, w, stream))) return st;
+        return launch_xa(pl, B, xa, na, w, stream);
+    }
+    if (target == CCSD_TARGET_RANK2) {
+        if (!pl->h.is_cc) return set_err(CCSD_ERR_INVALID, "rank2 score requested from a graph-only plan");
+        if ((st = launch_h(pl, B, in->rank2, w, stream))) return st;
+        RankEpi ep{};
+        ep.mode = MODE_SCORE; ep.sscale = sscale; ep.out = out;
+        return launch_hf(pl, B, in->rank2, ep, na, w, stream);
+    }
+    return set_err(CCSD_ERR_UNSUPPORTED, "Object not yet supported. Select from [x, adj, rank2].");
+}
+
+extern "C" int ccsd_init_state(ccsd_plan_t* pl, int32_t B, const float* flags, const ccsd_noise_t* prior, uint64_t seed,
+                               int64_t sample_offset, ccsd_state_t* state, void* stream) {
+    if (!pl || B < 1 || !flags) return set_err(CCSD_ERR_INVALID, "bad argument");
+    int st = check_state(pl, state, "state");
+    if (st) return st;
+    const PlanD& p = pl->h;
+    // the off-bit table lives in front of nothing here: use a small private scratch in the state-free path
+    unsigned long long* offbits = nullptr;
+    RT_CHECK(rt_malloc((void**)&offbits, (size_t)B * 8));
+    CCSD_LAUNCH(k_flagbits, dim3(grid_for(B, 256)), dim3(CCSD_NTHREADS), 0, stream, flags, offbits, B, p.N);
+    NoiseArgs na = make_noise(prior, seed, sample_offset, 0);
+    const long long total = (long long)B * (p.N * p.F + p.N * p.N) + (p.is_cc ? (long long)B * ((p.E + 3) / 4) * p.K : 0);
+    CCSD_LAUNCH(k_init_state, dim3(grid_for(total, 256)), dim3(CCSD_NTHREADS), 0, stream, state->x, state->adj, state->rank2,
+                flags, na, (const unsigned long long*)offbits, (const unsigned char*)pl->edges,
+                (const unsigned long long*)pl->cells, B, p.N, p.F, p.E, p.K, p.is_cc);
+    rtError_t e = rt_last_error();
+#ifndef CCSD_EMU
+    (void)hipStreamSynchronize((hipStream_t)stream);
+#endif
+    (void)rt_free(offbits);
+    if (e != RT_OK) return set_err(CCSD_ERR_RUNTIME, rt_error_string(e));
+    return CCSD_OK;
+}
+
+// phase 1 of the Langevin corrector.  `base` = pre-corrector state, `cur` = per-target current
+// iterate (== base for the first inner step).
+static int corrector_norms(ccsd_plan* pl, int B, int step, int it, const ccsd_state_t* base, const ccsd_state_t* cur,
+                           const float* flags, const ccsd_noise_t* noise, uint64_t seed, int64_t off, float* sums,
+                           Workspace& w, void* stream) {
+    const PlanD& p = pl->h;
+    int st;
+    NoiseArgs na = make_noise(noise, seed, off, draw_base(pl, step, it));
+    // A-net sees (x_0, adj_cur, rank2_0): hodge projections from the base rank2, edge coefficients from adj_cur
+    if ((st = launch_p(pl, B, cur->adj, base->rank2, w, stream))) return st;
+    XaArgs xa{};
+    xa.xX = cur->x; xa.adjX = base->adj;      // score_x(x_cur, adj_0)      solver.py:761
+    xa.xA = base->x; xa.adjA = cur->adj;      // score_adj(x_0, adj_cur)    solver.py:775
+    xa.flags = flags; xa.do_x = xa.do_a = 1; xa.mode = MODE_NORMS;
+    xa.out_x = w.net_x; xa.out_a = w.net_adj; xa.norm2 = w.norm2;
+    if ((st = launch_xa(pl, B, xa, na, w, stream))) return st;
+    if (p.is_cc) {
+        if ((st = launch_h(pl, B, cur->rank2, w, stream))) return st;
+        RankEpi ep{};
+        ep.mode = MODE_NORMS; ep.out = w.net_r; ep.part = w.part;
+        if ((st = launch_hf(pl, B, cur->rank2, ep, na, w, stream))) return st;
+    }
+    CCSD_LAUNCH(k_normsum, dim3(1), dim3(CCSD_NTHREADS), 0, stream, (const float*)w.norm2, (const float*)w.part, B, w.ntiles,
+                p.is_cc, sums);
+    LAUNCH_CHECK();
+    return CCSD_OK;
+}
+static int corrector_apply(ccsd_plan* pl, int B, int step, int it, const ccsd_state_t* cur, const float* flags,
+                           const ccsd_noise_t* noise, uint64_t seed, int64_t off, const float* sums, ccsd_state_t* out,
+                           Workspace& w, void* stream) {
+    const PlanD& p = pl->h;
+    NoiseArgs na = make_noise(noise, seed, off, draw_base(pl, step, it));
+    LangArgs a{};
+    a.x = cur->x; a.adj = cur->adj; a.r = cur->rank2;
+    a.nx = w.net_x; a.nadj = w.net_adj; a.nr = w.net_r;
+    a.ox = out->x; a.oadj = out->adj; a.orr = out->rank2;
+    a.flags = flags; a.sums = sums;
+    for (int t = 0; t < 3; ++t) {
+        const ccsd_step_coef_t& c = pl->coef[(size_t)step * 3 + t];
+        a.ss[t] = c.sscale; a.alpha[t] = c.alpha;
+    }
+    a.snr = p.snr; a.seps = p.seps;
+    a.B = B; a.N = p.N; a.F = p.F; a.E = p.E; a.K = p.K; a.is_cc = p.is_cc;
+    const long long total = (long long)B * (p.N * p.F + p.N * p.N) + (p.is_cc ? (long long)B * ((p.E + 3) / 4) * p.K : 0);
+    CCSD_LAUNCH(k_langevin_apply, dim3(grid_for(total, 256)), dim3(CCSD_NTHREADS), 0, stream, a, na,
+                (const unsigned long long*)w.offbits, (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells);
+    LAUNCH_CHECK();
+    return CCSD_OK;
+}
+static int predictor(ccsd_plan* pl, int B, int step, const ccsd_state_t* in, const float* flags, const ccsd_noise_t* noise,
+                     uint64_t seed, int64_t off, ccsd_state_t* out, ccsd_state_t* mean, Workspace& w, void* stream) {
+    const PlanD& p = pl->h;
+    int st;
+    NoiseArgs na = make_noise(noise, seed, off, draw_base(pl, step, pl->cfg.n_corr_steps));
+    const ccsd_step_coef_t* c = &pl->coef[(size_t)step * 3];
+    if ((st = launch_p(pl, B, in->adj, in->rank2, w, stream))) return st;
+    XaArgs xa{};
+    xa.xX = xa.xA = in->x; xa.adjX = xa.adjA = in->adj; xa.flags = flags;
+    xa.do_x = xa.do_a = 1; xa.mode = MODE_PRED;
+    xa.pa_x = c[0].pa; xa.pb_x = c[0].pb; xa.pc_x = c[0].pc;
+    xa.pa_a = c[1].pa; xa.pb_a = c[1].pb; xa.pc_a = c[1].pc;
+    xa.out_x = out->x; xa.out_a = out->adj;
+    xa.mean_x = mean ? mean->x : nullptr; xa.mean_a = mean ? mean->adj : nullptr;
+    if ((st = launch_xa(pl, B, xa, na, w, stream))) return st;
+    if (p.is_cc) {
+        if ((st = launch_h(pl, B, in->rank2, w, stream))) return st;
+        RankEpi ep{};
+        ep.mode = MODE_PRED; ep.pa = c[2].pa; ep.pb = c[2].pb; ep.pc = c[2].pc;
+        ep.out = out->rank2; ep.mean = mean ? mean->rank2 : nullptr;
+        if ((st = launch_hf(pl, B, in->rank2, ep, na, w, stream))) return st;
+    }
+    return CCSD_OK;
+}
+
+static int check_step(const ccsd_plan* pl, int step) {
+    if (step < 0 || step >= pl->cfg.diff_steps) return set_err(CCSD_ERR_INVALID, "step out of range");
+    return CCSD_OK;
+}
+
+extern "C" int ccsd_corrector_norms(ccsd_plan_t* pl, int32_t B, int32_t step, int32_t corr_iter, const ccsd_state_t* base,
+                                    const ccsd_state_t* cur, const float* flags, const ccsd_noise_t* noise, uint64_t seed,
+                                    int64_t sample_offset, float* norm_sums, void* workspace, size_t ws_bytes, void* stream) {
+    int st = check_common(pl, B, flags, workspace, ws_bytes);
+    if (st || (st = check_step(pl, step)) || (st = check_state(pl, base, "base")) || (st = check_state(pl, cur, "cur"))) return st;
+    if (!norm_sums) return set_err(CCSD_ERR_INVALID, "NULL norm_sums");
+    Workspace w = carve_ws(pl, B, workspace);
+    if ((st = launch_flagbits(pl, B, flags, w, stream))) return st;
+    return corrector_norms(pl, B, step, corr_iter, base, cur, flags, noise, seed, sample_offset, norm_sums, w, stream);
+}
+extern "C" int ccsd_corrector_apply(ccsd_plan_t* pl, int32_t B, int32_t step, int32_t corr_iter, const ccsd_state_t* cur,
+                                    const float* flags, const ccsd_noise_t* noise, uint64_t seed, int64_t sample_offset,
+                                    const float* norm_sums, ccsd_state_t* out, void* workspace, size_t ws_bytes, void* stream) {
+    int st = check_common(pl, B, flags, workspace, ws_bytes);
+    if (st || (st = check_step(pl, step)) || (st = check_state(pl, cur, "cur")) || (st = check_state(pl, out, "out"))) return st;
+    if (!norm_sums) return set_err(CCSD_ERR_INVALID, "NULL norm_sums");
+    Workspace w = carve_ws(pl, B, workspace);
+    if ((st = launch_flagbits(pl, B, flags, w, stream))) return st;
+    return corrector_apply(pl, B, step, corr_iter, cur, flags, noise, seed, sample_offset, norm_sums, out, w, stream);
+}
+extern "C" int ccsd_predictor(ccsd_plan_t* pl, int32_t B, int32_t step, const ccsd_state_t* in, const float* flags,
+                              const ccsd_noise_t* noise, uint64_t seed, int64_t sample_offset, ccsd_state_t* out,
+                              ccsd_state_t* mean, void* workspace, size_t ws_bytes, void* stream) {
+    int st = check_common(pl, B, flags, workspace, ws_bytes);
+    if (st || (st = check_step(pl, step)) || (st = check_state(pl, in, "in")) || (st = check_state(pl, out, "out"))) return st;
+    if (mean && (st = check_state(pl, mean, "mean"))) return st;
+    if (in->x == out->x || in->adj == out->adj || (pl->h.is_cc && in->rank2 == out->rank2))
+        return set_err(CCSD_ERR_INVALID, "predictor cannot run in place");
+    Workspace w = carve_ws(pl, B, workspace);
+    if ((st = launch_flagbits(pl, B, flags, w, stream))) return st;
+    return predictor(pl, B, step, in, flags, noise, seed, sample_offset, out, mean, w, stream);
+}
+
+extern "C" int ccsd_sampler_run(ccsd_plan_t* pl, int32_t B, const float* flags, uint64_t seed, int64_t sample_offset,
+                                int32_t first_step, int32_t last_step, ccsd_state_t* state, ccsd_state_t* scratch,
+                                ccsd_state_t* result, float* traj, void* workspace, size_t ws_bytes, void* stream) {
+    int st = check_common(pl, B, flags, workspace, ws_bytes);
+    if (st || (st = check_state(pl, state, "state")) || (st = check_state(pl, scratch, "scratch")) ||
+        (st = check_state(pl, result, "result"))) return st;
+    if (first_step < 0 || last_step > pl->cfg.diff_steps || first_step >= last_step) return set_err(CCSD_ERR_INVALID, "bad step range");
+    const bool lang = pl->cfg.corrector == CCSD_CORR_LANGEVIN;
+    if (lang && pl->cfg.n_corr_steps != 1)
+        return set_err(CCSD_ERR_UNSUPPORTED, "ccsd_sampler_run handles n_steps == 1; drive other values step by step");
+    const PlanD& p = pl->h;
+    Workspace w = carve_ws(pl, B, workspace);
+    if ((st = launch_flagbits(pl, B, flags, w, stream))) return st;
+    const size_t nx = (size_t)p.N * p.F, na = (size_t)p.N * p.N, nr = p.is_cc ? (size_t)p.E * p.K : 0;
+    ccsd_state_t a = *state, b = *scratch;   // a = live buffer
+    for (int step = first_step; step < last_step; ++step) {
+        const bool lastone = step == last_step - 1;
+        const bool want_mean = pl->cfg.denoise && (lastone || traj);
+        if (lang) {   // a -> (corrector) -> b -> (predictor) -> a
+            if ((st = corrector_norms(pl, B, step, 0, &a, &a, flags, nullptr, seed, sample_offset, w.sums, w, stream))) return st;
+            if ((st = corrector_apply(pl, B, step, 0, &a, flags, nullptr, seed, sample_offset, w.sums, &b, w, stream))) return st;
+            if ((st = predictor(pl, B, step, &b, flags, nullptr, seed, sample_offset, &a, want_mean ? result : nullptr, w, stream))) return st;
+        } else {      // a -> (predictor) -> b, then swap roles
+            if ((st = predictor(pl, B, step, &a, flags, nullptr, seed, sample_offset, &b, want_mean ? result : nullptr, w, stream))) return st;
+            ccsd_state_t t = a; a = b; b = t;
+        }
+        if (traj) {
+            const ccsd_state_t* src = pl->cfg.denoise ? result : &a;
+            float* slot = traj + (size_t)step * (nx + na + nr);
+            RT_CHECK(rt_d2d_async(slot, src->x, nx * 4, stream));
+            RT_CHECK(rt_d2d_async(slot + nx, src->adj, na * 4, stream));
+            if (nr) RT_CHECK(rt_d2d_async(slot + nx + na, src->rank2, nr * 4, stream));
+        }
+    }
+    if (a.x != state->x) {   // odd number of predictor-only steps: bring the live state home
+        RT_CHECK(rt_d2d_async(state->x, a.x, (size_t)B * nx * 4, stream));
+        RT_CHECK(rt_d2d_async(state->adj, a.adj, (size_t)B * na * 4, stream));
+        if (nr) RT_CHECK(rt_d2d_async(state->rank2, a.rank2, (size_t)B * nr * 4, stream));
+    }
+    if (!pl->cfg.denoise) {
+        RT_CHECK(rt_d2d_async(result->x, a.x, (size_t)B * nx * 4, stream));
+        RT_CHECK(rt_d2d_async(result->adj, a.adj, (size_t)B * na * 4, stream));
+        if (nr) RT_CHECK(rt_d2d_async(result->rank2, a.rank2, (size_t)B * nr * 4, stream));
+    }
+    return CCSD_OK;
+}
+
+extern "C" int ccsd_quantize(const float* in, int64_t n, float thr, int64_t* out, void* stream) {
+    if (!in || !out || n < 0) return set_err(CCSD_ERR_INVALID, "bad argument");
+    if (n == 0) return CCSD_OK;
+    CCSD_LAUNCH(k_quantize, dim3(grid_for(n, 256)), dim3(CCSD_NTHREADS), 0, stream, in, (long long)n, thr, (long long*)out);
+    LAUNCH_CHECK();
+    return CCSD_OK;
+}

@@ -1,0 +1,1110 @@
+// ccsd_kernels.h -- hand-written gfx950 kernels for the CCSD predictor-corrector sampling path.
+//
+// Data layout in HBM (all fp32, contiguous, batch-major; same as the reference tensors):
+//   x (B,N,F)   adj (B,N,N)   rank2 (B,E,K)   flags (B,N) of exact 0/1
+//   H (B,E,E) = F F^T (diag zeroed)            P_l (B*E, wc_l) = hodge Q|K projections of layer l
+//
+// Kernels
+//   k_flagbits      flags -> per-sample bitmask of switched-off nodes
+//   k_gemm_h        H = F F^T                      (64x64 MFMA f32 16x16x4 tiles, LDS staged)
+//   k_gemm_p        P_l = A_l(F) . Wcat_l          (same tile engine; A_1 = on-the-fly rank2' of hodge layer 0)
+//   k_edgecoef      triu entries of adj powers     (inputs of the hodge branch)
+//   k_hf_score      (H F) + ScoreNetworkF epilogue + fused predictor update / Langevin norms
+//   k_xa            ScoreNetworkX + ScoreNetworkA(_CC): one workgroup per graph, everything LDS-resident,
+//                   all per-(i,j) MLPs on MFMA through block_linear
+//   k_normsum / k_langevin_apply / k_init_state / k_quantize
+//
+// Reference file:line citations sit next to each restated formula.
+#pragma once
+#include "ccsd_plan.h"
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+CCSD_DEV float elu1(float v) { return v > 0.f ? v : expm1f(v); }  // F.elu, alpha = 1
+
+struct NoiseArgs {
+    const float* zx;
+    const float* zadj;
+    const float* zr;
+    unsigned long long seed;
+    unsigned int draw_x, draw_adj, draw_r;
+    long long b_off;
+};
+
+// Philox4x32-10 (Salmon et al. 2011), counter = (group, sample, draw, 0), key = seed
+CCSD_DEV void philox4(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3, unsigned int k0,
+                      unsigned int k1, unsigned int* out) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0;
+        const unsigned int n1 = (unsigned int)p1;
+        const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1;
+        const unsigned int n3 = (unsigned int)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// four standard normals of group `g` of sample `b` of draw `draw` (Box-Muller on two uniform pairs)
+CCSD_DEV void philox_normal4(unsigned long long seed, unsigned int draw, long long b, unsigned int g, float* n) {
+    unsigned int r[4];
+    philox4(g, (unsigned int)b, draw, (unsigned int)((unsigned long long)b >> 32), (unsigned int)seed,
+            (unsigned int)(seed >> 32), r);
+    const float inv24 = 1.0f / 16777216.0f, twopi = 6.283185307179586f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u1 = (float)((r[2 * h] >> 8) + 1u) * inv24;
+        const float u2 = (float)(r[2 * h + 1] >> 8) * inv24;
+        const float rad = sqrtf(-2.0f * logf(u1));
+        n[2 * h] = rad * cosf(twopi * u2);
+        n[2 * h + 1] = rad * sinf(twopi * u2);
+    }
+}
+CCSD_DEV float philox_normal1(unsigned long long seed, unsigned int draw, long long b, unsigned int idx) {
+    float n[4];
+    philox_normal4(seed, draw, b, idx >> 2, n);
+    const unsigned int s = idx & 3u;
+    return s == 0 ? n[0] : s == 1 ? n[1] : s == 2 ? n[2] : n[3];
+}
+
+// raw draws (before triu/sym/masks), gen_noise graph_utils.py:171
+CCSD_DEV float raw_noise_x(const NoiseArgs& na, int b, int idx, int per_sample) {
+    return na.zx ? na.zx[(size_t)b * per_sample + idx] : philox_normal1(na.seed, na.draw_x, na.b_off + b, (unsigned)idx);
+}
+// symmetric noise: z.triu(1) + transpose -> element (i,j) takes the raw draw at (min,max); diag = 0
+CCSD_DEV float raw_noise_adj(const NoiseArgs& na, int b, int i, int j, int N) {
+    if (i == j) return 0.f;
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const int idx = lo * N + hi;
+    return na.zadj ? na.zadj[(size_t)b * N * N + idx] : philox_normal1(na.seed, na.draw_adj, na.b_off + b, (unsigned)idx);
+}
+// rank2 noise for the four consecutive edge rows 4*eg .. 4*eg+3 at column k (one Philox group)
+CCSD_DEV void raw_noise_r4(const NoiseArgs& na, int b, int eg, int k, int E, int K, float* n) {
+    if (na.zr) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int e = 4 * eg + s;
+            n[s] = e < E ? na.zr[((size_t)b * E + e) * K + k] : 0.f;
+        }
+    } else {
+        philox_normal4(na.seed, na.draw_r, na.b_off + b, (unsigned)(eg * K + k), n);
+    }
+}
+
+// block-wide sum; result valid in every thread.  `red` = 64 floats of LDS.
+CCSD_DEV float block_sum(float v, float* red) {
+#ifdef CCSD_EMU
+    (void)red;
+    return v;
+#else
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < nw; ++w) t += red[w];
+    __syncthreads();
+    return t;
+#endif
+}
+
+// per-thread MLP over at most W features (fully unrolled, predicated: stays in registers).
+// Restates layers.py:260-275 for the tiny channel-mixing MLPs (hodge branch, ScoreNetworkF).
+template <int W>
+CCSD_DEV void small_mlp(const MlpD& m, const float* __restrict__ w, const float* in, float* out) {
+    float a[W], t[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) a[i] = in[i];
+    for (int l = 0; l < m.n; ++l) {
+        const int ni = mlp_in(m, l), no = mlp_out(m, l);
+        const float* wl = w + m.w[l];
+        const float* bl = w + m.b[l];
+#pragma unroll
+        for (int o = 0; o < W; ++o) {
+            float acc = 0.f;
+            if (o < no) {
+                acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < W; ++i)
+                    if (i < ni) acc = fmaf(a[i], wl[o * ni + i], acc);
+                acc += bl[o];
+                if (l < m.n - 1) acc = elu1(acc);
+            }
+            t[o] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < W; ++i) a[i] = t[i];
+    }
+#pragma unroll
+    for (int i = 0; i < W; ++i) out[i] = a[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// block_linear: Y[o][m] = act( sum_k X[k][m] * W[o][k] + b[o] )  for m < rows, o < out.
+// X, Y: LDS, feature-major with row stride ld (ld == 16 mod 32 -> conflict-free fragment reads).
+// W: global, torch Linear layout [out][in].  One MFMA f32 16x16x4 output tile per task, tasks
+// round-robin over the waves of the workgroup.  The accumulation is a k-ordered fmaf chain, the
+// same as the emulation loop below.
+// ---------------------------------------------------------------------------------------------
+template <int ACT>  // 0 none, 1 ELU
+CCSD_DEV void block_linear(float* Y, const float* X, const float* __restrict__ W, const float* __restrict__ bias,
+                           int in, int out, int rows, int ld) {
+#ifdef CCSD_EMU
+    for (int o = 0; o < out; ++o)
+        for (int m = 0; m < rows; ++m) {
+            float acc = 0.f;
+            for (int k = 0; k < in; ++k) acc = fmaf(X[k * ld + m], W[o * in + k], acc);
+            acc += bias[o];
+            Y[o * ld + m] = ACT ? elu1(acc) : acc;
+        }
+#else
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int mt = (rows + 15) >> 4, nt = (out + 15) >> 4, ks = (in + 3) >> 2;
+    const int l15 = lane & 15, kq = lane >> 4;
+    for (int task = wave; task < mt * nt; task += nw) {
+        const int m0 = (task % mt) << 4, n0 = (task / mt) << 4;
+        const int bn = n0 + l15;
+        const float* xr = X + m0 + l15;
+        const float* wr = W + (size_t)(bn < out ? bn : 0) * in;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < ks; ++s) {
+            const int k = 4 * s + kq;
+            const bool kin = k < in;
+            const float a = kin ? xr[k * ld] : 0.f;
+            const float bv = (kin && bn < out) ? wr[k] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
+        }
+        if (bn < out) {
+            const float bb = bias[bn];
+            float* yr = Y + bn * ld + m0 + 4 * kq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[r] + bb;
+                yr[r] = ACT ? elu1(v) : v;
+            }
+        }
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// 64x64 output tile engine for the rank-2 contractions.  LDS slabs As[BK][TLD] (k-major, m fast)
+// and Bs[BK][TLD] (k-major, n fast); 4 waves as 2x2, each wave 32x32 = 2x2 MFMA 16x16x4 tiles.
+// ---------------------------------------------------------------------------------------------
+#define T_BM 64
+#define T_BN 64
+#define T_BK 32
+#define T_LD 80  // 64 + 16: lanes l and l+16 (next k) land on disjoint banks
+
+struct TileAcc {
+#ifdef CCSD_EMU
+    float a[T_BM][T_BN];
+#else
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 a[2][2];
+#endif
+};
+CCSD_DEV void tile_zero(TileAcc& t) {
+#ifdef CCSD_EMU
+    for (int i = 0; i < T_BM; ++i)
+        for (int j = 0; j < T_BN; ++j) t.a[i][j] = 0.f;
+#else
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) t.a[i][j] = (TileAcc::f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
+}
+CCSD_DEV void tile_mma(TileAcc& t, const float* As, const float* Bs) {
+#ifdef CCSD_EMU
+    for (int i = 0; i < T_BM; ++i)
+        for (int j = 0; j < T_BN; ++j) {
+            float acc = t.a[i][j];
+            for (int k = 0; k < T_BK; ++k) acc = fmaf(As[k * T_LD + i], Bs[k * T_LD + j], acc);
+            t.a[i][j] = acc;
+        }
+#else
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32, l15 = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < T_BK / 4; ++s) {
+        const float* ar = As + (4 * s + kq) * T_LD + wm + l15;
+        const float* br = Bs + (4 * s + kq) * T_LD + wn + l15;
+        const float a0 = ar[0], a1 = ar[16], b0 = br[0], b1 = br[16];
+        t.a[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, t.a[0][0], 0, 0, 0);
+        t.a[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, t.a[0][1], 0, 0, 0);
+        t.a[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, t.a[1][0], 0, 0, 0);
+        t.a[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, t.a[1][1], 0, 0, 0);
+    }
+#endif
+}
+// visit the accumulator in groups of four consecutive rows: f(m_local (multiple of 4), n_local, v[4])
+template <class Fn>
+CCSD_DEV void tile_foreach4(TileAcc& t, Fn f) {
+#ifdef CCSD_EMU
+    for (int i = 0; i < T_BM; i += 4)
+        for (int j = 0; j < T_BN; ++j) {
+            float v[4] = {t.a[i][j], t.a[i + 1][j], t.a[i + 2][j], t.a[i + 3][j]};
+            f(i, j, v);
+        }
+#else
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32, l15 = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[4] = {t.a[i][j][0], t.a[i][j][1], t.a[i][j][2], t.a[i][j][3]};
+            f(wm + 16 * i + 4 * kq, wn + 16 * j + l15, v);
+        }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_flagbits: offbits[b] has bit n set iff flags[b][n] == 0  (get_rank2_flags tests `flags == 0`,
+// cc_utils.py:549)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_flagbits(const float* __restrict__ flags, unsigned long long* __restrict__ offbits, int B, int N) {
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+        unsigned long long m = 0;
+        for (int n = 0; n < N; ++n)
+            if (flags[(size_t)b * N + n] == 0.f) m |= 1ull << n;
+        offbits[b] = m;
+    }
+}
+CCSD_DEV float edge_on(unsigned long long off, const unsigned char* __restrict__ edges, int e) {
+    return ((off >> edges[2 * e]) | (off >> edges[2 * e + 1])) & 1ull ? 0.f : 1.f;
+}
+CCSD_DEV float cell_on(unsigned long long off, const unsigned long long* __restrict__ cells, int k) {
+    return (cells[k] & off) ? 0.f : 1.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gemm_h: H[b] = (F[b] F[b]^T) * hodge_mask           hodge_laplacian + mask, cc_utils.py:929, 964-969
+// grid (ceil(E/64), ceil(E/64), B)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gemm_h(const float* __restrict__ rank2, float* __restrict__ H, int E, int K,
+                                                int zero_diag) {
+    __shared__ float As[T_BK * T_LD];
+    __shared__ float Bs[T_BK * T_LD];
+    const int b = blockIdx.z, m0 = blockIdx.y * T_BM, n0 = blockIdx.x * T_BN;
+    const float* Fb = rank2 + (size_t)b * E * K;
+    TileAcc acc;
+    tile_zero(acc);
+    for (int k0 = 0; k0 < K; k0 += T_BK) {
+        for (int idx = threadIdx.x; idx < T_BM * T_BK; idx += blockDim.x) {
+            const int r = idx / T_BK, kk = idx % T_BK, k = k0 + kk;
+            const int ra = m0 + r, rb = n0 + r;
+            As[kk * T_LD + r] = (ra < E && k < K) ? Fb[(size_t)ra * K + k] : 0.f;
+            Bs[kk * T_LD + r] = (rb < E && k < K) ? Fb[(size_t)rb * K + k] : 0.f;
+        }
+        __syncthreads();
+        tile_mma(acc, As, Bs);
+        __syncthreads();
+    }
+    float* Hb = H + (size_t)b * E * E;
+    tile_foreach4(acc, [&](int ml, int nl, const float* v) {
+        const int n = n0 + nl;
+        if (n >= E) return;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int m = m0 + ml + s;
+            if (m < E) Hb[(size_t)m * E + n] = (zero_diag && m == n) ? 0.f : v[s];
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gemm_p: P[r][c] = sum_k A(r,k) * Wcat[k][c]   over the flattened rows r = b*E + e.
+// layer 0: A = rank2 as given                               (DenseHCNConv out = rank2 @ W, hodge_layers.py:185)
+// layer 1: A = rank2' = mask_rank2(mlp_value(stack_c a_c[e]*rank2[e,k]))   (hodge_attention.py:107,322-323
+//          with the layer-0 hodge adjacency diagonal, cc_utils.py:1536) -- produced on the fly, never stored.
+// grid (ceil(wc/64), ceil(B*E/64), 1)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gemm_p(const float* __restrict__ rank2, const float* __restrict__ W,
+                                                float* __restrict__ P, int rows, int E, int K, int wc, int wcat_off,
+                                                int layer, MlpD mval, int cin, const float* __restrict__ acoef,
+                                                const unsigned long long* __restrict__ offbits,
+                                                const unsigned char* __restrict__ edges,
+                                                const unsigned long long* __restrict__ cells) {
+    __shared__ float As[T_BK * T_LD];
+    __shared__ float Bs[T_BK * T_LD];
+    const int m0 = blockIdx.y * T_BM, n0 = blockIdx.x * T_BN;
+    const float* Wc = W + wcat_off;
+    TileAcc acc;
+    tile_zero(acc);
+    for (int k0 = 0; k0 < K; k0 += T_BK) {
+        for (int idx = threadIdx.x; idx < T_BM * T_BK; idx += blockDim.x) {
+            const int r = idx / T_BK, kk = idx % T_BK, k = k0 + kk, row = m0 + r;
+            float v = 0.f;
+            if (row < rows && k < K) {
+                v = rank2[(size_t)row * K + k];
+                if (layer == 1) {
+                    const int b = row / E, e = row % E;
+                    const unsigned long long off = offbits[b];
+                    float in[CCSD_SMALLW], out[CCSD_SMALLW];
+#pragma unroll
+                    for (int c = 0; c < CCSD_SMALLW; ++c) in[c] = c < cin ? acoef[((size_t)b * cin + c) * E + e] * v : 0.f;
+                    small_mlp<CCSD_SMALLW>(mval, W, in, out);
+                    v = edge_on(off, edges, e) * out[0] * cell_on(off, cells, k);
+                }
+            }
+            As[kk * T_LD + r] = v;
+        }
+        for (int idx = threadIdx.x; idx < T_BK * T_BN; idx += blockDim.x) {
+            const int kk = idx / T_BN, c = idx % T_BN, k = k0 + kk, col = n0 + c;
+            Bs[kk * T_LD + c] = (k < K && col < wc) ? Wc[(size_t)k * wc + col] : 0.f;
+        }
+        __syncthreads();
+        tile_mma(acc, As, Bs);
+        __syncthreads();
+    }
+    tile_foreach4(acc, [&](int ml, int nl, const float* v) {
+        const int n = n0 + nl;
+        if (n >= wc) return;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int m = m0 + ml + s;
+            if (m < rows) P[(size_t)m * wc + n] = v[s];
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_edgecoef: acoef[b][c][e] = (adj^(c+1))[i_e][j_e]      pow_tensor + adj_to_hodgedual,
+// graph_utils.py:285-292, cc_utils.py:1525-1536.  One workgroup per graph; LDS: 3*N*N floats.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_edgecoef(const float* __restrict__ adj, float* __restrict__ acoef, int N, int E, int cinit,
+                           const unsigned char* __restrict__ edges) {
+    CCSD_DYN_SMEM(sm);
+    float* A = sm;
+    float* P0 = sm + N * N;
+    float* P1 = sm + 2 * N * N;
+    const int b = blockIdx.x, NN = N * N;
+    for (int i = threadIdx.x; i < NN; i += blockDim.x) { A[i] = adj[(size_t)b * NN + i]; P0[i] = A[i]; }
+    __syncthreads();
+    for (int c = 0; c < cinit; ++c) {
+        for (int e = threadIdx.x; e < E; e += blockDim.x)
+            acoef[((size_t)b * cinit + c) * E + e] = P0[edges[2 * e] * N + edges[2 * e + 1]];
+        if (c + 1 < cinit) {
+            for (int i = threadIdx.x; i < NN; i += blockDim.x) {
+                const int r = i / N, cc = i % N;
+                float acc = 0.f;
+                for (int k = 0; k < N; ++k) acc = fmaf(P0[r * N + k], A[k * N + cc], acc);
+                P1[i] = acc;
+            }
+            __syncthreads();
+            float* t = P0; P0 = P1; P1 = t;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_hf_score: ScoreNetworkF.  Tile (edge rows m0.., cell columns n0..) of  H.F  on MFMA, then per
+// element the channel MLP stack of ScoreNetwork_F.py:198-217 and one of three fused epilogues.
+// grid (ceil(K/64), ceil(E/64), B)
+// ---------------------------------------------------------------------------------------------
+enum { MODE_SCORE = 0, MODE_NORMS = 1, MODE_PRED = 2 };
+
+struct RankEpi {
+    int mode;
+    float sscale;            // MODE_SCORE: out = sscale * net
+    float pa, pb, pc;        // MODE_PRED
+    float* out;              // SCORE: score; NORMS: raw net output (kept for the apply pass); PRED: new state
+    float* mean;             // PRED: nullable
+    float* part;             // NORMS: [B][ntiles][2] partial sums of net^2 and z^2
+};
+
+CCSD_DEV float fnet_element(const PlanD& p, const float* __restrict__ w, float f, float hf, float m) {
+    if (p.f_affine) return m * fmaf(p.f_alpha, f, fmaf(p.f_beta, hf, p.f_gamma));
+    // general path: channels [F, HF] -> L x (MLP, mask) -> concat -> final MLP -> mask
+    float ch[CCSD_FW];
+#pragma unroll
+    for (int i = 0; i < CCSD_FW; ++i) ch[i] = 0.f;
+    ch[0] = f;
+    if (p.f_cnum == 2) ch[1] = hf;
+    int ci0 = 0, co0 = p.f_cnum;
+    for (int l = 0; l < p.f_L; ++l) {
+        float in[CCSD_FW], out[CCSD_FW];
+#pragma unroll
+        for (int i = 0; i < CCSD_FW; ++i) {
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < CCSD_FW; ++j)
+                if (j == ci0 + i) v = ch[j];
+            in[i] = v;
+        }
+        small_mlp<CCSD_FW>(p.fl[l], w, in, out);
+        const int no = p.fl[l].out;
+#pragma unroll
+        for (int j = 0; j < CCSD_FW; ++j)
+#pragma unroll
+            for (int i = 0; i < CCSD_FW; ++i)
+                if (i < no && j == co0 + i) ch[j] = m * out[i];   // mask_rank2 after every layer (hodge_layers.py:90)
+        ci0 = co0; co0 += no;
+    }
+    float out[CCSD_FW];
+    small_mlp<CCSD_FW>(p.f_fin, w, ch, out);
+    return m * out[0];
+}
+
+__global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan, const float* __restrict__ w,
+                                                  const float* __restrict__ rank2, const float* __restrict__ H,
+                                                  const unsigned long long* __restrict__ offbits,
+                                                  const unsigned char* __restrict__ edges,
+                                                  const unsigned long long* __restrict__ cells, RankEpi ep,
+                                                  NoiseArgs na) {
+    __shared__ float As[T_BK * T_LD];
+    __shared__ float Bs[T_BK * T_LD];
+    __shared__ float red[64];
+    const PlanD& p = *plan;
+    const int E = p.E, K = p.K;
+    const int b = blockIdx.z, m0 = blockIdx.y * T_BM, n0 = blockIdx.x * T_BN;
+    const float* Fb = rank2 + (size_t)b * E * K;
+    const float* Hb = H + (size_t)b * E * E;
+    TileAcc acc;
+    tile_zero(acc);
+    if (p.f_cnum == 2) {
+        for (int k0 = 0; k0 < E; k0 += T_BK) {
+            for (int idx = threadIdx.x; idx < T_BM * T_BK; idx += blockDim.x) {
+                const int r = idx / T_BK, kk = idx % T_BK, k = k0 + kk, row = m0 + r;
+                As[kk * T_LD + r] = (row < E && k < E) ? Hb[(size_t)row * E + k] : 0.f;
+            }
+            for (int idx = threadIdx.x; idx < T_BK * T_BN; idx += blockDim.x) {
+                const int kk = idx / T_BN, c = idx % T_BN, k = k0 + kk, col = n0 + c;
+                Bs[kk * T_LD + c] = (k < E && col < K) ? Fb[(size_t)k * K + col] : 0.f;
+            }
+            __syncthreads();
+            tile_mma(acc, As, Bs);
+            __syncthreads();
+        }
+    }
+    const unsigned long long off = offbits[b];
+    float s_net = 0.f, s_z = 0.f;
+    tile_foreach4(acc, [&](int ml, int nl, const float* hf) {
+        const int k = n0 + nl, e0 = m0 + ml;
+        if (k >= K || e0 >= E) return;
+        const float fr = cell_on(off, cells, k);
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ep.mode != MODE_SCORE) raw_noise_r4(na, b, e0 >> 2, k, E, K, z);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int e = e0 + s;
+            if (e >= E) continue;
+            const size_t gi = ((size_t)b * E + e) * K + k;
+            const float f = Fb[(size_t)e * K + k];
+            const float m = edge_on(off, edges, e) * fr;          // flags_left * flags_right, cc_utils.py:590
+            const float net = fnet_element(p, w, f, hf[s], m);
+            const float zz = z[s] * m;                            // gen_noise_rank2, cc_utils.py:613-615
+            if (ep.mode == MODE_SCORE) {
+                ep.out[gi] = ep.sscale * net;
+            } else if (ep.mode == MODE_NORMS) {
+                ep.out[gi] = net;
+                s_net = fmaf(net, net, s_net);
+                s_z = fmaf(zz, zz, s_z);
+            } else {
+                const float mean = fmaf(ep.pa, f, ep.pb * net);   // v_mean = pa*v + pb*net
+                if (ep.mean) ep.mean[gi] = mean;
+                ep.out[gi] = fmaf(ep.pc, zz, mean);
+            }
+        }
+    });
+    if (ep.mode == MODE_NORMS) {
+        const float tn = block_sum(s_net, red);
+        const float tz = block_sum(s_z, red);
+        if (threadIdx.x == 0) {
+            const int tile = blockIdx.y * gridDim.x + blockIdx.x, nt = gridDim.x * gridDim.y;
+            ep.part[((size_t)b * nt + tile) * 2 + 0] = tn;
+            ep.part[((size_t)b * nt + tile) * 2 + 1] = tz;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_xa: ScoreNetworkX + ScoreNetworkA / ScoreNetworkA_CC for one graph per workgroup.
+// ---------------------------------------------------------------------------------------------
+struct XaArgs {
+    // inputs: the X-network and the A-network may see different (x, adj) when the Langevin
+    // corrector runs more than one inner step (solver.py:759-784)
+    const float* xX; const float* adjX;
+    const float* xA; const float* adjA;
+    const float* flags;
+    const float* P0; const float* P1;     // hodge projections (B*E, wc_l)
+    int do_x, do_a;
+    int mode;
+    float ss_x, ss_a;                     // MODE_SCORE scaling
+    float pa_x, pb_x, pc_x, pa_a, pb_a, pc_a;
+    float* out_x; float* out_a;           // SCORE: scores; NORMS: raw nets; PRED: new state
+    float* mean_x; float* mean_a;         // PRED, nullable
+    float* norm2;                         // NORMS: [B][4] = |net_x|^2, |net_adj|^2, |z_x|^2, |z_adj|^2
+};
+
+// D^-1/2 (A + self loops) D^-1/2 of one channel into `an`   (DenseGCNConv, layers.py:139-147)
+CCSD_DEV void gcn_normalize(const float* a, float* an, float* deg, int N) {
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        float s = 0.f;
+        for (int j = 0; j < N; ++j) s += (i == j) ? 1.f : a[i * N + j];
+        deg[i] = 1.0f / sqrtf(fmaxf(s, 1.f));
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < N * N; t += blockDim.x) {
+        const int i = t / N, j = t % N;
+        const float v = (i == j) ? 1.f : a[t];
+        an[t] = deg[i] * v * deg[j];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_xa(const PlanD* __restrict__ plan, const float* __restrict__ w,
+                                            const unsigned char* __restrict__ edges, XaArgs xa, NoiseArgs na) {
+    CCSD_DYN_SMEM(sm);
+    const PlanD& p = *plan;
+    const int N = p.N, F = p.F, NN = N * N, E = p.E, ldn = p.ldn;
+    const int b = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    float* s_flags = sm + p.o_flags;
+    float* s_x = sm + p.o_x;
+    float* s_adj = sm + p.o_adj;
+    float* s_an = sm + p.o_an;
+    float* s_tmp = sm + p.o_tmp;
+    float* s_xw = sm + p.o_xw;
+    float* s_qkv = sm + p.o_qkv;
+    float* s_red = sm + p.o_red;
+
+    for (int i = tid; i < N; i += nth) s_flags[i] = xa.flags[(size_t)b * N + i];
+    float nx_net = 0.f, nx_z = 0.f, na_net = 0.f, na_z = 0.f;
+
+    // ================= ScoreNetworkX (ScoreNetwork_X.py:102-132) =================
+    if (xa.do_x) {
+        float* s_xcat = sm + p.o_xcat;
+        float* s_h1 = sm + p.o_h1;
+        float* s_h2 = sm + p.o_h2;
+        for (int i = tid; i < N * F; i += nth) s_x[i] = xa.xX[(size_t)b * N * F + i];
+        for (int i = tid; i < NN; i += nth) s_adj[i] = xa.adjX[(size_t)b * NN + i];
+        __syncthreads();
+        gcn_normalize(s_adj, s_an, s_tmp, N);
+        for (int t = tid; t < N * F; t += nth) s_xcat[(t % F) * ldn + t / F] = s_x[t];
+        __syncthreads();
+        const int H = p.x_nhid;
+        for (int l = 0; l < p.x_depth; ++l) {
+            const int fin = l ? H : F;
+            const float* src = s_xcat + (l ? (F + (l - 1) * H) : 0) * ldn;
+            const float* W = w + p.x_gw[l];
+            const float* B = w + p.x_gb[l];
+            for (int t = tid; t < N * H; t += nth) {  // out = x @ W
+                const int i = t / H, o = t % H;
+                float acc = 0.f;
+                for (int k = 0; k < fin; ++k) acc = fmaf(src[k * ldn + i], W[k * H + o], acc);
+                s_xw[t] = acc;
+            }
+            __syncthreads();
+            float* dst = s_xcat + (F + l * H) * ldn;
+            for (int t = tid; t < N * H; t += nth) {  // tanh(adj_n @ out + b)
+                const int i = t / H, o = t % H;
+                float acc = 0.f;
+                for (int j = 0; j < N; ++j) acc = fmaf(s_an[i * N + j], s_xw[j * H + o], acc);
+                dst[o * ldn + i] = tanhf(acc + B[o]);
+            }
+            __syncthreads();
+        }
+        const MlpD& m = p.x_fin;
+        block_linear<1>(s_h1, s_xcat, w + m.w[0], w + m.b[0], m.in, m.hid, N, ldn);
+        __syncthreads();
+        block_linear<1>(s_h2, s_h1, w + m.w[1], w + m.b[1], m.hid, m.hid, N, ldn);
+        __syncthreads();
+        block_linear<0>(s_h1, s_h2, w + m.w[2], w + m.b[2], m.hid, m.out, N, ldn);
+        __syncthreads();
+        for (int t = tid; t < N * F; t += nth) {
+            const int i = t / F, f = t % F;
+            const float fl = s_flags[i];
+            const float net = s_h1[f * ldn + i] * fl;                   // mask_x, graph_utils.py:37
+            const size_t gi = (size_t)b * N * F + t;
+            if (xa.mode == MODE_SCORE) {
+                xa.out_x[gi] = xa.ss_x * net;
+            } else {
+                const float z = raw_noise_x(na, b, t, N * F) * fl;       // gen_noise(sym=False)
+                if (xa.mode == MODE_NORMS) {
+                    xa.out_x[gi] = net;
+                    nx_net = fmaf(net, net, nx_net);
+                    nx_z = fmaf(z, z, nx_z);
+                } else {
+                    const float mean = fmaf(xa.pa_x, s_x[t], xa.pb_x * net);
+                    if (xa.mean_x) xa.mean_x[gi] = mean;
+                    xa.out_x[gi] = fmaf(xa.pc_x, z, mean);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ================= ScoreNetworkA / ScoreNetworkA_CC =================
+    if (xa.do_a) {
+        float* s_chan = sm + p.o_chan;
+        float* s_att = sm + p.o_att;
+        float* s_xcur = sm + p.o_xcur;
+        float* s_xnext = sm + p.o_xnext;
+        float* s_mch = sm + p.o_vcat;
+        float* s_c0 = sm + p.o_c0;
+        float* s_c1 = sm + p.o_c1;
+        const int ldp = p.ldp, pch = p.pch;
+        for (int t = tid; t < N * F; t += nth) {
+            const float v = xa.xA[(size_t)b * N * F + t];
+            s_xcur[(t % F) * ldn + t / F] = v;
+        }
+        for (int i = tid; i < NN; i += nth) { const float v = xa.adjA[(size_t)b * NN + i]; s_adj[i] = v; s_chan[i] = v; }
+        __syncthreads();
+        // pow_tensor: channel c = channel(c-1) @ adj   (graph_utils.py:285-292)
+        for (int c = 1; c < p.a_cinit; ++c) {
+            for (int t = tid; t < NN; t += nth) {
+                const int i = t / N, j = t % N;
+                float acc = 0.f;
+                for (int k = 0; k < N; ++k) acc = fmaf(s_chan[(c - 1) * NN + i * N + k], s_adj[k * N + j], acc);
+                s_chan[c * NN + t] = acc;
+            }
+            __syncthreads();
+        }
+        // ---- AttentionLayer stack (attention.py:270-304)
+        for (int l = 0; l < p.a_L; ++l) {
+            const AttnLayerD& L = p.al[l];
+            const int cols = 2 * L.adim + L.fout;
+            const float inv_scale = (float)sqrt((double)L.fout);  // attention.py:121: / math.sqrt(out_dim)
+            // multi_channel MLP, first Linear: its input is cat_c V_c, so accumulate channel by channel
+            for (int t = tid; t < L.mc.hid * N; t += nth) s_mch[(t / N) * ldn + t % N] = w[L.mc.b[0] + t / N];
+            for (int c = 0; c < L.cin; ++c) {
+                const float* ac = s_chan + (L.ci0 + c) * NN;
+                const float* wb = w + L.attn_base + c * L.attn_stride;
+                const float* Wq = wb;
+                const float* bq = Wq + L.fin * L.adim;
+                const float* Wk = bq + L.adim;
+                const float* bk = Wk + L.fin * L.adim;
+                const float* Wv = bk + L.adim;
+                const float* bv = Wv + L.fin * L.fout;
+                gcn_normalize(ac, s_an, s_tmp, N);
+                for (int t = tid; t < N * cols; t += nth) {  // x @ [Wq | Wk | Wv]
+                    const int i = t / cols, col = t % cols;
+                    const float* W; int o, ow;
+                    if (col < L.adim) { W = Wq; o = col; ow = L.adim; }
+                    else if (col < 2 * L.adim) { W = Wk; o = col - L.adim; ow = L.adim; }
+                    else { W = Wv; o = col - 2 * L.adim; ow = L.fout; }
+                    float acc = 0.f;
+                    for (int k = 0; k < L.fin; ++k) acc = fmaf(s_xcur[k * ldn + i], W[k * ow + o], acc);
+                    s_xw[t] = acc;
+                }
+                __syncthreads();
+                for (int t = tid; t < N * cols; t += nth) {  // adj_n @ (.) + bias
+                    const int i = t / cols, col = t % cols;
+                    float acc = 0.f;
+                    for (int j = 0; j < N; ++j) acc = fmaf(s_an[i * N + j], s_xw[j * cols + col], acc);
+                    const float bb = col < L.adim ? bq[col] : col < 2 * L.adim ? bk[col - L.adim] : bv[col - 2 * L.adim];
+                    s_qkv[t] = acc + bb;
+                }
+                __syncthreads();
+                // head chunks: tanh(Q_h K_h^T / sqrt(out_dim)), mean over chunks (attention.py:111-129)
+                for (int t = tid; t < NN; t += nth) {
+                    const int i = t / N, j = t % N;
+                    float s = 0.f;
+                    for (int h = 0; h < L.nchunk; ++h) {
+                        float d = 0.f;
+                        for (int q = 0; q < L.dsplit; ++q)
+                            d = fmaf(s_qkv[i * cols + h * L.dsplit + q], s_qkv[j * cols + L.adim + h * L.dsplit + q], d);
+                        s += tanhf(d / inv_scale);
+                    }
+                    s_tmp[t] = s / (float)L.nchunk;
+                }
+                for (int t = tid; t < L.mc.hid * N; t += nth) {  // += W0[:, c-th block] . V_c
+                    const int hh = t / N, i = t % N;
+                    const float* w0 = w + L.mc.w[0] + hh * L.mc.in + c * L.fout;
+                    float acc = s_mch[hh * ldn + i];
+                    for (int o = 0; o < L.fout; ++o) acc = fmaf(s_qkv[i * cols + 2 * L.adim + o], w0[o], acc);
+                    s_mch[hh * ldn + i] = acc;
+                }
+                __syncthreads();
+                for (int t = tid; t < NN; t += nth) {  // symmetrise (attention.py:130)
+                    const int i = t / N, j = t % N;
+                    s_att[c * NN + t] = (s_tmp[t] + s_tmp[j * N + i]) / 2.f;
+                }
+                __syncthreads();
+            }
+            // node update: tanh(mask_x(multi_channel(cat V_c)))  (attention.py:292-293)
+            for (int t = tid; t < L.mc.hid * N; t += nth) { float* q = s_mch + (t / N) * ldn + t % N; *q = elu1(*q); }
+            __syncthreads();
+            block_linear<0>(s_xnext, s_mch, w + L.mc.w[1], w + L.mc.b[1], L.mc.hid, L.mc.out, N, ldn);
+            __syncthreads();
+            for (int t = tid; t < N * L.fout; t += nth) {
+                const int o = t / N, i = t % N;
+                s_xnext[o * ldn + i] = tanhf(s_xnext[o * ldn + i] * s_flags[i]);
+            }
+            // edge update: MLP over [attention_c | adj_c] per (i,j)  (attention.py:295-300), chunked
+            float* chan_out = s_chan + L.co0 * NN;
+            for (int p0 = 0; p0 < NN; p0 += pch) {
+                const int rows = (NN - p0) < pch ? (NN - p0) : pch;
+                __syncthreads();
+                for (int t = tid; t < 2 * L.cin * rows; t += nth) {
+                    const int f = t / rows, r = t % rows;
+                    s_c0[f * ldp + r] = f < L.cin ? s_att[f * NN + p0 + r] : s_chan[(L.ci0 + f - L.cin) * NN + p0 + r];
+                }
+                __syncthreads();
+                float* cur = s_c0; float* nxt = s_c1;
+                for (int i = 0; i < L.mlp.n; ++i) {
+                    if (i < L.mlp.n - 1) block_linear<1>(nxt, cur, w + L.mlp.w[i], w + L.mlp.b[i], mlp_in(L.mlp, i), mlp_out(L.mlp, i), rows, ldp);
+                    else block_linear<0>(nxt, cur, w + L.mlp.w[i], w + L.mlp.b[i], mlp_in(L.mlp, i), mlp_out(L.mlp, i), rows, ldp);
+                    __syncthreads();
+                    float* t2 = cur; cur = nxt; nxt = t2;
+                }
+                for (int t = tid; t < L.cout * rows; t += nth) {
+                    const int o = t / rows, r = t % rows;
+                    chan_out[o * NN + p0 + r] = cur[o * ldp + r];
+                }
+            }
+            __syncthreads();
+            // _adj + _adj^T, then mask_adjs (attention.py:301-302); in place per unordered pair
+            for (int t = tid; t < L.cout * NN; t += nth) {
+                const int o = t / NN, ij = t % NN, i = ij / N, j = ij % N;
+                if (i > j) continue;
+                float* m = chan_out + o * NN;
+                const float s = (m[i * N + j] + m[j * N + i]) * s_flags[i] * s_flags[j];
+                m[i * N + j] = s;
+                m[j * N + i] = s;
+            }
+            __syncthreads();
+            float* t3 = s_xcur; s_xcur = s_xnext; s_xnext = t3;
+        }
+
+        // ---- hodge branch of ScoreNetworkA_CC (ScoreNetwork_A_CC.py:295-316)
+        float* s_hd = sm + p.o_hd;
+        if (p.h_L > 0) {
+            float* s_acoef = sm + p.o_acoef;
+            float* s_hq = sm + p.o_hq;
+            const float kscale = (float)sqrt((double)p.K);  // hodge_attention.py:118,122: / sqrt(out_dim), out_dim = K
+            for (int t = tid; t < p.a_cinit * E; t += nth) {
+                const int c = t / E, e = t % E;
+                const float v = s_chan[c * NN + edges[2 * e] * N + edges[2 * e + 1]];
+                s_acoef[t] = v;
+                s_hd[t] = v;  // diagonal of adj_to_hodgedual(adjc): first c_init hodge channels
+            }
+            __syncthreads();
+            const HodgeLayerD& h0 = p.hl[0];
+            float* s_hdiag = sm + p.o_hatt;                       // [cin][E] attention diagonals
+            float* s_hatt = sm + p.o_h1m;                          // [cin0][E][E] dense layer-0 attention
+            float* s_h1m = s_hatt + p.hl[0].cin * E * E;           // [cout0][E][E] layer-0 output
+            const float* P0b = xa.P0 + (size_t)b * E * h0.wc;
+            for (int c = 0; c < h0.cin; ++c) {
+                // DenseHCNConv on a diagonal hodge adjacency (hodge_layers.py:185-193): row scaling
+                for (int t = tid; t < E * 2 * h0.adim; t += nth) {
+                    const int e = t / (2 * h0.adim), d = t % (2 * h0.adim);
+                    const float a = s_acoef[c * E + e];
+                    const float g = 1.0f / sqrtf(fmaxf(a, 1.f));
+                    const float coef = g * a * g;
+                    s_hq[t] = coef * P0b[(size_t)e * h0.wc + c * 2 * h0.adim + d] + w[h0.bcat + c * 2 * h0.adim + d];
+                }
+                __syncthreads();
+                if (p.h_L == 1) {
+                    for (int e = tid; e < E; e += nth) {  // only the diagonal is ever used (cc_utils.py:1571)
+                        float s = 0.f;
+                        for (int hh = 0; hh < h0.nchunk; ++hh) {
+                            float d = 0.f;
+                            for (int q = 0; q < h0.dsplit; ++q)
+                                d = fmaf(s_hq[e * 2 * h0.adim + hh * h0.dsplit + q], s_hq[e * 2 * h0.adim + h0.adim + hh * h0.dsplit + q], d);
+                            s += tanhf(d / kscale);
+                        }
+                        s /= (float)h0.nchunk;
+                        s_hdiag[c * E + e] = (s + s) / 2.f;
+                    }
+                } else {
+                    for (int t = tid; t < E * E; t += nth) {
+                        const int e = t / E, e2 = t % E;
+                        float s1 = 0.f, s2 = 0.f;
+                        for (int hh = 0; hh < h0.nchunk; ++hh) {
+                            float d1 = 0.f, d2 = 0.f;
+                            for (int q = 0; q < h0.dsplit; ++q) {
+                                const int oq = hh * h0.dsplit + q, ok = h0.adim + oq;
+                                d1 = fmaf(s_hq[e * 2 * h0.adim + oq], s_hq[e2 * 2 * h0.adim + ok], d1);
+                                d2 = fmaf(s_hq[e2 * 2 * h0.adim + oq], s_hq[e * 2 * h0.adim + ok], d2);
+                            }
+                            s1 += tanhf(d1 / kscale);
+                            s2 += tanhf(d2 / kscale);
+                        }
+                        s_hatt[c * E * E + t] = (s1 / (float)h0.nchunk + s2 / (float)h0.nchunk) / 2.f;
+                    }
+                }
+                __syncthreads();
+            }
+            // mlp_attention -> mask_hodge_adjs -> tanh -> + transpose  (hodge_attention.py:315-320)
+            if (p.h_L == 1) {
+                for (int e = tid; e < E; e += nth) {
+                    float in[CCSD_SMALLW], out[CCSD_SMALLW];
+#pragma unroll
+                    for (int c = 0; c < CCSD_SMALLW; ++c) in[c] = c < h0.cin ? s_hdiag[c * E + e] : 0.f;
+                    small_mlp<CCSD_SMALLW>(h0.matt, w, in, out);
+                    const float fh = s_flags[edges[2 * e]] * s_flags[edges[2 * e + 1]];
+#pragma unroll
+                    for (int o = 0; o < CCSD_SMALLW; ++o)
+                        if (o < h0.cout) { const float tv = tanhf(out[o] * fh * fh); s_hd[(p.a_cinit + o) * E + e] = tv + tv; }
+                }
+                __syncthreads();
+            } else {
+                for (int t = tid; t < E * E; t += nth) {
+                    const int e = t / E, e2 = t % E;
+                    float in[CCSD_SMALLW], out[CCSD_SMALLW];
+#pragma unroll
+                    for (int c = 0; c < CCSD_SMALLW; ++c) in[c] = c < h0.cin ? s_hatt[c * E * E + t] : 0.f;
+                    small_mlp<CCSD_SMALLW>(h0.matt, w, in, out);
+                    const float fh = s_flags[edges[2 * e]] * s_flags[edges[2 * e + 1]];
+                    const float fh2 = s_flags[edges[2 * e2]] * s_flags[edges[2 * e2 + 1]];
+#pragma unroll
+                    for (int o = 0; o < CCSD_SMALLW; ++o)
+                        if (o < h0.cout) {
+                            const float tv = tanhf(out[o] * fh * fh2);   // inputs are exactly symmetric -> h + h^T = 2h
+                            s_h1m[o * E * E + t] = tv + tv;
+                            if (e == e2) s_hd[(p.a_cinit + o) * E + e] = tv + tv;
+                        }
+                }
+                __syncthreads();
+                // second (last) HodgeAdjAttentionLayer: dense hodge adjacency, diagonal of the output only
+                const HodgeLayerD& h1 = p.hl[1];
+                const float* P1b = xa.P1 + (size_t)b * E * h1.wc;
+                float* s_deg = s_an;                 // E <= N*N always holds for N >= 3; guarded on the host
+                float* s_attd = s_hdiag;             // [cin][E]
+                for (int c = 0; c < h1.cin; ++c) {
+                    const float* Hc = s_h1m + c * E * E;
+                    for (int e = tid; e < E; e += nth) {
+                        float s = 0.f;
+                        for (int e2 = 0; e2 < E; ++e2) s += Hc[e * E + e2];
+                        s_deg[e] = 1.0f / sqrtf(fmaxf(s, 1.f));
+                    }
+                    __syncthreads();
+                    for (int t = tid; t < E * 2 * h1.adim; t += nth) {
+                        const int e = t / (2 * h1.adim), d = t % (2 * h1.adim);
+                        float acc = 0.f;
+                        for (int e2 = 0; e2 < E; ++e2)
+                            acc = fmaf(s_deg[e] * Hc[e * E + e2] * s_deg[e2], P1b[(size_t)e2 * h1.wc + c * 2 * h1.adim + d], acc);
+                        s_hq[t] = acc + w[h1.bcat + c * 2 * h1.adim + d];
+                    }
+                    __syncthreads();
+                    for (int e = tid; e < E; e += nth) {
+                        float s = 0.f;
+                        for (int hh = 0; hh < h1.nchunk; ++hh) {
+                            float d = 0.f;
+                            for (int q = 0; q < h1.dsplit; ++q)
+                                d = fmaf(s_hq[e * 2 * h1.adim + hh * h1.dsplit + q], s_hq[e * 2 * h1.adim + h1.adim + hh * h1.dsplit + q], d);
+                            s += tanhf(d / kscale);
+                        }
+                        s /= (float)h1.nchunk;
+                        s_attd[c * E + e] = (s + s) / 2.f;
+                    }
+                    __syncthreads();
+                }
+                for (int e = tid; e < E; e += nth) {
+                    float in[CCSD_SMALLW], out[CCSD_SMALLW];
+#pragma unroll
+                    for (int c = 0; c < CCSD_SMALLW; ++c) in[c] = c < h1.cin ? s_attd[c * E + e] : 0.f;
+                    small_mlp<CCSD_SMALLW>(h1.matt, w, in, out);
+                    const float fh = s_flags[edges[2 * e]] * s_flags[edges[2 * e + 1]];
+#pragma unroll
+                    for (int o = 0; o < CCSD_SMALLW; ++o)
+                        if (o < h1.cout) { const float tv = tanhf(out[o] * fh * fh); s_hd[(p.a_cinit + h0.cout + o) * E + e] = tv + tv; }
+                }
+                __syncthreads();
+            }
+        }
+
+        // ---- final MLP over every (i,j) on [graph channels | hodge channels]  (ScoreNetwork_A_CC.py:318-331)
+        const MlpD& m = p.a_fin;
+        for (int p0 = 0; p0 < NN; p0 += pch) {
+            const int rows = (NN - p0) < pch ? (NN - p0) : pch;
+            __syncthreads();
+            for (int t = tid; t < p.a_fdim * rows; t += nth) {
+                const int f = t / rows, r = t % rows, ij = p0 + r, i = ij / N, j = ij % N;
+                float v;
+                if (f < p.a_nch_graph) v = s_chan[f * NN + ij];
+                else if (i == j) v = 0.f;                              // hodgedual_to_adj leaves the diagonal 0
+                else {
+                    const int lo = i < j ? i : j, hi = i < j ? j : i;
+                    const int e = lo * N - lo * (lo + 1) / 2 + (hi - lo - 1);   // row-major triu index
+                    v = s_hd[(f - p.a_nch_graph) * E + e];
+                }
+                s_c0[f * ldp + r] = v;
+            }
+            __syncthreads();
+            block_linear<1>(s_c1, s_c0, w + m.w[0], w + m.b[0], m.in, m.hid, rows, ldp);
+            __syncthreads();
+            block_linear<1>(s_c0, s_c1, w + m.w[1], w + m.b[1], m.hid, m.hid, rows, ldp);
+            __syncthreads();
+            block_linear<0>(s_c1, s_c0, w + m.w[2], w + m.b[2], m.hid, 1, rows, ldp);
+            __syncthreads();
+            for (int r = tid; r < rows; r += nth) {
+                const int ij = p0 + r, i = ij / N, j = ij % N;
+                const float fm = s_flags[i] * s_flags[j];
+                const float net = (i == j) ? 0.f : s_c1[r] * fm;       // * no-diag mask, then mask_adjs
+                const size_t gi = (size_t)b * NN + ij;
+                if (xa.mode == MODE_SCORE) {
+                    xa.out_a[gi] = xa.ss_a * net;
+                } else {
+                    const float z = raw_noise_adj(na, b, i, j, N) * fm;   // gen_noise(sym=True), graph_utils.py:173-175
+                    if (xa.mode == MODE_NORMS) {
+                        xa.out_a[gi] = net;
+                        na_net = fmaf(net, net, na_net);
+                        na_z = fmaf(z, z, na_z);
+                    } else {
+                        const float mean = fmaf(xa.pa_a, s_adj[ij], xa.pb_a * net);
+                        if (xa.mean_a) xa.mean_a[gi] = mean;
+                        xa.out_a[gi] = fmaf(xa.pc_a, z, mean);
+                    }
+                }
+            }
+        }
+    }
+    if (xa.mode == MODE_NORMS) {
+        __syncthreads();
+        const float t0 = block_sum(nx_net, s_red), t1 = block_sum(na_net, s_red);
+        const float t2 = block_sum(nx_z, s_red), t3 = block_sum(na_z, s_red);
+        if (tid == 0) {
+            float* o = xa.norm2 + (size_t)b * 4;
+            if (xa.do_x) { o[0] = t0; o[2] = t2; }
+            if (xa.do_a) { o[1] = t1; o[3] = t3; }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_normsum: sums[0..5] = sum_b sqrt(|net_x|^2), |net_adj|, |net_rank2|, |z_x|, |z_adj|, |z_rank2|
+// (torch.norm(...).mean() numerators, solver.py:763-767).  One workgroup, deterministic order.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_normsum(const float* __restrict__ norm2, const float* __restrict__ part, int B, int ntiles,
+                          int is_cc, float* __restrict__ sums) {
+    __shared__ float red[64];
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        acc[0] += sqrtf(norm2[b * 4 + 0]);
+        acc[1] += sqrtf(norm2[b * 4 + 1]);
+        acc[3] += sqrtf(norm2[b * 4 + 2]);
+        acc[4] += sqrtf(norm2[b * 4 + 3]);
+        if (is_cc) {
+            float sn = 0.f, sz = 0.f;
+            for (int t = 0; t < ntiles; ++t) {
+                sn += part[((size_t)b * ntiles + t) * 2 + 0];
+                sz += part[((size_t)b * ntiles + t) * 2 + 1];
+            }
+            acc[2] += sqrtf(sn);
+            acc[5] += sqrtf(sz);
+        }
+    }
+    for (int i = 0; i < 6; ++i) {
+        const float t = block_sum(acc[i], red);
+        if (threadIdx.x == 0) sums[i] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_langevin_apply: step = (snr * zn / gn)^2 * 2 * alpha; v_mean = v + step*score;
+// v = v_mean + sqrt(2 step) * z * scale_eps          (solver.py:767-769, 781-783, 797-801)
+// score = sscale * net, so gn = |sscale| * sum|net| and step*score = step*sscale*net.
+// grid-stride over the three tensors of the whole batch.
+// ---------------------------------------------------------------------------------------------
+struct LangArgs {
+    const float* x; const float* adj; const float* r;          // state in
+    const float* nx; const float* nadj; const float* nr;        // raw network outputs kept by the NORMS pass
+    float* ox; float* oadj; float* orr;                          // state out
+    const float* flags;
+    const float* sums;
+    float ss[3], alpha[3];
+    float snr, seps;
+    int B, N, F, E, K, is_cc;
+};
+CCSD_DEV void langevin_coef(const LangArgs& a, int t, float* c1, float* c2) {
+    const float gn = fabsf(a.ss[t]) * a.sums[t], zn = a.sums[3 + t];
+    const float q = a.snr * zn / gn;
+    const float step = q * q * 2.f * a.alpha[t];
+    *c1 = step * a.ss[t];
+    *c2 = sqrtf(step * 2.f) * a.seps;
+}
+__global__ void k_langevin_apply(LangArgs a, NoiseArgs na, const unsigned long long* __restrict__ offbits,
+                                 const unsigned char* __restrict__ edges, const unsigned long long* __restrict__ cells) {
+    const long long nxe = (long long)a.B * a.N * a.F, nae = (long long)a.B * a.N * a.N;
+    const long long nre = a.is_cc ? (long long)a.B * ((a.E + 3) / 4) * a.K : 0;  // one thread per 4-edge group x column
+    const long long total = nxe + nae + nre;
+    float c1x, c2x, c1a, c2a, c1r = 0.f, c2r = 0.f;
+    langevin_coef(a, 0, &c1x, &c2x);
+    langevin_coef(a, 1, &c1a, &c2a);
+    if (a.is_cc) langevin_coef(a, 2, &c1r, &c2r);
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        if (t < nxe) {
+            const int per = a.N * a.F, b = (int)(t / per), idx = (int)(t % per), i = idx / a.F;
+            const float z = raw_noise_x(na, b, idx, per) * a.flags[(size_t)b * a.N + i];
+            a.ox[t] = fmaf(c2x, z, fmaf(c1x, a.nx[t], a.x[t]));
+        } else if (t < nxe + nae) {
+            const long long u = t - nxe;
+            const int per = a.N * a.N, b = (int)(u / per), ij = (int)(u % per), i = ij / a.N, j = ij % a.N;
+            const float z = raw_noise_adj(na, b, i, j, a.N) * a.flags[(size_t)b * a.N + i] * a.flags[(size_t)b * a.N + j];
+            a.oadj[u] = fmaf(c2a, z, fmaf(c1a, a.nadj[u], a.adj[u]));
+        } else {
+            const long long u = t - nxe - nae;
+            const int eg_n = (a.E + 3) / 4;
+            const int k = (int)(u % a.K), eg = (int)((u / a.K) % eg_n), b = (int)(u / ((long long)a.K * eg_n));
+            float z[4];
+            raw_noise_r4(na, b, eg, k, a.E, a.K, z);
+            const unsigned long long off = offbits[b];
+            const float fr = cell_on(off, cells, k);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int e = 4 * eg + s;
+                if (e >= a.E) continue;
+                const size_t gi = ((size_t)b * a.E + e) * a.K + k;
+                const float zz = z[s] * edge_on(off, edges, e) * fr;
+                a.orr[gi] = fmaf(c2r, zz, fmaf(c1r, a.nr[gi], a.r[gi]));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_init_state: masked prior (solver.py:1111-1118; sde.py:436,448-449).  Same indexing as above.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_init_state(float* x, float* adj, float* r, const float* __restrict__ flags, NoiseArgs na,
+                             const unsigned long long* __restrict__ offbits, const unsigned char* __restrict__ edges,
+                             const unsigned long long* __restrict__ cells, int B, int N, int F, int E, int K, int is_cc) {
+    const long long nxe = (long long)B * N * F, nae = (long long)B * N * N;
+    const int eg_n = (E + 3) / 4;
+    const long long nre = is_cc ? (long long)B * eg_n * K : 0;
+    const long long total = nxe + nae + nre;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        if (t < nxe) {
+            const int per = N * F, b = (int)(t / per), idx = (int)(t % per);
+            x[t] = raw_noise_x(na, b, idx, per) * flags[(size_t)b * N + idx / F];
+        } else if (t < nxe + nae) {
+            const long long u = t - nxe;
+            const int per = N * N, b = (int)(u / per), ij = (int)(u % per), i = ij / N, j = ij % N;
+            adj[u] = raw_noise_adj(na, b, i, j, N) * flags[(size_t)b * N + i] * flags[(size_t)b * N + j];
+        } else {
+            const long long u = t - nxe - nae;
+            const int k = (int)(u % K), eg = (int)((u / K) % eg_n), b = (int)(u / ((long long)K * eg_n));
+            float z[4];
+            raw_noise_r4(na, b, eg, k, E, K, z);
+            const unsigned long long off = offbits[b];
+            const float fr = cell_on(off, cells, k);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int e = 4 * eg + s;
+                if (e < E) r[((size_t)b * E + e) * K + k] = edge_on(off, edges, e) * z[s] * fr;
+            }
+        }
+    }
+}
+
+// quantize / quantize_mol (graph_utils.py:191, 209-213)
+__global__ void k_quantize(const float* __restrict__ in, long long n, float thr, long long* __restrict__ out) {
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const float v = in[t];
+        long long q;
+        if (thr >= 0.f) q = v < thr ? 0 : 1;
+        else q = v >= 2.5f ? 3 : v >= 1.5f ? 2 : v >= 0.5f ? 1 : 0;
+        out[t] = q;
+    }
+}

@@ -1,0 +1,300 @@
+// ccsd_plan.h -- device-visible description of the three score networks (offsets into the flat
+// weight blob, channel bookkeeping, LDS carve-up) and the host code that derives it from
+// ccsd_config_t.  The canonical blob order written here is the contract with
+// ccsd_amd/plan.py::pack_weights.
+#pragma once
+#include "../../include/ccsd_hip.h"
+#include "ccsd_rt.h"
+
+#define CCSD_MAXLIN 4     // linears per MLP
+#define CCSD_MAXL 8       // attention layers / GCN depth
+#define CCSD_MAXHL 2      // hodge layers handled by the HIP path
+#define CCSD_MAXFL 4      // HodgeNetworkLayers in ScoreNetworkF
+#define CCSD_SMALLW 8     // widest per-thread MLP in the hodge branch
+#define CCSD_FW 16        // widest per-thread MLP in ScoreNetworkF's general path
+
+struct MlpD {
+    int n, in, hid, out;
+    int w[CCSD_MAXLIN], b[CCSD_MAXLIN];
+};
+// dims of linear i of an MlpD
+static inline __host__ __device__ int mlp_in(const MlpD& m, int i) { return i == 0 ? m.in : m.hid; }
+static inline __host__ __device__ int mlp_out(const MlpD& m, int i) { return i == m.n - 1 ? m.out : m.hid; }
+
+struct AttnLayerD {
+    int cin, cout, fin, adim, fout, dsplit, nchunk;
+    int ci0, co0;             // first input / output channel inside the channel stack
+    int attn_base, attn_stride;  // per-channel block: Wq[fin][ad] bq Wk bk Wv[fin][fo] bv
+    MlpD mlp, mc;
+};
+struct HodgeLayerD {
+    int cin, cout, adim, dsplit, nchunk, wc;   // wc = cin*2*adim columns of Wcat
+    int wcat, bcat;                             // Wcat[K][wc], bcat[wc]
+    MlpD mval, matt;
+};
+
+struct PlanD {
+    int N, F, E, K, is_cc;
+    float snr, seps;
+    // ScoreNetworkX
+    int x_depth, x_nhid, x_fdim;
+    int x_gw[CCSD_MAXL], x_gb[CCSD_MAXL];
+    MlpD x_fin;
+    // ScoreNetworkA(_CC)
+    int a_L, a_cinit, a_is_cc, a_nch_graph, a_nch_hodge, a_fdim;
+    AttnLayerD al[CCSD_MAXL];
+    int h_L;
+    HodgeLayerD hl[CCSD_MAXHL];
+    MlpD a_fin;
+    // ScoreNetworkF
+    int f_L, f_cnum, f_hmask, f_fdim, f_affine;
+    float f_alpha, f_beta, f_gamma;
+    MlpD fl[CCSD_MAXFL];
+    MlpD f_fin;
+    // k_xa LDS carve-up (float offsets) and strides
+    int ldn, ldp, pch;          // node-row stride, pair-chunk stride, pairs per chunk
+    int o_flags, o_x, o_adj, o_an, o_xw, o_qkv, o_tmp, o_xcat, o_h1, o_h2, o_chan, o_att, o_xcur, o_xnext,
+        o_vcat, o_c0, o_c1, o_acoef, o_hq, o_hatt, o_h1m, o_hd, o_red;
+    int xa_lds_floats;
+};
+
+#ifndef CCSD_DEVICE_ONLY
+#include <math.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+static inline int64_t ccsd_comb(int n, int k) {
+    if (k < 0 || k > n) return 0;
+    long double r = 1;
+    for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i;
+    return (int64_t)(r + 0.5L);
+}
+static inline void ccsd_dims(const ccsd_config_t* c, int* E, int64_t* K) {
+    *E = c->N * (c->N - 1) / 2;
+    int64_t k = 0;
+    if (c->is_cc)
+        for (int d = c->d_min; d <= c->d_max; ++d) k += ccsd_comb(c->N, d);
+    *K = k;
+}
+
+struct PlanBuilder {
+    int cur = 0;
+    std::string err;
+    int status = CCSD_OK;
+    int take(int64_t n) {
+        int o = cur;
+        cur += (int)n;
+        return o;
+    }
+    void fail(int st, const std::string& m) {
+        if (status == CCSD_OK) { status = st; err = m; }
+    }
+    MlpD mlp(int n, int in, int hid, int out) {
+        MlpD m{};
+        m.n = n; m.in = in; m.hid = hid; m.out = out;
+        if (n < 1 || n > CCSD_MAXLIN) { fail(CCSD_ERR_UNSUPPORTED, "MLP with more than 4 (or fewer than 1) linears"); m.n = 1; }
+        for (int i = 0; i < m.n; ++i) {
+            m.w[i] = take((int64_t)mlp_out(m, i) * mlp_in(m, i));
+            m.b[i] = take(mlp_out(m, i));
+        }
+        return m;
+    }
+};
+
+static inline int round_ld(int rows) {  // multiple of 16, and == 16 mod 32 (conflict-free MFMA A-fragment reads)
+    int r = (rows + 15) / 16 * 16;
+    if (r % 32 == 0) r += 16;
+    return r;
+}
+
+// Fills `p` (except the affine fold, which needs the weights) and returns the blob size.
+static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuilder& pb) {
+    memset(p, 0, sizeof(*p));
+    if (!c || c->abi_version != CCSD_ABI_VERSION) { pb.fail(CCSD_ERR_INVALID, "abi_version mismatch"); return 0; }
+    if (c->N < 2 || c->N > 64 || c->F < 1) { pb.fail(CCSD_ERR_UNSUPPORTED, "need 2 <= N <= 64 and F >= 1"); return 0; }
+    int E; int64_t K64;
+    ccsd_dims(c, &E, &K64);
+    if (c->is_cc && (c->d_min < 1 || c->d_max < c->d_min || c->d_max > c->N)) { pb.fail(CCSD_ERR_INVALID, "bad d_min/d_max"); return 0; }
+    if (K64 > (1 << 24)) { pb.fail(CCSD_ERR_UNSUPPORTED, "rank-2 width K too large"); return 0; }
+    p->N = c->N; p->F = c->F; p->E = E; p->K = (int)K64; p->is_cc = c->is_cc;
+    p->snr = c->snr; p->seps = c->scale_eps;
+    const int N = c->N, F = c->F, K = (int)K64;
+    // ---- ScoreNetworkX
+    if (c->x_depth < 1 || c->x_depth > CCSD_MAXL) { pb.fail(CCSD_ERR_UNSUPPORTED, "x_depth out of range"); return 0; }
+    p->x_depth = c->x_depth; p->x_nhid = c->x_nhid; p->x_fdim = F + c->x_depth * c->x_nhid;
+    for (int l = 0; l < c->x_depth; ++l) {
+        p->x_gw[l] = pb.take((int64_t)(l ? c->x_nhid : F) * c->x_nhid);
+        p->x_gb[l] = pb.take(c->x_nhid);
+    }
+    p->x_fin = pb.mlp(3, p->x_fdim, 2 * p->x_fdim, F);
+    // ---- ScoreNetworkA graph branch
+    if (c->a_num_layers < 1 || c->a_num_layers > CCSD_MAXL) { pb.fail(CCSD_ERR_UNSUPPORTED, "a_num_layers out of range"); return 0; }
+    if (c->a_num_heads < 1 || c->a_c_init < 1) { pb.fail(CCSD_ERR_INVALID, "bad heads/c_init"); return 0; }
+    p->a_L = c->a_num_layers; p->a_cinit = c->a_c_init; p->a_is_cc = c->a_is_cc_net;
+    int ch = c->a_c_init;
+    for (int l = 0; l < p->a_L; ++l) {
+        AttnLayerD& a = p->al[l];
+        const bool first = (l == 0), last = (l == p->a_L - 1) && !first;
+        a.cin = first ? c->a_c_init : c->a_c_hid;
+        a.cout = last ? c->a_c_final : c->a_c_hid;
+        a.fin = first ? F : c->a_nhid;
+        a.adim = first ? c->a_nhid : c->a_adim;
+        a.fout = c->a_nhid;
+        a.dsplit = a.adim / c->a_num_heads;
+        if (a.dsplit < 1 || a.adim % a.dsplit) { pb.fail(CCSD_ERR_INVALID, "attn_dim not divisible into head chunks"); return 0; }
+        a.nchunk = a.adim / a.dsplit;
+        a.ci0 = ch - a.cin; a.co0 = ch; ch += a.cout;
+        a.attn_stride = 2 * (a.fin * a.adim + a.adim) + a.fin * a.fout + a.fout;
+        a.attn_base = pb.take((int64_t)a.cin * a.attn_stride);
+        const int hid = 2 * (a.cin > a.cout ? a.cin : a.cout);
+        a.mlp = pb.mlp(c->a_num_linears, 2 * a.cin, hid, a.cout);
+        a.mc = pb.mlp(2, a.cin * a.fout, hid, a.fout);
+    }
+    p->a_nch_graph = ch;
+    int fdim = c->a_c_hid * (p->a_L - 1) + c->a_c_final + c->a_c_init;
+    if (fdim != ch) { pb.fail(CCSD_ERR_INVALID, "ScoreNetworkA channel count inconsistent (num_layers==1 needs c_hid==c_final)"); return 0; }
+    // ---- hodge branch
+    p->h_L = 0; p->a_nch_hodge = 0;
+    if (c->a_is_cc_net) {
+        if (!c->is_cc) { pb.fail(CCSD_ERR_INVALID, "ScoreNetworkA_CC is only for combinatorial complexes"); return 0; }
+        if (c->h_num_layers < 1 || c->h_num_layers > CCSD_MAXHL) {
+            pb.fail(CCSD_ERR_UNSUPPORTED, "HIP path supports 1 or 2 HodgeAdjAttentionLayers"); return 0; }
+        p->h_L = c->h_num_layers;
+        int hch = c->a_c_init;
+        for (int l = 0; l < p->h_L; ++l) {
+            HodgeLayerD& h = p->hl[l];
+            const bool first = (l == 0), last = (l == p->h_L - 1) && !first;
+            h.cin = first ? c->a_c_init : c->h_c_hid;
+            h.cout = last ? c->h_c_final : c->h_c_hid;
+            h.adim = first ? c->h_nhid : c->h_adim;
+            h.dsplit = h.adim / c->h_num_heads;
+            if (h.dsplit < 1 || h.adim % h.dsplit) { pb.fail(CCSD_ERR_INVALID, "hodge attn_dim not divisible into head chunks"); return 0; }
+            h.nchunk = h.adim / h.dsplit;
+            h.wc = h.cin * 2 * h.adim;
+            h.wcat = pb.take((int64_t)K * h.wc);
+            h.bcat = pb.take(h.wc);
+            const int hid = 2 * (h.cin > h.cout ? h.cin : h.cout);
+            h.mval = pb.mlp(c->h_num_linears, h.cin, hid, 1);
+            h.matt = pb.mlp(c->h_num_linears, h.cin, hid, h.cout);
+            if (h.cin > CCSD_SMALLW || hid > CCSD_SMALLW || h.cout > CCSD_SMALLW) {
+                pb.fail(CCSD_ERR_UNSUPPORTED, "hodge MLP wider than 8"); return 0; }
+            hch += h.cout;
+        }
+        p->a_nch_hodge = hch;
+        int hf = c->h_c_hid * (p->h_L - 1) + c->h_c_final + c->a_c_init;
+        if (hf != hch) { pb.fail(CCSD_ERR_INVALID, "hodge channel count inconsistent (num_layers_h==1 needs c_hid_h==c_final_h)"); return 0; }
+    }
+    p->a_fdim = p->a_nch_graph + p->a_nch_hodge;
+    p->a_fin = pb.mlp(3, p->a_fdim, 2 * p->a_fdim, 1);
+    // ---- ScoreNetworkF
+    if (c->is_cc) {
+        if (c->f_num_layers < 1 || c->f_num_layers > CCSD_MAXFL) { pb.fail(CCSD_ERR_UNSUPPORTED, "f_num_layers out of range"); return 0; }
+        if (c->f_cnum < 1 || c->f_cnum > 2) { pb.fail(CCSD_ERR_UNSUPPORTED, "HIP path supports cnum in {1,2}"); return 0; }
+        p->f_L = c->f_num_layers; p->f_cnum = c->f_cnum; p->f_hmask = c->f_use_hodge_mask;
+        int fch = c->f_cnum;
+        for (int l = 0; l < p->f_L; ++l) {
+            const bool first = (l == 0), last = (l == p->f_L - 1) && !first;
+            const int cin = first ? c->f_cnum : c->f_c_hid, cout = last ? c->f_c_final : c->f_c_hid;
+            p->fl[l] = pb.mlp(c->f_num_linears, cin, c->f_nhid, cout);
+            if (cin > CCSD_FW || cout > CCSD_FW || c->f_nhid > CCSD_FW) { pb.fail(CCSD_ERR_UNSUPPORTED, "ScoreNetworkF layer wider than 16"); return 0; }
+            fch += cout;
+        }
+        p->f_fdim = c->f_c_hid * (p->f_L - 1) + c->f_c_final + c->f_cnum;
+        if (p->f_fdim != fch) { pb.fail(CCSD_ERR_INVALID, "ScoreNetworkF channel count inconsistent"); return 0; }
+        p->f_fin = pb.mlp(c->f_num_layers_mlp, p->f_fdim, 2 * p->f_fdim, 1);
+        if (p->f_fdim > CCSD_FW || (c->f_num_layers_mlp > 1 && 2 * p->f_fdim > CCSD_FW)) {
+            pb.fail(CCSD_ERR_UNSUPPORTED, "ScoreNetworkF final MLP wider than 16"); return 0; }
+        p->f_affine = (c->f_num_linears == 1 && c->f_num_layers_mlp == 1) ? 1 : 0;
+    }
+    const size_t nweights = (size_t)pb.cur;
+
+    // ---- k_xa LDS carve-up
+    const int NN = N * N;
+    p->ldn = round_ld(N);
+    int fmaxA = F > c->a_nhid ? F : c->a_nhid;
+    int colmax = 0, mchid = 0, pairw = 0, cinmax = 0;
+    for (int l = 0; l < p->a_L; ++l) {
+        const AttnLayerD& a = p->al[l];
+        int cols = 2 * a.adim + a.fout; if (cols > colmax) colmax = cols;
+        if (a.mc.hid > mchid) mchid = a.mc.hid;
+        int w = 2 * a.cin; if (a.mlp.hid > w) w = a.mlp.hid; if (a.cout > w) w = a.cout; if (w > pairw) pairw = w;
+        if (a.cin > cinmax) cinmax = a.cin;
+    }
+    if (2 * p->a_fdim > pairw) pairw = 2 * p->a_fdim;
+    int o = 0;
+    auto carve = [&](int n) { int r = o; o += (n + 3) / 4 * 4; return r; };
+    p->o_flags = carve(N);
+    p->o_x = carve(N * F);
+    p->o_adj = carve(NN);
+    p->o_an = carve(NN);
+    p->o_tmp = carve(NN);
+    int xwcols = colmax > c->x_nhid ? colmax : c->x_nhid;
+    p->o_xw = carve(N * xwcols);
+    p->o_qkv = carve(N * xwcols);
+    p->o_red = carve(64);
+    const int phase0 = o;
+    // X-network phase buffers ...
+    p->o_xcat = carve(p->x_fdim * p->ldn);
+    p->o_h1 = carve(2 * p->x_fdim * p->ldn);
+    p->o_h2 = carve(2 * p->x_fdim * p->ldn);
+    const int xphase_end = o;
+    // ... are dead when the A-network phase starts: alias them
+    o = phase0;
+    p->o_chan = carve(p->a_nch_graph * NN);
+    p->o_att = carve(cinmax * NN);
+    p->o_xcur = carve(fmaxA * p->ldn);
+    p->o_xnext = carve(fmaxA * p->ldn);
+    p->o_vcat = carve(mchid * p->ldn);          // hidden layer of multi_channel
+    if (p->h_L) {
+        if (E > NN) { pb.fail(CCSD_ERR_UNSUPPORTED, "E > N*N"); return 0; }
+        p->o_acoef = carve(c->a_c_init * E);
+        int adm = p->hl[0].adim; if (p->h_L > 1 && p->hl[1].adim > adm) adm = p->hl[1].adim;
+        p->o_hq = carve(E * 2 * adm);
+        p->o_hd = carve(p->a_nch_hodge * E);
+        p->o_hatt = carve(CCSD_SMALLW * E);     // per-channel attention diagonals
+        if (p->h_L > 1) p->o_h1m = carve((p->hl[0].cin + p->hl[0].cout) * E * E);  // dense layer-0 attention + output
+    }
+    // pair-chunk buffers: grow the chunk while the workgroup stays <= 64 KB (2+ workgroups per CU);
+    // if even 48 pairs do not fit, keep growing up to the CU's 160 KB (minus a margin)
+    const int NNpad = (NN + 15) / 16 * 16;
+    auto total_with = [&](int pc) { return o + 2 * ((pairw * round_ld(pc) + 3) / 4 * 4); };
+    int pch = 16;
+    while (pch + 16 <= NNpad && total_with(pch + 16) * 4 <= 64 * 1024) pch += 16;
+    while (pch < 48 && pch + 16 <= NNpad && total_with(pch + 16) * 4 <= 152 * 1024) pch += 16;
+    p->pch = pch; p->ldp = round_ld(pch);
+    p->o_c0 = carve(pairw * p->ldp);
+    p->o_c1 = carve(pairw * p->ldp);
+    if (xphase_end > o) o = xphase_end;
+    p->xa_lds_floats = o;
+    if ((size_t)o * 4 > 160 * 1024) pb.fail(CCSD_ERR_UNSUPPORTED, "graph-network working set exceeds the 160 KB LDS of a CU");
+    return nweights;
+}
+
+// Fold ScoreNetworkF into  score = mask * (alpha*F + beta*(H F) + gamma)  when every MLP in it is a
+// single Linear (num_linears == 1 and num_layers_mlp == 1: true for every shipped CC checkpoint but
+// ENZYMES).  The intermediate mask_rank2 factors are 0/1 and the final output is masked again, so
+// the fold is exact in real arithmetic.
+static inline void ccsd_fold_fnet(PlanD* p, const float* w) {
+    if (!p->is_cc || !p->f_affine) return;
+    const int fd = p->f_fdim;
+    std::vector<double> A(fd * 3, 0.0);  // channel j = A[j][0]*F + A[j][1]*HF + A[j][2]
+    A[0 * 3 + 0] = 1.0;
+    if (p->f_cnum == 2) A[1 * 3 + 1] = 1.0;
+    int ci0 = 0, co0 = p->f_cnum;
+    for (int l = 0; l < p->f_L; ++l) {
+        const MlpD& m = p->fl[l];
+        for (int oo = 0; oo < m.out; ++oo) {
+            double acc[3] = {0, 0, (double)w[m.b[0] + oo]};
+            for (int i = 0; i < m.in; ++i)
+                for (int t = 0; t < 3; ++t) acc[t] += (double)w[m.w[0] + oo * m.in + i] * A[(ci0 + i) * 3 + t];
+            for (int t = 0; t < 3; ++t) A[(co0 + oo) * 3 + t] = acc[t];
+        }
+        ci0 = co0; co0 += m.out;
+    }
+    double r[3] = {0, 0, (double)w[p->f_fin.b[0]]};
+    for (int j = 0; j < fd; ++j)
+        for (int t = 0; t < 3; ++t) r[t] += (double)w[p->f_fin.w[0] + j] * A[j * 3 + t];
+    p->f_alpha = (float)r[0]; p->f_beta = (float)r[1]; p->f_gamma = (float)r[2];
+}
+#endif  // CCSD_DEVICE_ONLY

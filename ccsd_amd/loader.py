@@ -1,0 +1,166 @@
+"""Factory functions with the reference's names and argument meaning (ccsd/src/utils/loader.py).
+
+load_seed :35-55, load_device :58-68, load_model :71-101, load_sde :242-267,
+load_sampling_fn :337-458, load_ckpt :569-616, load_model_from_ckpt :619-657.
+Configs are plain dicts (or anything with item/attribute access); checkpoints are read from the
+neutral `<name>.npz` + `<name>.json` pair (ccsd_amd/checkpoints, written by tools/make_golden.py) or
+from the reference's own `.pth` files.
+"""
+from __future__ import annotations
+
+import json
+import os
+import random
+from typing import Any, Dict, List, Optional, Union
+
+import numpy as np
+import torch
+
+from .models import load_model  # noqa: F401  (re-exported, loader.py:71)
+from .plan import rank2_dim
+from .sde import SDE, VESDE, VPSDE, subVPSDE
+from .solver import get_pc_sampler
+
+PKG_CKPT_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "checkpoints")
+
+
+class AttrDict(dict):
+    """dict with recursive attribute access (the reference uses easydict.EasyDict)."""
+
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        for k, v in dict(d or {}, **kw).items():
+            self[k] = v
+
+    def __setitem__(self, k, v):
+        if isinstance(v, dict) and not isinstance(v, AttrDict):
+            v = AttrDict(v)
+        super().__setitem__(k, v)
+
+    __setattr__ = __setitem__
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+def _get(cfg, key, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+def load_seed(seed: int) -> int:
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+        torch.cuda.manual_seed_all(seed)
+    return seed
+
+
+def load_device() -> Union[str, List[int]]:
+    if torch.cuda.is_available():
+        return list(range(torch.cuda.device_count()))
+    return "cpu"
+
+
+def _device_id(device) -> str:
+    """loader.py:378: first device of a list, else the string."""
+    if isinstance(device, list):
+        d = device[0]
+        return str(d) if "cuda" in str(d) else f"cuda:{d}"
+    return device
+
+
+def load_sde(config_sde) -> SDE:
+    t = _get(config_sde, "type")
+    bmin, bmax, n = _get(config_sde, "beta_min"), _get(config_sde, "beta_max"), _get(config_sde, "num_scales")
+    if t == "VP":
+        return VPSDE(beta_min=bmin, beta_max=bmax, N=n)
+    if t == "VE":
+        return VESDE(sigma_min=bmin, sigma_max=bmax, N=n)
+    if t == "subVP":
+        return subVPSDE(beta_min=bmin, beta_max=bmax, N=n)
+    raise NotImplementedError(f"SDE class {t} not (yet) supported.")
+
+
+def load_model_from_ckpt(params: Dict[str, Any], state_dict: Dict[str, Any], device):
+    model = load_model(params)
+    model.load_state_dict(state_dict)
+    if isinstance(device, list) and len(device) > 1:
+        # the reference wraps the module in DataParallel here (loader.py:649-650); this build shards
+        # the batch over one process per GPU instead (bench.py / ccsd_amd.distributed), so a device
+        # list just selects its first entry for this process.
+        pass
+    return model.to(_device_id(device))
+
+
+def load_ckpt(config, device, ts: Optional[str] = None, return_ckpt: bool = False, is_cc: bool = False) -> Dict[str, Any]:
+    """Reads <folder>/checkpoints/<data>/<ckpt>.npz+.json (neutral format), the packaged copy of a shipped
+    checkpoint, or the reference's .pth (torch.load with weights_only=False: it pickles an EasyDict)."""
+    if ts is not None:
+        config["ckpt"] = ts
+    name = _get(config, "ckpt")
+    data = _get(_get(config, "data"), "data")
+    folder = _get(config, "folder", "./")
+    base = os.path.join(folder, "checkpoints", f"{data}", f"{name}")
+    cands = [base, os.path.join(PKG_CKPT_DIR, name)]
+    out: Dict[str, Any] = {}
+    for c in cands:
+        if os.path.exists(c + ".npz") and os.path.exists(c + ".json"):
+            with open(c + ".json") as f:
+                meta = json.load(f)
+            z = np.load(c + ".npz")
+            out = {"config": AttrDict(meta["config"])}
+            for part in ["x", "adj"] + (["rank2"] if is_cc else []):
+                out[f"params_{part}"] = meta[f"params_{part}"]
+                out[f"{part}_state_dict"] = {k.split("/", 1)[1]: torch.from_numpy(z[k]) for k in z.files if k.startswith(part + "/")}
+            print(f"{c}.npz loaded")
+            break
+    else:
+        path = base + ".pth"
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        print(f"{path} loaded")
+        out = {"config": ckpt["model_config"]}
+        for part in ["x", "adj"] + (["rank2"] if is_cc else []):
+            out[f"params_{part}"] = dict(ckpt[f"params_{part}"])
+            out[f"{part}_state_dict"] = ckpt[f"{part}_state_dict"]
+        if _get(_get(config, "sample"), "use_ema", False):
+            for part in ["x", "adj"] + (["rank2"] if is_cc else []):
+                out[f"ema_{part}"] = ckpt[f"ema_{part}"]
+        if return_ckpt:
+            out["ckpt"] = ckpt
+    out["config"]["folder"] = folder
+    return out
+
+
+def load_sampling_fn(config_train, config_module, config_sample, device, is_cc: bool = False, d_min: Optional[int] = None,
+                     d_max: Optional[int] = None, divide_batch: Optional[int] = None, **extra):
+    """loader.py:372-458.  `extra` forwards the build-specific knobs of get_pc_sampler (rng, keep_traj, ...)."""
+    sde_cfg = _get(config_train, "sde")
+    sde_x, sde_adj = load_sde(_get(sde_cfg, "x")), load_sde(_get(sde_cfg, "adj"))
+    sde_rank2 = load_sde(_get(sde_cfg, "rank2")) if is_cc else None
+    data = _get(config_train, "data")
+    N, F = _get(data, "max_node_num"), _get(data, "max_feat_num")
+    if _get(config_module, "predictor") == "S4":
+        raise NotImplementedError("S4_solver is not built in this round (SURVEY.md section 8f row 4)")
+    if _get(data, "data") in ["QM9", "ZINC250k"]:
+        bs = _get(config_sample, "n_samples")
+    else:
+        bs = _get(data, "batch_size")
+    if divide_batch is not None:
+        bs = bs // divide_batch
+    kw = dict(sde_x=sde_x, sde_adj=sde_adj, shape_x=(bs, N, F), shape_adj=(bs, N, N),
+              predictor=_get(config_module, "predictor"), corrector=_get(config_module, "corrector"),
+              snr=_get(config_module, "snr"), scale_eps=_get(config_module, "scale_eps"),
+              n_steps=_get(config_module, "n_steps"), probability_flow=_get(config_sample, "probability_flow"),
+              continuous=True, denoise=_get(config_sample, "noise_removal"), eps=_get(config_sample, "eps"),
+              device=_device_id(device))
+    if is_cc:
+        kw.update(is_cc=True, sde_rank2=sde_rank2, shape_rank2=(bs, *rank2_dim(N, d_min, d_max)), d_min=d_min, d_max=d_max)
+    kw.update(extra)
+    return get_pc_sampler(**kw)

@@ -1,0 +1,183 @@
+"""get_pc_sampler: the reference's predictor-corrector sampler factory, backed by the HIP kernels.
+
+Same signature, closure signature and return tuple as ccsd/src/solver.py:856-1176:
+  graph: pc_sampler(model_x, model_adj, init_flags)              -> (x, adj, nfe, diff_traj)
+  CC:    pc_sampler(model_x, model_adj, model_rank2, init_flags) -> (x, adj, rank2, nfe, diff_traj)
+
+Extra keyword-only knobs (not in the reference):
+  rng        "philox" (default): counter-based noise generated inside the kernels, one C call for the loop;
+             "torch": priors from the CPU generator and in-loop noise from randn_like on the state's
+                      device, in the reference's draw order (what the reference itself does, solver.py:1111-1113,
+                      graph_utils.py:171);
+             "torch_cpu": every draw from torch's CPU generator -> identical-seed parity with the
+                      reference's CPU run.
+  keep_traj  record diff_traj (the reference always does; default False here because only the plotting
+             code consumes it -- SURVEY.md section 7).  With keep_traj=False an empty list is returned.
+  group      torch.distributed process group: all-reduce the six Langevin norm sums across ranks so that
+             a sharded batch reproduces the single-process step size exactly.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from .engine import PCEngine
+from .sde import SDE
+
+
+def get_predictor(predictor: str) -> str:
+    if predictor not in ("Reverse", "Euler"):
+        raise NotImplementedError(f"Predictor {predictor} not yet supported. Select from [Reverse, Euler].")
+    return predictor
+
+
+def get_corrector(corrector: str) -> str:
+    if corrector not in ("Langevin", "None"):
+        raise NotImplementedError(f"Corrector {corrector} not yet supported. Select from [Langevin, None].")
+    return corrector
+
+
+def _unwrap(model):
+    return getattr(model, "module", model)
+
+
+def get_pc_sampler(sde_x: SDE, sde_adj: SDE, shape_x: Sequence[int], shape_adj: Sequence[int], predictor: str = "Euler",
+                   corrector: str = "None", snr: float = 0.1, scale_eps: float = 1.0, n_steps: int = 1,
+                   probability_flow: bool = False, continuous: bool = False, denoise: bool = True, eps: float = 1e-3,
+                   device: str = "cuda", is_cc: bool = False, sde_rank2: Optional[SDE] = None,
+                   shape_rank2: Optional[Sequence[int]] = None, d_min: Optional[int] = None, d_max: Optional[int] = None,
+                   *, rng: str = "philox", keep_traj: bool = False, seed: Optional[int] = None, group=None,
+                   sample_offset: int = 0, max_steps: Optional[int] = None, lib: Optional[_lib.Library] = None) -> Callable:
+    get_predictor(predictor)
+    get_corrector(corrector)
+    if rng not in ("philox", "torch", "torch_cpu"):
+        raise ValueError(f"rng {rng} unknown. Select from [philox, torch, torch_cpu].")
+    B, N, F = shape_x
+    sdes = [sde_x, sde_adj] + ([sde_rank2] if is_cc else [])
+    cache = {}
+
+    def build_engine(models) -> PCEngine:
+        if not continuous:
+            raise NotImplementedError("Discrete not supported")   # losses.py:69,161
+        key = tuple(id(m) for m in models)
+        if key not in cache:
+            ms = [_unwrap(m) for m in models]
+            for m in ms:
+                m.eval()
+            args = []
+            for m in ms:
+                args += [m.params, m.state_dict()]
+            if not is_cc:
+                args += [None, None]
+            cache.clear()
+            cache[key] = PCEngine(*args, N=N, F=F, is_cc=is_cc, d_min=d_min or 0, d_max=d_max or 0, sdes=sdes,
+                                  predictor=predictor, corrector=corrector, snr=snr, scale_eps=scale_eps, n_steps=n_steps,
+                                  probability_flow=probability_flow, denoise=denoise, eps=eps, device=device, lib=lib)
+        return cache[key]
+
+    def draw(shape, dev):
+        if rng == "torch_cpu":
+            return torch.randn(*shape).to(dev)
+        return torch.randn(*shape, device=dev)
+
+    def pc_sampler(*args):
+        models, init_flags = args[:-1], args[-1]
+        if len(models) != len(sdes):
+            raise TypeError(f"pc_sampler expects {len(sdes)} models and init_flags")
+        eng = build_engine(models)
+        dev = eng.device
+        flags = init_flags.to(dev, torch.float32).contiguous()
+        if flags.shape != (B, N):
+            raise ValueError(f"init_flags must have shape {(B, N)}, got {tuple(flags.shape)}")
+        the_seed = int(seed if seed is not None else torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        shapes = eng.shapes(B)
+        nt = 3 if is_cc else 2
+        state, scratch, result = eng.alloc_state(B), eng.alloc_state(B), eng.alloc_state(B)
+        diff_steps = sde_adj.N
+        last = diff_steps if max_steps is None else min(max_steps, diff_steps)
+        diff_traj: List[List[torch.Tensor]] = []
+        with torch.no_grad():
+            if rng == "philox":
+                eng.init_state(flags, state, None, the_seed, sample_offset)
+                traj = None
+                if keep_traj:
+                    per = sum(s[1] * s[2] for s in shapes[:nt])
+                    traj = torch.empty(diff_steps, per, device=dev)
+                if group is None:
+                    eng.run(flags, state, scratch, result, the_seed, sample_offset, 0, last, traj)
+                else:
+                    _stepwise(eng, flags, state, scratch, result, None, the_seed, sample_offset, last, diff_traj, keep_traj, group)
+                if traj is not None:
+                    o = 0
+                    for i in range(last):
+                        row, o2, item = traj[i], 0, []
+                        for s in shapes[:nt]:
+                            n = s[1] * s[2]
+                            item.append(row[o2:o2 + n].view(s[1], s[2]).clone())
+                            o2 += n
+                        diff_traj.append(item)
+            else:
+                # priors on the CPU generator, then moved (solver.py:1111-1113)
+                px = sde_x.prior_sampling(shape_x)
+                pa = torch.randn(*shape_adj)          # raw draw; the kernel applies triu(1)+transpose
+                prior = [px.to(dev), pa.to(dev)]
+                if is_cc:
+                    prior.append(sde_rank2.prior_sampling(shape_rank2).to(dev))
+                eng.init_state(flags, state, prior)
+                noise_fn = lambda k: draw(shapes[k], dev)
+                _stepwise(eng, flags, state, scratch, result, noise_fn, the_seed, sample_offset, last, diff_traj, keep_traj, group)
+        if rng != "philox" or group is not None:
+            out = result if denoise else state
+        else:
+            out = result
+        print(" ")
+        return (*out[:nt], diff_steps * (n_steps + 1), diff_traj)
+
+    def _stepwise(eng, flags, state, scratch, result, noise_fn, the_seed, off, last, diff_traj, keep, grp):
+        """Python-driven loop: used for host-supplied noise and for the exact multi-GPU mode."""
+        import torch.distributed as dist
+
+        dev = eng.device
+        sums = torch.zeros(8, device=dev)
+        nt = 3 if is_cc else 2
+        third = eng.alloc_state(flags.shape[0]) if (corrector == "Langevin" and n_steps > 1) else None
+        a, b = state, scratch   # a = live
+        for step in range(last):
+            lastone = step == last - 1
+            if corrector == "Langevin":
+                base, cur = a, a
+                bufs = [b, third]
+                # the reference finishes all inner steps of one target before the next target draws
+                # (solver.py:1131-1137): target-major draw order
+                zs = [[None] * nt for _ in range(n_steps)]
+                if noise_fn:
+                    for k in range(nt):
+                        for it in range(n_steps):
+                            zs[it][k] = noise_fn(k)
+                for it in range(n_steps):
+                    z = zs[it] if noise_fn else None
+                    eng.corrector_norms(step, it, base, cur, flags, z, the_seed, off, sums)
+                    if grp is not None and dist.is_available() and dist.is_initialized():
+                        dist.all_reduce(sums, group=grp)   # six floats over RCCL / gloo: exact batch-global step size
+                    out = bufs[it % 2]
+                    eng.corrector_apply(step, it, cur, flags, z, the_seed, off, sums, out)
+                    cur = out
+                z = [noise_fn(k) for k in range(nt)] if noise_fn else None
+                want_mean = denoise and (lastone or keep)
+                eng.predictor(step, cur, flags, z, the_seed, off, a, result if want_mean else None)   # base is dead: reuse it
+            else:
+                z = [noise_fn(k) for k in range(nt)] if noise_fn else None
+                want_mean = denoise and (lastone or keep)
+                eng.predictor(step, a, flags, z, the_seed, off, b, result if want_mean else None)
+                a, b = b, a
+            if keep:
+                src = result if denoise else a
+                diff_traj.append([t[0].detach().clone() for t in src[:nt]])
+        if a is not state:
+            for dst, src in zip(state, a):
+                if dst is not None:
+                    dst.copy_(src)
+
+    return pc_sampler

@@ -1,0 +1,168 @@
+/*
+ * ccsd_hip.h -- C ABI of the MI355X-native CCSD reverse-SDE sampling path (libccsd_hip.so).
+ *
+ * Drop-in boundary.  The reference (AdrienC21/CCSD v0.3.3) is pure Python; its seam for this
+ * path is  load_sampling_fn(...) -> sampling_fn(model_x, model_adj[, model_rank2], init_flags)
+ * (ccsd/src/utils/loader.py:337-458, ccsd/src/solver.py:856-1176).  A maintainer binds this
+ * library with ctypes; every pointer marked `dev` is a device pointer into a
+ * caller-owned allocation (PyTorch-ROCm tensors in practice), fp32, contiguous, batch-major.
+ * No torch types appear in any signature.  All calls are asynchronous on `stream`
+ * (a hipStream_t passed as void*; NULL = the default stream) and return an int status.
+ *
+ * Entry point                  replaces (reference file:line)
+ * ---------------------------  -----------------------------------------------------------------
+ * ccsd_plan_create/destroy     load_model_from_ckpt + load_sde + get_pc_sampler closure setup
+ *                              (loader.py:619-657, 242-267; solver.py:856-1104)
+ * ccsd_score                   get_score_fn / get_score_fn_cc applied to ScoreNetworkX /
+ *                              ScoreNetworkA(_CC) / ScoreNetworkF.forward
+ *                              (losses.py:18-198; models/ScoreNetwork_{X,A,A_CC,F}.py)
+ * ccsd_init_state              sde.prior_sampling(_sym) + mask_x/mask_adjs/mask_rank2
+ *                              (solver.py:1111-1118; sde.py:426-449, 583-608)
+ * ccsd_corrector_norms         first half of LangevinCorrector.update_fn_* : score, noise, the two
+ *                              batch norms (solver.py:759-767, 773-780, 787-797)
+ * ccsd_corrector_apply         second half: step_size, x_mean, x (solver.py:767-769, 781-783, 797-801)
+ * ccsd_predictor               ReverseDiffusionPredictor / EulerMaruyamaPredictor.update_fn_*
+ *                              (solver.py:210-313, 367-463) + RSDE.sde/discretize (sde.py:180-340)
+ * ccsd_sampler_run             the whole pc_sampler loop (solver.py:1109-1174)
+ * ccsd_quantize_mol            quantize_mol / quantize (graph_utils.py:181-213)
+ */
+#ifndef CCSD_HIP_H
+#define CCSD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCSD_ABI_VERSION 1
+
+/* status codes; the Python shim re-raises the reference's exception types */
+enum {
+    CCSD_OK = 0,
+    CCSD_ERR_INVALID = 1,       /* ValueError: bad argument / shape / NULL */
+    CCSD_ERR_UNSUPPORTED = 2,   /* NotImplementedError: config outside the HIP path's envelope */
+    CCSD_ERR_WEIGHTS = 3,       /* ValueError: weight blob size does not match the config */
+    CCSD_ERR_RUNTIME = 4,       /* RuntimeError: HIP runtime failure (hipGetLastError text via ccsd_last_error) */
+    CCSD_ERR_WORKSPACE = 5      /* ValueError: workspace too small */
+};
+
+enum { CCSD_SDE_VP = 0, CCSD_SDE_VE = 1, CCSD_SDE_SUBVP = 2 };
+enum { CCSD_PRED_EULER = 0, CCSD_PRED_REVERSE = 1 };
+enum { CCSD_CORR_NONE = 0, CCSD_CORR_LANGEVIN = 1 };
+enum { CCSD_TARGET_X = 0, CCSD_TARGET_ADJ = 1, CCSD_TARGET_RANK2 = 2 };
+
+/* Per diffusion step, per target (x, adj, rank2) scalars.  The host computes them with the same
+ * fp32 arithmetic as the reference's SDE classes (sde.py) so that the device never re-derives a
+ * table index or a sigma:
+ *   sscale : score = sscale * net(...)      (1 for VE, -1/std(t) for VP/subVP; losses.py:157-163)
+ *   alpha  : Langevin alpha                 (alphas[timestep] for VP/subVP, 1 for VE; solver.py:752-756)
+ *   pa,pb,pc : predictor  v_mean = pa*v + pb*net ; v = v_mean + pc*z   (pb already includes sscale)
+ */
+typedef struct {
+    float sscale, alpha, pa, pb, pc;
+} ccsd_step_coef_t;
+
+typedef struct {
+    int32_t abi_version;        /* = CCSD_ABI_VERSION */
+    /* shapes */
+    int32_t N, F, is_cc, d_min, d_max;   /* E and K are derived: E=N(N-1)/2, K=sum C(N,k) */
+    /* ScoreNetworkX (ScoreNetwork_X.py:26-75) */
+    int32_t x_depth, x_nhid;
+    /* ScoreNetworkA / ScoreNetworkA_CC graph branch (ScoreNetwork_A.py:351-460) */
+    int32_t a_num_layers, a_num_linears, a_c_init, a_c_hid, a_c_final, a_nhid, a_adim, a_num_heads;
+    /* ScoreNetworkA_CC hodge branch (ScoreNetwork_A_CC.py:155-205); a_is_cc_net=0 -> ScoreNetworkA */
+    int32_t a_is_cc_net, h_num_layers, h_num_linears, h_nhid, h_adim, h_c_hid, h_c_final, h_num_heads;
+    /* ScoreNetworkF (ScoreNetwork_F.py:24-145) */
+    int32_t f_num_layers, f_num_linears, f_nhid, f_c_hid, f_c_final, f_cnum, f_num_layers_mlp, f_use_hodge_mask;
+    /* sampler (solver.py:856-875) */
+    int32_t predictor, corrector, n_corr_steps, probability_flow, denoise;
+    float snr, scale_eps;
+    int32_t diff_steps;         /* sde_adj.N == number of rows of step_coef */
+} ccsd_config_t;
+
+typedef struct ccsd_plan ccsd_plan_t;
+
+/* Build a plan: validates the config, uploads weights and tables to the current HIP device.
+ * `weights` is a HOST pointer to the canonical weight blob (order documented in DESIGN.md,
+ * produced by ccsd_amd.plan.pack_weights); `step_coef` is a HOST array [diff_steps][3]. */
+int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, size_t n_weights,
+                     const ccsd_step_coef_t* step_coef, ccsd_plan_t** out);
+void ccsd_plan_destroy(ccsd_plan_t* plan);
+
+/* number of floats the canonical weight blob must hold for this config (0 on invalid config) */
+size_t ccsd_weight_count(const ccsd_config_t* cfg);
+/* E and K for the config */
+void ccsd_rank2_dims(const ccsd_config_t* cfg, int32_t* E, int64_t* K);
+/* bytes of device scratch the step/run calls need for batch B */
+size_t ccsd_workspace_bytes(const ccsd_plan_t* plan, int32_t B);
+
+const char* ccsd_last_error(void);
+
+/* Device state of one batch shard: caller-owned, fp32, contiguous.  rank2 may be NULL when !is_cc. */
+typedef struct {
+    float* x;      /* dev (B,N,F) */
+    float* adj;    /* dev (B,N,N) */
+    float* rank2;  /* dev (B,E,K) */
+} ccsd_state_t;
+
+/* Noise of one half-step.  NULL pointers => counter-based Philox4x32-10 in-kernel, keyed by
+ * (seed, draw index, global sample index, element).  Non-NULL => the RAW standard-normal draw the
+ * reference would have obtained from randn_like (full (B,N,N) for adj; the kernel applies
+ * triu(1)+transpose and the flag masks exactly as gen_noise does, graph_utils.py:171-178). */
+typedef struct {
+    const float* zx;     /* dev (B,N,F) or NULL */
+    const float* zadj;   /* dev (B,N,N) or NULL */
+    const float* zrank2; /* dev (B,E,K) or NULL */
+} ccsd_noise_t;
+
+/* score = sscale(t) * net(x, adj, rank2, flags) for one target; `sscale` is passed by the caller
+ * (1 for VE, -1/std(t) for VP).  out has the target's shape. */
+int ccsd_score(ccsd_plan_t* plan, int32_t target, int32_t B, const ccsd_state_t* in, const float* flags_dev,
+               float sscale, float* out_dev, void* workspace, size_t workspace_bytes, void* stream);
+
+/* state <- masked prior.  prior==NULL: Philox draws (draw index 0..2); else mask the given raw draws. */
+int ccsd_init_state(ccsd_plan_t* plan, int32_t B, const float* flags_dev, const ccsd_noise_t* prior,
+                    uint64_t seed, int64_t sample_offset, ccsd_state_t* state, void* stream);
+
+/* Langevin corrector, phase 1: evaluate the three scores (all correctors see the same pre-corrector
+ * state `base`, solver.py:1129-1137; with n_steps > 1 each target's own tensor is taken from `cur`, its
+ * current inner iterate, solver.py:760-769; cur == base for the first inner step), keep them in the
+ * workspace, and write
+ * norm_sums_dev[6] = { sum_b ||net_x[b]||, sum_b ||net_adj[b]||, sum_b ||net_rank2[b]||,
+ *                      sum_b ||z_x[b]||,  sum_b ||z_adj[b]||,  sum_b ||z_rank2[b]|| }.
+ * In multi-GPU exact mode the caller all-reduces these six floats (RCCL) between the two phases. */
+int ccsd_corrector_norms(ccsd_plan_t* plan, int32_t B, int32_t step, int32_t corr_iter,
+                         const ccsd_state_t* base, const ccsd_state_t* cur, const float* flags_dev, const ccsd_noise_t* noise,
+                         uint64_t seed, int64_t sample_offset, float* norm_sums_dev,
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* phase 2: step_size = (snr*zn/gn)^2*2*alpha from norm_sums_dev; out = cur + step*score + sqrt(2 step)*z*scale_eps */
+int ccsd_corrector_apply(ccsd_plan_t* plan, int32_t B, int32_t step, int32_t corr_iter,
+                         const ccsd_state_t* cur, const float* flags_dev, const ccsd_noise_t* noise,
+                         uint64_t seed, int64_t sample_offset, const float* norm_sums_dev,
+                         ccsd_state_t* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* predictor half-step: out = pa*in + pb*net(in) + pc*z; mean (nullable) = pa*in + pb*net(in). */
+int ccsd_predictor(ccsd_plan_t* plan, int32_t B, int32_t step, const ccsd_state_t* in, const float* flags_dev,
+                   const ccsd_noise_t* noise, uint64_t seed, int64_t sample_offset,
+                   ccsd_state_t* out, ccsd_state_t* mean, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The whole loop with in-kernel Philox noise and per-shard Langevin norms (the reference's own
+ * divide_batch semantics, sampler.py:1199-1211).  `state` holds the prior on entry (see
+ * ccsd_init_state) and the last state on exit; `result` receives the means (denoise) or the state;
+ * `scratch` is a second state used for ping-pong.  traj_dev (nullable): [diff_steps][N*F+N*N+E*K]
+ * receives sample 0 of every step (diff_traj, solver.py:1150-1165).  first_step/last_step allow
+ * running a sub-range [first_step, last_step) of the diff_steps steps. */
+int ccsd_sampler_run(ccsd_plan_t* plan, int32_t B, const float* flags_dev, uint64_t seed, int64_t sample_offset,
+                     int32_t first_step, int32_t last_step, ccsd_state_t* state, ccsd_state_t* scratch,
+                     ccsd_state_t* result, float* traj_dev, void* workspace, size_t workspace_bytes, void* stream);
+
+/* quantize_mol: >=2.5->3, [1.5,2.5)->2, [0.5,1.5)->1, <0.5->0 (int64 out); thr<0 selects it, otherwise
+ * quantize(t, thr): t<thr ? 0 : 1. */
+int ccsd_quantize(const float* in_dev, int64_t n, float thr, int64_t* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCSD_HIP_H */

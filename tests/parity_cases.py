@@ -1,0 +1,282 @@
+"""Parity cases shared by the CPU-emulation suite (tests/test_emu_parity.py, runs anywhere) and the
+GPU suite (tests/test_gpu_parity.py, -m gpu).  Every case drives the product code (ccsd_amd.*) through
+the C ABI; `lib`/`device` select the backend: the HIP library on cuda:0, or the host emulation of the
+same kernel source on cpu."""
+import json
+
+import numpy as np
+import torch
+
+from ccsd_amd import loader, solver
+from ccsd_amd.engine import PCEngine
+from ccsd_amd.plan import rank2_dim
+from oracle import ccsd_oracle as O
+from tests.helpers import load_ckpt_np, load_golden, make_flags, rng_matches
+
+# float tolerance of the path (BASELINE.json north_star: scores within 1e-4 relative): relative to the
+# tensor's largest magnitude, since individual entries pass through zero.
+RTOL = 1e-4
+
+
+def assert_close(got: torch.Tensor, want, what: str, rtol: float = RTOL):
+    want = torch.as_tensor(want)
+    got = got.detach().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite values"
+    scale = max(want.abs().max().item(), 1e-6)
+    err = (got - want).abs().max().item()
+    assert err <= rtol * scale, f"{what}: max abs err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.2e} > {rtol})"
+
+
+def masked_state(seed, B, N, Fd, is_cc, d_min, d_max, flags, scale=1.0):
+    torch.manual_seed(seed)
+    x = O.mask_x(torch.randn(B, N, Fd) * scale, flags)
+    a = torch.randn(B, N, N).triu(1) * scale
+    adj = O.mask_adjs(a + a.transpose(-1, -2), flags)
+    if not is_cc:
+        return x, adj, None
+    E, K = O.get_rank2_dim(N, d_min, d_max)
+    return x, adj, O.mask_rank2(torch.randn(B, E, K) * scale, N, d_min, d_max, flags)
+
+
+def engine_from_ckpt(name, lib, device, **kw):
+    meta, parts = load_ckpt_np(name)
+    cfg, is_cc = meta["config"], meta["is_cc"]
+    N, Fd = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
+    d_min, d_max = (cfg["data"]["d_min"], cfg["data"]["d_max"]) if is_cc else (0, 0)
+    eng = PCEngine(meta["params_x"], parts["x"], meta["params_adj"], parts["adj"], meta.get("params_rank2"),
+                   parts.get("rank2"), N=N, F=Fd, is_cc=is_cc, d_min=d_min, d_max=d_max, device=device, lib=lib, **kw)
+    return eng, meta, parts
+
+
+def case_forward_vs_reference_golden(name, lib, device):
+    """G1: each network's forward on the golden inputs vs the reference's outputs."""
+    g = load_golden(f"g1_{name}.npz")
+    assert rng_matches(g)
+    eng, meta, _ = engine_from_ckpt(name, lib, device)
+    cfg, is_cc = meta["config"], meta["is_cc"]
+    N, Fd = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
+    d_min, d_max = (cfg["data"]["d_min"], cfg["data"]["d_max"]) if is_cc else (0, 0)
+    flags = torch.from_numpy(g["flags"])
+    B = flags.shape[0]
+    for tag, scale in (("unit", 1.0), ("small", 0.3)):
+        x, adj, rank2 = masked_state(int(g["seed"]), B, N, Fd, is_cc, d_min, d_max, flags, scale)
+        dv = lambda t: None if t is None else t.to(device)
+        for t, p in enumerate(["x", "adj"] + (["rank2"] if is_cc else [])):
+            out = eng.score(t, dv(x), dv(adj), dv(rank2), dv(flags))
+            assert_close(out, g[f"{tag}/net_{p}"], f"{name} {tag} net_{p}")
+            if tag == "unit" and f"unit/score_{p}_t1" in g.files:
+                sde = loader.load_sde(cfg["sde"][p])
+                tt = torch.ones(1) * 0.5
+                ss = 1.0 if sde.kind == "VE" else float(-1.0 / sde.marginal_prob(torch.zeros(1, 1, 1), tt)[1])
+                out = eng.score(t, dv(x), dv(adj), dv(rank2), dv(flags), ss)
+                assert_close(out, g[f"unit/score_{p}_t1"], f"{name} score_{p} t=0.5")
+
+
+def case_model_objects_forward(lib, device):
+    """The nn.Module-like objects: ctor kwargs, load_state_dict, forward (reference loader.py:619-657)."""
+    meta, parts = load_ckpt_np("ccsd_qm9_CC")
+    g = load_golden("g1_ccsd_qm9_CC.npz")
+    flags = torch.from_numpy(g["flags"])
+    x, adj, rank2 = masked_state(int(g["seed"]), 4, 9, 4, True, 3, 9, flags)
+    for p in ("x", "adj", "rank2"):
+        m = loader.load_model_from_ckpt(meta[f"params_{p}"], parts[p], device)
+        out = m(x.to(device), adj.to(device), rank2.to(device), flags.to(device), lib=lib)
+        assert_close(out, g[f"unit/net_{p}"], f"model object {p}")
+        assert set(m.state_dict().keys()) == set(parts[p].keys())
+
+
+def case_kat_small_general(lib, device):
+    """Small nets built by the reference constructors with num_linears_h=2 / num_layers_mlp=2 / 2-linear
+    HodgeNetworkLayers: the non-affine per-element paths."""
+    g = load_golden("kat_small_models.npz")
+    meta = json.loads(str(g["meta"]))
+    flags, x, adj, rank2 = (torch.from_numpy(g[k]).to(device) for k in ("flags", "x", "adj", "rank2"))
+    sd = lambda tag: {k[len(tag) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}/w/")}
+    eng = PCEngine(meta["x"], sd("x"), meta["adj"], sd("adj"), meta["rank2"], sd("rank2"), N=5, F=10, is_cc=True, d_min=3,
+                   d_max=4, device=device, lib=lib)
+    for t, tag in enumerate(["x", "adj", "rank2"]):
+        assert_close(eng.score(t, x, adj, rank2, flags), g[f"{tag}/out"], f"kat {tag}")
+    eng = PCEngine(None, None, meta["gadj"], sd("gadj"), None, None, N=5, F=10, is_cc=False, device=device, lib=lib)
+    assert_close(eng.score(1, x, adj, None, flags), g["gadj/out"], "kat graph-only A")
+
+
+def sampler_from_golden(g, ckpt, case, lib, device, rng="torch_cpu", **extra):
+    meta, parts = load_ckpt_np(ckpt)
+    cfg, is_cc = meta["config"], meta["is_cc"]
+    sm = json.loads(str(g["sampler"]))
+    N, Fd = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
+    flags = torch.from_numpy(g["flags"])
+    B = flags.shape[0]
+    num_scales = int(case[1:]) if case.startswith("k") else None
+    max_steps = None if case.startswith("k") else int(case.split("first")[1])
+    names = ["x", "adj"] + (["rank2"] if is_cc else [])
+    sdes = []
+    for p in names:
+        c = dict(cfg["sde"][p])
+        if num_scales is not None:
+            c["num_scales"] = num_scales
+        sdes.append(loader.load_sde(c))
+    models = [loader.load_model_from_ckpt(meta[f"params_{p}"], parts[p], device) for p in names]
+    kw = dict(sde_x=sdes[0], sde_adj=sdes[1], shape_x=(B, N, Fd), shape_adj=(B, N, N), predictor=sm["predictor"],
+              corrector=sm["corrector"], snr=sm["snr"], scale_eps=sm["scale_eps"], n_steps=sm["n_steps"],
+              probability_flow=False, continuous=True, denoise=True, eps=1e-4, device=device, rng=rng,
+              max_steps=max_steps, lib=lib)
+    if is_cc:
+        d_min, d_max = cfg["data"]["d_min"], cfg["data"]["d_max"]
+        kw.update(is_cc=True, sde_rank2=sdes[2], shape_rank2=(B, *rank2_dim(N, d_min, d_max)), d_min=d_min, d_max=d_max)
+    kw.update(extra)
+    return solver.get_pc_sampler(**kw), models, flags, names
+
+
+def case_pc_sampler_identical_seed(gname, ckpt, case, lib, device):
+    """G5: get_pc_sampler closure, every draw from torch's CPU generator -> the reference's CPU outputs."""
+    g = load_golden(f"g5_{gname}.npz")
+    assert rng_matches(g)
+    fn, models, flags, names = sampler_from_golden(g, ckpt, case, lib, device, keep_traj=True)
+    torch.manual_seed(int(g["seed"]))
+    res = fn(*models, flags.to(device))
+    for p, v in zip(names, res):
+        assert_close(v, g[f"{case}/{p}"], f"{gname} {case} {p}")
+    assert int(res[len(names)]) == int(g[f"{case}/nfe"])
+    assert len(res[-1]) == int(g[f"{case}/traj_len"])
+    assert_close(res[-1][-1][1], g[f"{case}/traj_last_adj"], "diff_traj[-1] adj")
+    # integer outputs: bit-exact (thresholds are >= 7e-4 away, g[*/min_thr_dist])
+    adj = res[1].cpu()
+    assert np.array_equal(O.quantize_mol(adj), g[f"{case}/quantize_mol_adj"])
+    assert np.array_equal(O.quantize(adj).numpy(), g[f"{case}/quantize_adj"])
+    eng = PCEngine(None, None, None, None, None, None, N=adj.shape[-1], F=1, is_cc=False, device=device, lib=lib)
+    assert np.array_equal(eng.quantize(res[1], -1.0).cpu().numpy(), g[f"{case}/quantize_mol_adj"])
+    assert np.array_equal(eng.quantize(res[1], 0.5).cpu().numpy(), g[f"{case}/quantize_adj"].astype(np.int64))
+    if "rank2" in names:
+        assert np.array_equal(eng.quantize(res[2], 0.5).cpu().numpy().astype(np.uint8), g[f"{case}/quantize_rank2"])
+
+
+def case_philox_properties(lib, device, B=6, steps=3):
+    """In-kernel Philox noise: determinism, masks, symmetry, seed sensitivity; single C call == stepwise calls."""
+    g = load_golden("g5_ccsd_qm9_CC.npz")
+    outs = {}
+    for tag, kw in {"a": dict(seed=11), "b": dict(seed=11), "c": dict(seed=12)}.items():
+        fn, models, _, names = sampler_from_golden(g, "ccsd_qm9_CC", "n1000_first%d" % steps, lib, device, rng="philox", **kw)
+        # B baked from the golden flags (4); rebuild with our own batch through load_sampling_fn-like path
+        outs[tag] = (fn, models)
+    flags = torch.from_numpy(g["flags"]).to(device)
+    ra = outs["a"][0](*outs["a"][1], flags)
+    rb = outs["b"][0](*outs["b"][1], flags)
+    rc = outs["c"][0](*outs["c"][1], flags)
+    for va, vb, vc, p in zip(ra[:3], rb[:3], rc[:3], ["x", "adj", "rank2"]):
+        assert torch.equal(va, vb), f"philox run not deterministic for {p}"
+        assert not torch.equal(va, vc), f"seed does not change {p}"
+        assert torch.isfinite(va).all()
+    x, adj, rank2 = (t.cpu() for t in ra[:3])
+    fl = flags.cpu()
+    assert torch.equal(x, O.mask_x(x, fl)) and torch.equal(adj, O.mask_adjs(adj, fl))
+    assert torch.equal(rank2, O.mask_rank2(rank2, 9, 3, 9, fl))
+    assert torch.allclose(adj, adj.transpose(-1, -2), atol=1e-5), "adjacency not symmetric"
+    assert (adj.diagonal(dim1=-2, dim2=-1) == 0).all()
+    # stepwise driver (used for the exact multi-GPU mode) must reproduce the single C call bit-for-bit
+    fn, models, _, _ = sampler_from_golden(g, "ccsd_qm9_CC", "n1000_first%d" % steps, lib, device, rng="philox", seed=11,
+                                           group=_FakeGroup())
+    rs = fn(*models, flags)
+    for va, vs, p in zip(ra[:3], rs[:3], ["x", "adj", "rank2"]):
+        assert torch.equal(va, vs), f"stepwise != fused loop for {p}"
+
+
+class _FakeGroup:
+    """Stands in for a 1-rank process group: solver._stepwise all-reduces through torch.distributed only
+    when initialised; with a single rank the sum is the identity."""
+
+
+def case_philox_prior_statistics(lib, device):
+    eng, _, _ = engine_from_ckpt("ccsd_qm9_CC", lib, device)
+    B = 64
+    flags = torch.ones(B, 9, device=device)
+    st = eng.alloc_state(B)
+    eng.init_state(flags, st, None, seed=1234)
+    x, adj, r = (t.cpu() for t in st)
+    assert abs(r.mean().item()) < 5e-3 and abs(r.std().item() - 1.0) < 5e-3
+    iu = torch.triu_indices(9, 9, 1)
+    up = adj[:, iu[0], iu[1]]
+    assert abs(up.mean().item()) < 0.08 and abs(up.std().item() - 1.0) < 0.08
+    assert abs(x.std().item() - 1.0) < 0.08
+    # kurtosis of a normal = 3
+    assert abs(((r - r.mean()) ** 4).mean().item() / r.var().item() ** 2 - 3.0) < 0.05
+    # different samples / draws are decorrelated
+    assert abs((r[0] * r[1]).mean().item()) < 0.03
+    st2 = eng.alloc_state(B)
+    eng.init_state(flags, st2, None, seed=1234, sample_offset=B)
+    assert not torch.equal(st2[2].cpu()[0], r[0])
+    eng.init_state(flags, st2, None, seed=1234, sample_offset=1)
+    assert torch.equal(st2[2].cpu()[0], r[1]), "sample_offset must shift the global sample index"
+
+
+def case_one_step_vs_oracle_large(name, lib, device, B, counts, predictor, corrector, snr, seps, seed=3):
+    """One full PC step with host-supplied noise on a bigger batch, against the oracle (not the goldens)."""
+    meta, parts = load_ckpt_np(name)
+    cfg, is_cc = meta["config"], meta["is_cc"]
+    N, Fd = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
+    names = ["x", "adj"] + (["rank2"] if is_cc else [])
+    flags = make_flags(B, N, counts)
+    kw = dict(shape_x=(B, N, Fd), shape_adj=(B, N, N), predictor=predictor, corrector=corrector, snr=snr, scale_eps=seps,
+              n_steps=1, probability_flow=False, continuous=True, denoise=True, eps=1e-4)
+    if is_cc:
+        d_min, d_max = cfg["data"]["d_min"], cfg["data"]["d_max"]
+        kw.update(is_cc=True, shape_rank2=(B, *rank2_dim(N, d_min, d_max)), d_min=d_min, d_max=d_max)
+    sd = [loader.load_sde(cfg["sde"][p]) for p in names]
+    ms = [loader.load_model_from_ckpt(meta[f"params_{p}"], parts[p], device) for p in names]
+    skw = dict(sde_x=sd[0], sde_adj=sd[1])
+    if is_cc:
+        skw["sde_rank2"] = sd[2]
+    fn = solver.get_pc_sampler(device=device, rng="torch_cpu", max_steps=1, lib=lib, **skw, **kw)
+    torch.manual_seed(seed)
+    got = fn(*ms, flags.to(device))
+    so = [O.load_sde(cfg["sde"][p]) for p in names]
+    okw = dict(sde_x=so[0], sde_adj=so[1])
+    if is_cc:
+        okw["sde_rank2"] = so[2]
+        nets = [(lambda x, a, r, f, p=p: O.run_network(meta[f"params_{p}"], parts[p], x, a, r, f)) for p in names]
+    else:
+        nets = [(lambda x, a, f, p=p: O.run_network(meta[f"params_{p}"], parts[p], x, a, None, f)) for p in names]
+    ofn = O.get_pc_sampler(n_diff_steps=1, keep_traj=False, **okw, **kw)
+    torch.manual_seed(seed)
+    want = ofn(*nets, flags)
+    for p, g_, w_ in zip(names, got, want):
+        assert_close(g_, w_, f"{name} B={B} one step {p}")
+
+
+def case_error_behaviour(lib, device):
+    """Same exception types as the reference for the same mistakes (SURVEY.md section 8b 'Errors')."""
+    import pytest
+
+    s = loader.load_sde(dict(type="VE", beta_min=0.1, beta_max=1.0, num_scales=4))
+    with pytest.raises(NotImplementedError):
+        solver.get_pc_sampler(s, s, (1, 3, 2), (1, 3, 3), predictor="Heun", continuous=True, lib=lib)
+    with pytest.raises(NotImplementedError):
+        solver.get_pc_sampler(s, s, (1, 3, 2), (1, 3, 3), corrector="MALA", continuous=True, lib=lib)
+    with pytest.raises(NotImplementedError):
+        loader.load_sde(dict(type="foo", beta_min=0.1, beta_max=1.0, num_scales=4))
+    with pytest.raises(ValueError):
+        loader.load_model({"model_type": "nope"})
+    with pytest.raises(ValueError):   # ScoreNetworkA_CC(is_cc=False), ScoreNetwork_A_CC.py:225-226
+        loader.load_model(dict(model_type="ScoreNetworkA_CC", max_feat_num=2, max_node_num=4, d_min=3, d_max=3, nhid=2,
+                               nhid_h=2, num_layers=2, num_layers_h=1, num_linears=1, num_linears_h=1, c_init=1, c_hid=2,
+                               c_hid_h=2, c_final=2, c_final_h=2, adim=2, adim_h=2, is_cc=False))
+    # continuous=False -> NotImplementedError at the first score evaluation (losses.py:69,161)
+    meta, parts = load_ckpt_np("gdss_community_small")
+    ms = [loader.load_model_from_ckpt(meta[f"params_{p}"], parts[p], device) for p in ("x", "adj")]
+    sv = loader.load_sde(dict(type="VP", beta_min=0.1, beta_max=1.0, num_scales=4))
+    fn = solver.get_pc_sampler(sv, sv, (2, 20, 10), (2, 20, 20), continuous=False, device=device, lib=lib)
+    with pytest.raises(NotImplementedError):
+        fn(*ms, torch.ones(2, 20, device=device))
+    # probability_flow with the Euler predictor dies like the reference does (sde.py:301 / solver.py:284)
+    fn = solver.get_pc_sampler(sv, sv, (2, 20, 10), (2, 20, 20), predictor="Euler", probability_flow=True, continuous=True,
+                               device=device, lib=lib)
+    with pytest.raises(TypeError):
+        fn(*ms, torch.ones(2, 20, device=device))
+    # wrong flag batch
+    fn = solver.get_pc_sampler(sv, sv, (2, 20, 10), (2, 20, 20), continuous=True, device=device, lib=lib)
+    with pytest.raises(ValueError):
+        fn(*ms, torch.ones(3, 20, device=device))
+    # state-dict mismatch
+    with pytest.raises(RuntimeError):
+        loader.load_model(meta["params_x"]).load_state_dict({"bogus": torch.zeros(1)})

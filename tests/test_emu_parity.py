@@ -1,0 +1,59 @@
+"""CPU suite: the product code (ccsd_amd.*) driven through the C ABI of the HOST EMULATION of the kernel
+source (tests/emu, see ccsd_amd/csrc/ccsd_rt.h) against the reference goldens and the oracle.  This checks
+indexing, weight layout, masks, SDE tables, draw order and the step orchestration on the GPU-less build
+box; the MFMA / wave-level code paths are covered by tests/test_gpu_parity.py (-m gpu)."""
+import pytest
+import torch
+
+from tests import parity_cases as pc
+from tests.emu_util import emu_library
+
+torch.set_num_threads(8)
+DEV = "cpu"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return emu_library()
+
+
+@pytest.mark.parametrize("name", ["ccsd_qm9_CC", "gdss_community_small"])
+def test_forward_vs_reference_golden(lib, name):
+    pc.case_forward_vs_reference_golden(name, lib, DEV)
+
+
+def test_forward_community_small_cc(lib):
+    pc.case_forward_vs_reference_golden("ccsd_community_small_CC", lib, DEV)
+
+
+def test_model_objects(lib):
+    pc.case_model_objects_forward(lib, DEV)
+
+
+def test_kat_small_general_paths(lib):
+    pc.case_kat_small_general(lib, DEV)
+
+
+@pytest.mark.parametrize("gname,ckpt,case", [
+    ("ccsd_qm9_CC", "ccsd_qm9_CC", "k10"),
+    ("ccsd_qm9_CC", "ccsd_qm9_CC", "n1000_first3"),
+    ("gdss_community_small", "gdss_community_small", "k10"),
+    ("gdss_community_small", "gdss_community_small", "n1000_first3"),
+    ("ccsd_qm9_CC_nsteps2_none", "ccsd_qm9_CC", "k6"),
+    ("ccsd_qm9_CC_langevin2", "ccsd_qm9_CC", "k4"),
+    ("ccsd_community_small_CC", "ccsd_community_small_CC", "n1000_first2"),
+])
+def test_pc_sampler_identical_seed(lib, gname, ckpt, case):
+    pc.case_pc_sampler_identical_seed(gname, ckpt, case, lib, DEV)
+
+
+def test_philox_properties(lib):
+    pc.case_philox_properties(lib, DEV)
+
+
+def test_philox_prior_statistics(lib):
+    pc.case_philox_prior_statistics(lib, DEV)
+
+
+def test_error_behaviour(lib):
+    pc.case_error_behaviour(lib, DEV)
