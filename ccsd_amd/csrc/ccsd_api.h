@@ -20,7 +20,28 @@ struct ccsd_plan {
     unsigned long long* cells = nullptr;
     std::vector<ccsd_step_coef_t> coef;  // [diff_steps][3]
     size_t nweights = 0;
+    // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
+    int prof_kernel = -1;
+    size_t prof_used = 0;
+#ifndef CCSD_EMU
+    std::vector<hipEvent_t> prof_ev;
+#endif
 };
+
+enum { KID_XA = 0, KID_GEMM_P = 1, KID_HF = 2, KID_GEMM_H = 3, KID_LANGEVIN = 4 };
+static void prof_mark(ccsd_plan* pl, int kid, void* stream) {
+#ifndef CCSD_EMU
+    if (pl->prof_kernel != kid) return;
+    if (pl->prof_used == pl->prof_ev.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        pl->prof_ev.push_back(e);
+    }
+    (void)hipEventRecord(pl->prof_ev[pl->prof_used++], (hipStream_t)stream);
+#else
+    (void)pl; (void)kid; (void)stream;
+#endif
+}
 
 #define RT_CHECK(expr)                                                                    \
     do {                                                                                  \
@@ -49,8 +70,32 @@ extern "C" size_t ccsd_weight_count(const ccsd_config_t* cfg) {
     return n;
 }
 
+extern "C" int ccsd_profile_kernel(ccsd_plan_t* plan, int32_t kernel_id) {
+    if (!plan) return set_err(CCSD_ERR_INVALID, "NULL plan");
+    plan->prof_kernel = kernel_id;
+    plan->prof_used = 0;
+    return CCSD_OK;
+}
+extern "C" int ccsd_profile_read(ccsd_plan_t* plan, int64_t* launches, double* total_ms) {
+    if (!plan || !launches || !total_ms) return set_err(CCSD_ERR_INVALID, "NULL argument");
+    *launches = 0; *total_ms = 0.0;
+#ifndef CCSD_EMU
+    for (size_t i = 0; i + 1 < plan->prof_used; i += 2) {
+        float ms = 0.f;
+        RT_CHECK(hipEventSynchronize(plan->prof_ev[i + 1]));
+        RT_CHECK(hipEventElapsedTime(&ms, plan->prof_ev[i], plan->prof_ev[i + 1]));
+        *total_ms += ms; *launches += 1;
+    }
+#endif
+    plan->prof_used = 0;
+    return CCSD_OK;
+}
+
 extern "C" void ccsd_plan_destroy(ccsd_plan_t* plan) {
     if (!plan) return;
+#ifndef CCSD_EMU
+    for (hipEvent_t e : plan->prof_ev) (void)hipEventDestroy(e);
+#endif
     if (plan->d) (void)rt_free(plan->d);
     if (plan->w) (void)rt_free(plan->w);
     if (plan->edges) (void)rt_free(plan->edges);
@@ -186,7 +231,9 @@ static int launch_h(const ccsd_plan* pl, int B, const float* rank2, Workspace& w
     const PlanD& p = pl->h;
     if (!p.is_cc || p.f_cnum < 2) return CCSD_OK;
     dim3 g((p.E + T_BN - 1) / T_BN, (p.E + T_BM - 1) / T_BM, B);
+    prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_H, stream);
     CCSD_LAUNCH(k_gemm_h, g, dim3(CCSD_NTHREADS), 0, stream, rank2, w.H, p.E, p.K, p.f_hmask);
+    prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_H, stream);
     LAUNCH_CHECK();
     return CCSD_OK;
 }
@@ -219,17 +266,21 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
 }
 static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Workspace& w, void* stream) {
     xa.P0 = w.P0; xa.P1 = w.P1;
+    prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
     CCSD_LAUNCH(k_xa, dim3(B), dim3(CCSD_NTHREADS), (size_t)pl->h.xa_lds_floats * 4, stream, (const PlanD*)pl->d,
                 (const float*)pl->w, (const unsigned char*)pl->edges, xa, na);
+    prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
     LAUNCH_CHECK();
     return CCSD_OK;
 }
 static int launch_hf(const ccsd_plan* pl, int B, const float* rank2, RankEpi& ep, NoiseArgs& na, Workspace& w, void* stream) {
     const PlanD& p = pl->h;
     dim3 g((p.K + T_BN - 1) / T_BN, (p.E + T_BM - 1) / T_BM, B);
+    prof_mark(const_cast<ccsd_plan*>(pl), KID_HF, stream);
     CCSD_LAUNCH(k_hf_score, g, dim3(CCSD_NTHREADS), 0, stream, (const PlanD*)pl->d, (const float*)pl->w, rank2,
                 (const float*)w.H, (const unsigned long long*)w.offbits, (const unsigned char*)pl->edges,
                 (const unsigned long long*)pl->cells, ep, na);
+    prof_mark(const_cast<ccsd_plan*>(pl), KID_HF, stream);
     LAUNCH_CHECK();
     return CCSD_OK;
 }

@@ -101,13 +101,13 @@ def case_kat_small_general(lib, device):
     assert_close(eng.score(1, x, adj, None, flags), g["gadj/out"], "kat graph-only A")
 
 
-def sampler_from_golden(g, ckpt, case, lib, device, rng="torch_cpu", **extra):
+def sampler_from_golden(g, ckpt, case, lib, device, rng="torch_cpu", shape_override=None, **extra):
     meta, parts = load_ckpt_np(ckpt)
     cfg, is_cc = meta["config"], meta["is_cc"]
     sm = json.loads(str(g["sampler"]))
     N, Fd = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
     flags = torch.from_numpy(g["flags"])
-    B = flags.shape[0]
+    B = flags.shape[0] if shape_override is None else shape_override
     num_scales = int(case[1:]) if case.startswith("k") else None
     max_steps = None if case.startswith("k") else int(case.split("first")[1])
     names = ["x", "adj"] + (["rank2"] if is_cc else [])
