@@ -47,6 +47,22 @@ def qm9_flags(B: int, seed: int = 42) -> torch.Tensor:
     return f
 
 
+def log(msg: str):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads() -> int:
+    """CPU share of this process: affinity mask, capped by the cgroup quota and by 16 (the GPU box's share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def load_qm9():
     from tests.helpers import load_ckpt_np
 
@@ -57,8 +73,9 @@ def cpu_baseline(B: int, steps: int = 2, warm: int = 1):
     """The oracle (CPU restatement certified bit-identical to the reference) timed on the host cores."""
     from oracle import ccsd_oracle as O
 
-    threads = os.cpu_count() or 1
+    threads = host_threads()
     torch.set_num_threads(threads)
+    log(f"cpu_baseline: oracle on {threads} host threads, B={B}")
     meta, parts = load_qm9()
     cfg = meta["config"]
     names = ["x", "adj", "rank2"]
@@ -69,10 +86,13 @@ def cpu_baseline(B: int, steps: int = 2, warm: int = 1):
               predictor="Reverse", corrector="Langevin", snr=0.2, scale_eps=0.7, n_steps=1, continuous=True, denoise=True,
               eps=1e-4, is_cc=True, d_min=3, d_max=9, keep_traj=False)
     torch.manual_seed(0)
+    t0 = time.perf_counter()
     O.get_pc_sampler(n_diff_steps=warm, **kw)(*nets, flags)
+    log(f"cpu_baseline: warm-up step took {time.perf_counter() - t0:.1f} s")
     t0 = time.perf_counter()
     O.get_pc_sampler(n_diff_steps=steps, **kw)(*nets, flags)
     dt = (time.perf_counter() - t0) / steps
+    log(f"cpu_baseline: {dt:.2f} s / PC step")
     return {"value": B / (dt * 1000.0), "unit": "complexes/s at 1000 PC steps", "cores": threads, "kind": "port",
             "sample": f"oracle (torch CPU, {threads} threads), B={B}, {steps} PC steps after {warm} warm-up, scaled to 1000 steps"}
 
@@ -135,6 +155,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log(f"rank {rank}/{world}: plan built, B={B} per GPU, warm-up {args.warmup} steps")
     eng.init_state(flags, state, None, seed, off)
     run_steps(0, args.warmup)
     eng.init_state(flags, state, None, seed, off)          # the timed region starts from a fresh prior, inputs resident
@@ -152,6 +173,7 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
+    log(f"timed region: {args.steps} steps in {dt:.3f} s")
     launches, kms = eng.profile_read() if not args.no_kernel_events else (0, 0.0)
     eng.profile_kernel(None)
     ok = all(torch.isfinite(t).all().item() for t in result)
