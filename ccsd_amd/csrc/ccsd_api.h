@@ -267,7 +267,7 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
 static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Workspace& w, void* stream) {
     xa.P0 = w.P0; xa.P1 = w.P1;
     prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
-    CCSD_LAUNCH(k_xa, dim3(B), dim3(CCSD_NTHREADS), (size_t)pl->h.xa_lds_floats * 4, stream, (const PlanD*)pl->d,
+    CCSD_LAUNCH(k_xa, dim3(B), dim3(CCSD_NTHREADS == 1 ? 1 : 512), (size_t)pl->h.xa_lds_floats * 4, stream, (const PlanD*)pl->d,
                 (const float*)pl->w, (const unsigned char*)pl->edges, xa, na);
     prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
     LAUNCH_CHECK();

@@ -21,7 +21,46 @@
 // ---------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------
-CCSD_DEV float elu1(float v) { return v > 0.f ? v : expm1f(v); }  // F.elu, alpha = 1
+// exp(x) through the hardware base-2 exponential (v_exp_f32, ~1 ulp)
+CCSD_DEV float fast_exp(float x) {
+#ifdef CCSD_EMU
+    return exp2f(x * 1.4426950408889634f);
+#else
+    return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+#endif
+}
+CCSD_DEV float fast_rcp(float x) {
+#ifdef CCSD_EMU
+    return 1.0f / x;
+#else
+    return __builtin_amdgcn_rcpf(x);
+#endif
+}
+// tanh to ~2e-7 absolute / 3e-6 relative: odd polynomial near 0 (no cancellation), 1 - 2/(e^{2x}+1) elsewhere
+CCSD_DEV float tanh_f(float x) {
+    const float ax = fabsf(x);
+    if (ax < 0.1f) {
+        const float x2 = x * x;
+        return x * fmaf(x2, fmaf(x2, fmaf(x2, -0.05396825397f, 0.13333333333f), -0.33333333333f), 1.0f);
+    }
+    const float e = fast_exp(2.0f * ax);            // overflows to +inf for large |x| -> 1 - 0 = 1
+    const float t = 1.0f - 2.0f * fast_rcp(e + 1.0f);
+    return x < 0.f ? -t : t;
+}
+// F.elu, alpha = 1: x > 0 ? x : expm1(x); expm1 by series near 0, exp(x) - 1 elsewhere (rel. error ~1e-6)
+CCSD_DEV float elu1(float v) {
+    if (v > 0.f) return v;
+    if (v > -0.1f) return v * fmaf(v, fmaf(v, fmaf(v, fmaf(v, 0.00833333333f, 0.04166666667f), 0.16666666667f), 0.5f), 1.0f);
+    return fast_exp(v) - 1.0f;
+}
+// t / d and t % d for 0 <= t < 2^22 and small d without the ~40-instruction integer division:
+// (t + 0.5) * (1/d) is never within 0.5/d of an integer, far more than the fp32 rounding of the product.
+struct FastDiv {
+    int d; float inv;
+    CCSD_DEV explicit FastDiv(int dd) : d(dd), inv(1.0f / (float)dd) {}
+    CCSD_DEV int div(int t) const { return (int)(((float)t + 0.5f) * inv); }
+    CCSD_DEV void divmod(int t, int& q, int& r) const { q = div(t); r = t - q * d; }
+};
 
 struct NoiseArgs {
     const float* zx;
@@ -147,21 +186,23 @@ CCSD_DEV void small_mlp(const MlpD& m, const float* __restrict__ w, const float*
 
 // ---------------------------------------------------------------------------------------------
 // block_linear: Y[o][m] = act( sum_k X[k][m] * W[o][k] + b[o] )  for m < rows, o < out.
-// X, Y: LDS, feature-major with row stride ld (ld == 16 mod 32 -> conflict-free fragment reads).
+// X, Y: LDS, feature-major (row stride ldx / ldy; strides == 16 mod 32 give conflict-free fragment
+// reads).  The input features may come from two arrays: k < ksplit from X, the rest from X2 (the
+// [attention | adjacency] concatenation of attention.py:295-297 is never materialised).
 // W: global, torch Linear layout [out][in].  One MFMA f32 16x16x4 output tile per task, tasks
 // round-robin over the waves of the workgroup.  The accumulation is a k-ordered fmaf chain, the
 // same as the emulation loop below.
 // ---------------------------------------------------------------------------------------------
 template <int ACT>  // 0 none, 1 ELU
-CCSD_DEV void block_linear(float* Y, const float* X, const float* __restrict__ W, const float* __restrict__ bias,
-                           int in, int out, int rows, int ld) {
+CCSD_DEV void block_linear(float* Y, int ldy, const float* X, int ldx, const float* X2, int ksplit,
+                           const float* __restrict__ W, const float* __restrict__ bias, int in, int out, int rows) {
 #ifdef CCSD_EMU
     for (int o = 0; o < out; ++o)
         for (int m = 0; m < rows; ++m) {
             float acc = 0.f;
-            for (int k = 0; k < in; ++k) acc = fmaf(X[k * ld + m], W[o * in + k], acc);
+            for (int k = 0; k < in; ++k) acc = fmaf(k < ksplit ? X[k * ldx + m] : X2[(k - ksplit) * ldx + m], W[o * in + k], acc);
             acc += bias[o];
-            Y[o * ld + m] = ACT ? elu1(acc) : acc;
+            Y[o * ldy + m] = ACT ? elu1(acc) : acc;
         }
 #else
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -171,23 +212,25 @@ CCSD_DEV void block_linear(float* Y, const float* X, const float* __restrict__ W
     for (int task = wave; task < mt * nt; task += nw) {
         const int m0 = (task % mt) << 4, n0 = (task / mt) << 4;
         const int bn = n0 + l15;
-        const float* xr = X + m0 + l15;
+        const int am = (m0 + l15 < rows) ? m0 + l15 : rows - 1;      // clamp: rows beyond `rows` are never stored
         const float* wr = W + (size_t)(bn < out ? bn : 0) * in;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int s = 0; s < ks; ++s) {
             const int k = 4 * s + kq;
             const bool kin = k < in;
-            const float a = kin ? xr[k * ld] : 0.f;
+            const float* xp = k < ksplit ? X + k * ldx : X2 + (k - ksplit) * ldx;
+            const float a = kin ? xp[am] : 0.f;
             const float bv = (kin && bn < out) ? wr[k] : 0.f;
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
         }
         if (bn < out) {
             const float bb = bias[bn];
-            float* yr = Y + bn * ld + m0 + 4 * kq;
+            float* yr = Y + bn * ldy;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 4 * kq + r;
                 const float v = acc[r] + bb;
-                yr[r] = ACT ? elu1(v) : v;
+                if (m < rows) yr[m] = ACT ? elu1(v) : v;
             }
         }
     }
@@ -547,23 +590,20 @@ struct XaArgs {
     float* norm2;                         // NORMS: [B][4] = |net_x|^2, |net_adj|^2, |z_x|^2, |z_adj|^2
 };
 
-// D^-1/2 (A + self loops) D^-1/2 of one channel into `an`   (DenseGCNConv, layers.py:139-147)
-CCSD_DEV void gcn_normalize(const float* a, float* an, float* deg, int N) {
-    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+// clamp(rowsum(A with unit diagonal), 1)^-1/2 for `nc` channels   (DenseGCNConv, layers.py:139-145)
+CCSD_DEV void gcn_dinv(const float* a, float* dinv, int nc, int N) {
+    const FastDiv dN(N);
+    for (int t = threadIdx.x; t < nc * N; t += blockDim.x) {
+        int c, i;
+        dN.divmod(t, c, i);
+        const float* r = a + c * N * N + i * N;
         float s = 0.f;
-        for (int j = 0; j < N; ++j) s += (i == j) ? 1.f : a[i * N + j];
-        deg[i] = 1.0f / sqrtf(fmaxf(s, 1.f));
+        for (int j = 0; j < N; ++j) s += (i == j) ? 1.f : r[j];
+        dinv[t] = 1.0f / sqrtf(fmaxf(s, 1.f));
     }
-    __syncthreads();
-    for (int t = threadIdx.x; t < N * N; t += blockDim.x) {
-        const int i = t / N, j = t % N;
-        const float v = (i == j) ? 1.f : a[t];
-        an[t] = deg[i] * v * deg[j];
-    }
-    __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_xa(const PlanD* __restrict__ plan, const float* __restrict__ w,
+__global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, const float* __restrict__ w,
                                             const unsigned char* __restrict__ edges, XaArgs xa, NoiseArgs na) {
     CCSD_DYN_SMEM(sm);
     const PlanD& p = *plan;
@@ -572,11 +612,11 @@ __global__ __launch_bounds__(256) void k_xa(const PlanD* __restrict__ plan, cons
     float* s_flags = sm + p.o_flags;
     float* s_x = sm + p.o_x;
     float* s_adj = sm + p.o_adj;
-    float* s_an = sm + p.o_an;
+    float* s_dinv = sm + p.o_an;
     float* s_tmp = sm + p.o_tmp;
-    float* s_xw = sm + p.o_xw;
-    float* s_qkv = sm + p.o_qkv;
     float* s_red = sm + p.o_red;
+    float* s_R = sm + p.o_c0;            // shared region: GCN scratch | MLP hidden activations | dense hodge layer
+    const FastDiv dN(N), dNN(NN), dF(F), dE(E > 0 ? E : 1);
 
     for (int i = tid; i < N; i += nth) s_flags[i] = xa.flags[(size_t)b * N + i];
     float nx_net = 0.f, nx_z = 0.f, na_net = 0.f, na_z = 0.f;
@@ -586,43 +626,48 @@ __global__ __launch_bounds__(256) void k_xa(const PlanD* __restrict__ plan, cons
         float* s_xcat = sm + p.o_xcat;
         float* s_h1 = sm + p.o_h1;
         float* s_h2 = sm + p.o_h2;
+        float* s_xw = s_R;
         for (int i = tid; i < N * F; i += nth) s_x[i] = xa.xX[(size_t)b * N * F + i];
         for (int i = tid; i < NN; i += nth) s_adj[i] = xa.adjX[(size_t)b * NN + i];
         __syncthreads();
-        gcn_normalize(s_adj, s_an, s_tmp, N);
-        for (int t = tid; t < N * F; t += nth) s_xcat[(t % F) * ldn + t / F] = s_x[t];
+        gcn_dinv(s_adj, s_dinv, 1, N);
+        for (int t = tid; t < N * F; t += nth) { int i, f; dF.divmod(t, i, f); s_xcat[f * ldn + i] = s_x[t]; }
         __syncthreads();
         const int H = p.x_nhid;
+        const FastDiv dH(H);
         for (int l = 0; l < p.x_depth; ++l) {
             const int fin = l ? H : F;
             const float* src = s_xcat + (l ? (F + (l - 1) * H) : 0) * ldn;
             const float* W = w + p.x_gw[l];
             const float* B = w + p.x_gb[l];
-            for (int t = tid; t < N * H; t += nth) {  // out = x @ W
-                const int i = t / H, o = t % H;
+            for (int t = tid; t < N * H; t += nth) {  // d_j * (x @ W)[j]
+                int j, o;
+                dH.divmod(t, j, o);
                 float acc = 0.f;
-                for (int k = 0; k < fin; ++k) acc = fmaf(src[k * ldn + i], W[k * H + o], acc);
-                s_xw[t] = acc;
+                for (int k = 0; k < fin; ++k) acc = fmaf(src[k * ldn + j], W[k * H + o], acc);
+                s_xw[t] = acc * s_dinv[j];
             }
             __syncthreads();
             float* dst = s_xcat + (F + l * H) * ldn;
-            for (int t = tid; t < N * H; t += nth) {  // tanh(adj_n @ out + b)
-                const int i = t / H, o = t % H;
+            for (int t = tid; t < N * H; t += nth) {  // tanh(d_i * sum_j A'_ij (.) + b)
+                int i, o;
+                dH.divmod(t, i, o);
                 float acc = 0.f;
-                for (int j = 0; j < N; ++j) acc = fmaf(s_an[i * N + j], s_xw[j * H + o], acc);
-                dst[o * ldn + i] = tanhf(acc + B[o]);
+                for (int j = 0; j < N; ++j) acc = fmaf((i == j) ? 1.f : s_adj[i * N + j], s_xw[j * H + o], acc);
+                dst[o * ldn + i] = tanh_f(fmaf(acc, s_dinv[i], B[o]));
             }
             __syncthreads();
         }
         const MlpD& m = p.x_fin;
-        block_linear<1>(s_h1, s_xcat, w + m.w[0], w + m.b[0], m.in, m.hid, N, ldn);
+        block_linear<1>(s_h1, ldn, s_xcat, ldn, s_xcat, m.in, w + m.w[0], w + m.b[0], m.in, m.hid, N);
         __syncthreads();
-        block_linear<1>(s_h2, s_h1, w + m.w[1], w + m.b[1], m.hid, m.hid, N, ldn);
+        block_linear<1>(s_h2, ldn, s_h1, ldn, s_h1, m.hid, w + m.w[1], w + m.b[1], m.hid, m.hid, N);
         __syncthreads();
-        block_linear<0>(s_h1, s_h2, w + m.w[2], w + m.b[2], m.hid, m.out, N, ldn);
+        block_linear<0>(s_h1, ldn, s_h2, ldn, s_h2, m.hid, w + m.w[2], w + m.b[2], m.hid, m.out, N);
         __syncthreads();
         for (int t = tid; t < N * F; t += nth) {
-            const int i = t / F, f = t % F;
+            int i, f;
+            dF.divmod(t, i, f);
             const float fl = s_flags[i];
             const float net = s_h1[f * ldn + i] * fl;                   // mask_x, graph_utils.py:37
             const size_t gi = (size_t)b * N * F + t;
@@ -651,298 +696,330 @@ __global__ __launch_bounds__(256) void k_xa(const PlanD* __restrict__ plan, cons
         float* s_xcur = sm + p.o_xcur;
         float* s_xnext = sm + p.o_xnext;
         float* s_mch = sm + p.o_vcat;
-        float* s_c0 = sm + p.o_c0;
-        float* s_c1 = sm + p.o_c1;
-        const int ldp = p.ldp, pch = p.pch;
         for (int t = tid; t < N * F; t += nth) {
             const float v = xa.xA[(size_t)b * N * F + t];
-            s_xcur[(t % F) * ldn + t / F] = v;
+            int i, f;
+            dF.divmod(t, i, f);
+            s_xcur[f * ldn + i] = v;
         }
         for (int i = tid; i < NN; i += nth) { const float v = xa.adjA[(size_t)b * NN + i]; s_adj[i] = v; s_chan[i] = v; }
         __syncthreads();
         // pow_tensor: channel c = channel(c-1) @ adj   (graph_utils.py:285-292)
         for (int c = 1; c < p.a_cinit; ++c) {
             for (int t = tid; t < NN; t += nth) {
-                const int i = t / N, j = t % N;
+                int i, j;
+                dN.divmod(t, i, j);
                 float acc = 0.f;
                 for (int k = 0; k < N; ++k) acc = fmaf(s_chan[(c - 1) * NN + i * N + k], s_adj[k * N + j], acc);
                 s_chan[c * NN + t] = acc;
             }
             __syncthreads();
         }
-        // ---- AttentionLayer stack (attention.py:270-304)
+        // ---- AttentionLayer stack (attention.py:270-304); channels are processed `cg` at a time
         for (int l = 0; l < p.a_L; ++l) {
             const AttnLayerD& L = p.al[l];
             const int cols = 2 * L.adim + L.fout;
+            const FastDiv dcols(cols), dNcols(N * cols);
             const float inv_scale = (float)sqrt((double)L.fout);  // attention.py:121: / math.sqrt(out_dim)
-            // multi_channel MLP, first Linear: its input is cat_c V_c, so accumulate channel by channel
-            for (int t = tid; t < L.mc.hid * N; t += nth) s_mch[(t / N) * ldn + t % N] = w[L.mc.b[0] + t / N];
-            for (int c = 0; c < L.cin; ++c) {
-                const float* ac = s_chan + (L.ci0 + c) * NN;
-                const float* wb = w + L.attn_base + c * L.attn_stride;
-                const float* Wq = wb;
-                const float* bq = Wq + L.fin * L.adim;
-                const float* Wk = bq + L.adim;
-                const float* bk = Wk + L.fin * L.adim;
-                const float* Wv = bk + L.adim;
-                const float* bv = Wv + L.fin * L.fout;
-                gcn_normalize(ac, s_an, s_tmp, N);
-                for (int t = tid; t < N * cols; t += nth) {  // x @ [Wq | Wk | Wv]
-                    const int i = t / cols, col = t % cols;
+            // multi_channel MLP, first Linear: its input is cat_c V_c, accumulated group by group
+            for (int t = tid; t < L.mc.hid * N; t += nth) { int hh, i; dN.divmod(t, hh, i); s_mch[hh * ldn + i] = w[L.mc.b[0] + hh]; }
+            for (int c0 = 0; c0 < L.cin; c0 += p.cg) {
+                const int gc = (L.cin - c0) < p.cg ? (L.cin - c0) : p.cg;
+                float* s_xw = s_R;
+                float* s_qkv = s_R + gc * N * cols;
+                const float* ac = s_chan + (L.ci0 + c0) * NN;
+                gcn_dinv(ac, s_dinv, gc, N);
+                __syncthreads();
+                for (int t = tid; t < gc * N * cols; t += nth) {  // d_j * (x @ [Wq | Wk | Wv]_c)[j]
+                    int c, r, j, col;
+                    dNcols.divmod(t, c, r);
+                    dcols.divmod(r, j, col);
+                    const float* wb = w + L.attn_base + (c0 + c) * L.attn_stride;
                     const float* W; int o, ow;
-                    if (col < L.adim) { W = Wq; o = col; ow = L.adim; }
-                    else if (col < 2 * L.adim) { W = Wk; o = col - L.adim; ow = L.adim; }
-                    else { W = Wv; o = col - 2 * L.adim; ow = L.fout; }
+                    if (col < L.adim) { W = wb; o = col; ow = L.adim; }
+                    else if (col < 2 * L.adim) { W = wb + L.fin * L.adim + L.adim; o = col - L.adim; ow = L.adim; }
+                    else { W = wb + 2 * (L.fin * L.adim + L.adim); o = col - 2 * L.adim; ow = L.fout; }
                     float acc = 0.f;
-                    for (int k = 0; k < L.fin; ++k) acc = fmaf(s_xcur[k * ldn + i], W[k * ow + o], acc);
-                    s_xw[t] = acc;
+                    for (int k = 0; k < L.fin; ++k) acc = fmaf(s_xcur[k * ldn + j], W[k * ow + o], acc);
+                    s_xw[t] = acc * s_dinv[c * N + j];
                 }
                 __syncthreads();
-                for (int t = tid; t < N * cols; t += nth) {  // adj_n @ (.) + bias
-                    const int i = t / cols, col = t % cols;
+                for (int t = tid; t < gc * N * cols; t += nth) {  // d_i * sum_j A'_ij (.) + bias
+                    int c, r, i, col;
+                    dNcols.divmod(t, c, r);
+                    dcols.divmod(r, i, col);
+                    const float* wb = w + L.attn_base + (c0 + c) * L.attn_stride;
+                    const float* arow = ac + c * NN + i * N;
+                    const float* xc = s_xw + c * N * cols + col;
                     float acc = 0.f;
-                    for (int j = 0; j < N; ++j) acc = fmaf(s_an[i * N + j], s_xw[j * cols + col], acc);
-                    const float bb = col < L.adim ? bq[col] : col < 2 * L.adim ? bk[col - L.adim] : bv[col - 2 * L.adim];
-                    s_qkv[t] = acc + bb;
+                    for (int j = 0; j < N; ++j) acc = fmaf((i == j) ? 1.f : arow[j], xc[j * cols], acc);
+                    const float bb = col < L.adim ? wb[L.fin * L.adim + col]
+                                   : col < 2 * L.adim ? wb[2 * L.fin * L.adim + L.adim + (col - L.adim)]
+                                                      : wb[2 * (L.fin * L.adim + L.adim) + L.fin * L.fout + (col - 2 * L.adim)];
+                    s_qkv[t] = fmaf(acc, s_dinv[c * N + i], bb);
                 }
                 __syncthreads();
                 // head chunks: tanh(Q_h K_h^T / sqrt(out_dim)), mean over chunks (attention.py:111-129)
-                for (int t = tid; t < NN; t += nth) {
-                    const int i = t / N, j = t % N;
-                    float s = 0.f;
+                for (int t = tid; t < gc * NN; t += nth) {
+                    int c, ij, i, j;
+                    dNN.divmod(t, c, ij);
+                    dN.divmod(ij, i, j);
+                    const float* q = s_qkv + c * N * cols;
+                    float sacc = 0.f;
                     for (int h = 0; h < L.nchunk; ++h) {
                         float d = 0.f;
-                        for (int q = 0; q < L.dsplit; ++q)
-                            d = fmaf(s_qkv[i * cols + h * L.dsplit + q], s_qkv[j * cols + L.adim + h * L.dsplit + q], d);
-                        s += tanhf(d / inv_scale);
+                        for (int u = 0; u < L.dsplit; ++u)
+                            d = fmaf(q[i * cols + h * L.dsplit + u], q[j * cols + L.adim + h * L.dsplit + u], d);
+                        sacc += tanh_f(d / inv_scale);
                     }
-                    s_tmp[t] = s / (float)L.nchunk;
+                    s_tmp[t] = sacc / (float)L.nchunk;
                 }
-                for (int t = tid; t < L.mc.hid * N; t += nth) {  // += W0[:, c-th block] . V_c
-                    const int hh = t / N, i = t % N;
-                    const float* w0 = w + L.mc.w[0] + hh * L.mc.in + c * L.fout;
+                for (int t = tid; t < L.mc.hid * N; t += nth) {  // += W0[:, blocks of this group] . V_c
+                    int hh, i;
+                    dN.divmod(t, hh, i);
                     float acc = s_mch[hh * ldn + i];
-                    for (int o = 0; o < L.fout; ++o) acc = fmaf(s_qkv[i * cols + 2 * L.adim + o], w0[o], acc);
+                    for (int c = 0; c < gc; ++c) {
+                        const float* w0 = w + L.mc.w[0] + hh * L.mc.in + (c0 + c) * L.fout;
+                        const float* v = s_qkv + c * N * cols + i * cols + 2 * L.adim;
+                        for (int o = 0; o < L.fout; ++o) acc = fmaf(v[o], w0[o], acc);
+                    }
                     s_mch[hh * ldn + i] = acc;
                 }
                 __syncthreads();
-                for (int t = tid; t < NN; t += nth) {  // symmetrise (attention.py:130)
-                    const int i = t / N, j = t % N;
-                    s_att[c * NN + t] = (s_tmp[t] + s_tmp[j * N + i]) / 2.f;
+                for (int t = tid; t < gc * NN; t += nth) {  // symmetrise (attention.py:130)
+                    int c, ij, i, j;
+                    dNN.divmod(t, c, ij);
+                    dN.divmod(ij, i, j);
+                    s_att[(c0 + c) * NN + ij] = (s_tmp[t] + s_tmp[c * NN + j * N + i]) / 2.f;
                 }
+                if (c0 + gc >= L.cin)   // last group: ELU of the multi_channel hidden layer rides along
+                    for (int t = tid; t < L.mc.hid * N; t += nth) { int hh, i; dN.divmod(t, hh, i); float* q = s_mch + hh * ldn + i; *q = elu1(*q); }
                 __syncthreads();
             }
-            // node update: tanh(mask_x(multi_channel(cat V_c)))  (attention.py:292-293)
-            for (int t = tid; t < L.mc.hid * N; t += nth) { float* q = s_mch + (t / N) * ldn + t % N; *q = elu1(*q); }
-            __syncthreads();
-            block_linear<0>(s_xnext, s_mch, w + L.mc.w[1], w + L.mc.b[1], L.mc.hid, L.mc.out, N, ldn);
-            __syncthreads();
-            for (int t = tid; t < N * L.fout; t += nth) {
-                const int o = t / N, i = t % N;
-                s_xnext[o * ldn + i] = tanhf(s_xnext[o * ldn + i] * s_flags[i]);
-            }
-            // edge update: MLP over [attention_c | adj_c] per (i,j)  (attention.py:295-300), chunked
+            // node update: tanh(mask_x(multi_channel(cat V_c)))  (attention.py:292-293); the first Linear of the
+            // edge MLP (input [attention_c | adj_c] per (i,j), attention.py:295-300) shares the barrier interval
             float* chan_out = s_chan + L.co0 * NN;
-            for (int p0 = 0; p0 < NN; p0 += pch) {
-                const int rows = (NN - p0) < pch ? (NN - p0) : pch;
-                __syncthreads();
-                for (int t = tid; t < 2 * L.cin * rows; t += nth) {
-                    const int f = t / rows, r = t % rows;
-                    s_c0[f * ldp + r] = f < L.cin ? s_att[f * NN + p0 + r] : s_chan[(L.ci0 + f - L.cin) * NN + p0 + r];
-                }
-                __syncthreads();
-                float* cur = s_c0; float* nxt = s_c1;
+            const float* adj_in = s_chan + L.ci0 * NN;
+            const int pc = p.pchp, ldpp = p.ldpp;
+            float* hb0 = s_R;
+            float* hb1 = s_R + p.pw_pair * ldpp;
+            for (int p0 = 0; p0 < NN; p0 += pc) {
+                const int rows = (NN - p0) < pc ? (NN - p0) : pc;
+                const float* cur = s_att + p0; const float* cur2 = adj_in + p0; int ldc = NN, ksp = L.cin;
+                float* bufs[2] = {hb0, hb1};
                 for (int i = 0; i < L.mlp.n; ++i) {
-                    if (i < L.mlp.n - 1) block_linear<1>(nxt, cur, w + L.mlp.w[i], w + L.mlp.b[i], mlp_in(L.mlp, i), mlp_out(L.mlp, i), rows, ldp);
-                    else block_linear<0>(nxt, cur, w + L.mlp.w[i], w + L.mlp.b[i], mlp_in(L.mlp, i), mlp_out(L.mlp, i), rows, ldp);
+                    const bool last = i == L.mlp.n - 1;
+                    float* y = last ? chan_out + p0 : bufs[i & 1];
+                    const int ldy = last ? NN : ldpp;
+                    if (!last) block_linear<1>(y, ldy, cur, ldc, cur2, ksp, w + L.mlp.w[i], w + L.mlp.b[i], mlp_in(L.mlp, i), mlp_out(L.mlp, i), rows);
+                    else block_linear<0>(y, ldy, cur, ldc, cur2, ksp, w + L.mlp.w[i], w + L.mlp.b[i], mlp_in(L.mlp, i), mlp_out(L.mlp, i), rows);
+                    if (p0 == 0 && i == 0)
+                        block_linear<0>(s_xnext, ldn, s_mch, ldn, s_mch, L.mc.hid, w + L.mc.w[1], w + L.mc.b[1], L.mc.hid, L.mc.out, N);
                     __syncthreads();
-                    float* t2 = cur; cur = nxt; nxt = t2;
-                }
-                for (int t = tid; t < L.cout * rows; t += nth) {
-                    const int o = t / rows, r = t % rows;
-                    chan_out[o * NN + p0 + r] = cur[o * ldp + r];
+                    cur = y; cur2 = y; ldc = ldy; ksp = mlp_out(L.mlp, i);
                 }
             }
-            __syncthreads();
-            // _adj + _adj^T, then mask_adjs (attention.py:301-302); in place per unordered pair
+            // _adj + _adj^T, then mask_adjs (attention.py:301-302), in place per unordered pair; node tanh/mask
             for (int t = tid; t < L.cout * NN; t += nth) {
-                const int o = t / NN, ij = t % NN, i = ij / N, j = ij % N;
+                int o, ij, i, j;
+                dNN.divmod(t, o, ij);
+                dN.divmod(ij, i, j);
                 if (i > j) continue;
                 float* m = chan_out + o * NN;
-                const float s = (m[i * N + j] + m[j * N + i]) * s_flags[i] * s_flags[j];
-                m[i * N + j] = s;
-                m[j * N + i] = s;
+                const float sv = (m[i * N + j] + m[j * N + i]) * s_flags[i] * s_flags[j];
+                m[i * N + j] = sv;
+                m[j * N + i] = sv;
+            }
+            for (int t = tid; t < N * L.fout; t += nth) {
+                int o, i;
+                dN.divmod(t, o, i);
+                s_xnext[o * ldn + i] = tanh_f(s_xnext[o * ldn + i] * s_flags[i]);
             }
             __syncthreads();
             float* t3 = s_xcur; s_xcur = s_xnext; s_xnext = t3;
         }
 
         // ---- hodge branch of ScoreNetworkA_CC (ScoreNetwork_A_CC.py:295-316)
-        float* s_hd = sm + p.o_hd;
         if (p.h_L > 0) {
+            float* s_hd = sm + p.o_hd;          // [hodge channel][E]: diagonals that reach the final MLP
             float* s_acoef = sm + p.o_acoef;
-            float* s_hq = sm + p.o_hq;
+            float* s_hq = sm + p.o_hq;          // [channel][E][2*adim]
+            float* s_hdiag = sm + p.o_hatt;     // [channel][E] attention diagonals
+            float* s_h1m = s_R;                 // [cout0][E][E] dense output of the first hodge layer
             const float kscale = (float)sqrt((double)p.K);  // hodge_attention.py:118,122: / sqrt(out_dim), out_dim = K
             for (int t = tid; t < p.a_cinit * E; t += nth) {
-                const int c = t / E, e = t % E;
+                int c, e;
+                dE.divmod(t, c, e);
                 const float v = s_chan[c * NN + edges[2 * e] * N + edges[2 * e + 1]];
                 s_acoef[t] = v;
                 s_hd[t] = v;  // diagonal of adj_to_hodgedual(adjc): first c_init hodge channels
             }
             __syncthreads();
             const HodgeLayerD& h0 = p.hl[0];
-            float* s_hdiag = sm + p.o_hatt;                       // [cin][E] attention diagonals
-            float* s_hatt = sm + p.o_h1m;                          // [cin0][E][E] dense layer-0 attention
-            float* s_h1m = s_hatt + p.hl[0].cin * E * E;           // [cout0][E][E] layer-0 output
+            const int qw0 = 2 * h0.adim;
+            const FastDiv dqw0(qw0), dEqw0(E * qw0);
             const float* P0b = xa.P0 + (size_t)b * E * h0.wc;
-            for (int c = 0; c < h0.cin; ++c) {
-                // DenseHCNConv on a diagonal hodge adjacency (hodge_layers.py:185-193): row scaling
-                for (int t = tid; t < E * 2 * h0.adim; t += nth) {
-                    const int e = t / (2 * h0.adim), d = t % (2 * h0.adim);
-                    const float a = s_acoef[c * E + e];
-                    const float g = 1.0f / sqrtf(fmaxf(a, 1.f));
-                    const float coef = g * a * g;
-                    s_hq[t] = coef * P0b[(size_t)e * h0.wc + c * 2 * h0.adim + d] + w[h0.bcat + c * 2 * h0.adim + d];
-                }
-                __syncthreads();
-                if (p.h_L == 1) {
-                    for (int e = tid; e < E; e += nth) {  // only the diagonal is ever used (cc_utils.py:1571)
-                        float s = 0.f;
-                        for (int hh = 0; hh < h0.nchunk; ++hh) {
-                            float d = 0.f;
-                            for (int q = 0; q < h0.dsplit; ++q)
-                                d = fmaf(s_hq[e * 2 * h0.adim + hh * h0.dsplit + q], s_hq[e * 2 * h0.adim + h0.adim + hh * h0.dsplit + q], d);
-                            s += tanhf(d / kscale);
-                        }
-                        s /= (float)h0.nchunk;
-                        s_hdiag[c * E + e] = (s + s) / 2.f;
-                    }
-                } else {
-                    for (int t = tid; t < E * E; t += nth) {
-                        const int e = t / E, e2 = t % E;
-                        float s1 = 0.f, s2 = 0.f;
-                        for (int hh = 0; hh < h0.nchunk; ++hh) {
-                            float d1 = 0.f, d2 = 0.f;
-                            for (int q = 0; q < h0.dsplit; ++q) {
-                                const int oq = hh * h0.dsplit + q, ok = h0.adim + oq;
-                                d1 = fmaf(s_hq[e * 2 * h0.adim + oq], s_hq[e2 * 2 * h0.adim + ok], d1);
-                                d2 = fmaf(s_hq[e2 * 2 * h0.adim + oq], s_hq[e * 2 * h0.adim + ok], d2);
-                            }
-                            s1 += tanhf(d1 / kscale);
-                            s2 += tanhf(d2 / kscale);
-                        }
-                        s_hatt[c * E * E + t] = (s1 / (float)h0.nchunk + s2 / (float)h0.nchunk) / 2.f;
-                    }
-                }
-                __syncthreads();
+            // DenseHCNConv on a diagonal hodge adjacency (hodge_layers.py:185-193): a row scaling
+            for (int t = tid; t < h0.cin * E * qw0; t += nth) {
+                int c, r, e, d;
+                dEqw0.divmod(t, c, r);
+                dqw0.divmod(r, e, d);
+                const float a = s_acoef[c * E + e];
+                const float g = 1.0f / sqrtf(fmaxf(a, 1.f));
+                s_hq[t] = fmaf(g * a * g, P0b[(size_t)e * h0.wc + c * qw0 + d], w[h0.bcat + c * qw0 + d]);
             }
-            // mlp_attention -> mask_hodge_adjs -> tanh -> + transpose  (hodge_attention.py:315-320)
+            __syncthreads();
             if (p.h_L == 1) {
+                // only the diagonal is ever used (hodgedual_to_adj, cc_utils.py:1571)
                 for (int e = tid; e < E; e += nth) {
                     float in[CCSD_SMALLW], out[CCSD_SMALLW];
 #pragma unroll
-                    for (int c = 0; c < CCSD_SMALLW; ++c) in[c] = c < h0.cin ? s_hdiag[c * E + e] : 0.f;
-                    small_mlp<CCSD_SMALLW>(h0.matt, w, in, out);
+                    for (int c = 0; c < CCSD_SMALLW; ++c) {
+                        float sacc = 0.f;
+                        if (c < h0.cin) {
+                            const float* q = s_hq + (c * E + e) * qw0;
+                            for (int hh = 0; hh < h0.nchunk; ++hh) {
+                                float d = 0.f;
+                                for (int u = 0; u < h0.dsplit; ++u) d = fmaf(q[hh * h0.dsplit + u], q[h0.adim + hh * h0.dsplit + u], d);
+                                sacc += tanh_f(d / kscale);
+                            }
+                            sacc /= (float)h0.nchunk;
+                            sacc = (sacc + sacc) / 2.f;
+                        }
+                        in[c] = sacc;
+                    }
+                    small_mlp<CCSD_SMALLW>(h0.matt, w, in, out);   // mlp_attention -> mask -> tanh -> + transpose
                     const float fh = s_flags[edges[2 * e]] * s_flags[edges[2 * e + 1]];
 #pragma unroll
                     for (int o = 0; o < CCSD_SMALLW; ++o)
-                        if (o < h0.cout) { const float tv = tanhf(out[o] * fh * fh); s_hd[(p.a_cinit + o) * E + e] = tv + tv; }
+                        if (o < h0.cout) { const float tv = tanh_f(out[o] * fh * fh); s_hd[(p.a_cinit + o) * E + e] = tv + tv; }
                 }
                 __syncthreads();
             } else {
+                // dense E x E attention of every channel, mlp_attention, mask, tanh, + transpose (hodge_attention.py:315-320)
                 for (int t = tid; t < E * E; t += nth) {
-                    const int e = t / E, e2 = t % E;
+                    int e, e2;
+                    dE.divmod(t, e, e2);
+                    if (e > e2) continue;                       // symmetric: compute the upper triangle, store both
                     float in[CCSD_SMALLW], out[CCSD_SMALLW];
 #pragma unroll
-                    for (int c = 0; c < CCSD_SMALLW; ++c) in[c] = c < h0.cin ? s_hatt[c * E * E + t] : 0.f;
+                    for (int c = 0; c < CCSD_SMALLW; ++c) {
+                        float v = 0.f;
+                        if (c < h0.cin) {
+                            const float* q1 = s_hq + (c * E + e) * qw0;
+                            const float* q2 = s_hq + (c * E + e2) * qw0;
+                            float s1 = 0.f, s2 = 0.f;
+                            for (int hh = 0; hh < h0.nchunk; ++hh) {
+                                float d1 = 0.f, d2 = 0.f;
+                                for (int u = 0; u < h0.dsplit; ++u) {
+                                    const int oq = hh * h0.dsplit + u, ok = h0.adim + oq;
+                                    d1 = fmaf(q1[oq], q2[ok], d1);
+                                    d2 = fmaf(q2[oq], q1[ok], d2);
+                                }
+                                s1 += tanh_f(d1 / kscale);
+                                s2 += tanh_f(d2 / kscale);
+                            }
+                            v = (s1 / (float)h0.nchunk + s2 / (float)h0.nchunk) / 2.f;
+                        }
+                        in[c] = v;
+                    }
                     small_mlp<CCSD_SMALLW>(h0.matt, w, in, out);
                     const float fh = s_flags[edges[2 * e]] * s_flags[edges[2 * e + 1]];
                     const float fh2 = s_flags[edges[2 * e2]] * s_flags[edges[2 * e2 + 1]];
 #pragma unroll
                     for (int o = 0; o < CCSD_SMALLW; ++o)
                         if (o < h0.cout) {
-                            const float tv = tanhf(out[o] * fh * fh2);   // inputs are exactly symmetric -> h + h^T = 2h
+                            const float tv = tanh_f(out[o] * fh * fh2);   // inputs are exactly symmetric -> h + h^T = 2h
                             s_h1m[o * E * E + t] = tv + tv;
+                            s_h1m[o * E * E + e2 * E + e] = tv + tv;
                             if (e == e2) s_hd[(p.a_cinit + o) * E + e] = tv + tv;
                         }
                 }
                 __syncthreads();
-                // second (last) HodgeAdjAttentionLayer: dense hodge adjacency, diagonal of the output only
+                // second (last) HodgeAdjAttentionLayer: dense hodge adjacency, only the diagonal of its output
                 const HodgeLayerD& h1 = p.hl[1];
+                const int qw1 = 2 * h1.adim;
+                const FastDiv dqw1(qw1), dEqw1(E * qw1);
                 const float* P1b = xa.P1 + (size_t)b * E * h1.wc;
-                float* s_deg = s_an;                 // E <= N*N always holds for N >= 3; guarded on the host
-                float* s_attd = s_hdiag;             // [cin][E]
-                for (int c = 0; c < h1.cin; ++c) {
-                    const float* Hc = s_h1m + c * E * E;
-                    for (int e = tid; e < E; e += nth) {
-                        float s = 0.f;
-                        for (int e2 = 0; e2 < E; ++e2) s += Hc[e * E + e2];
-                        s_deg[e] = 1.0f / sqrtf(fmaxf(s, 1.f));
-                    }
-                    __syncthreads();
-                    for (int t = tid; t < E * 2 * h1.adim; t += nth) {
-                        const int e = t / (2 * h1.adim), d = t % (2 * h1.adim);
-                        float acc = 0.f;
-                        for (int e2 = 0; e2 < E; ++e2)
-                            acc = fmaf(s_deg[e] * Hc[e * E + e2] * s_deg[e2], P1b[(size_t)e2 * h1.wc + c * 2 * h1.adim + d], acc);
-                        s_hq[t] = acc + w[h1.bcat + c * 2 * h1.adim + d];
-                    }
-                    __syncthreads();
-                    for (int e = tid; e < E; e += nth) {
-                        float s = 0.f;
-                        for (int hh = 0; hh < h1.nchunk; ++hh) {
-                            float d = 0.f;
-                            for (int q = 0; q < h1.dsplit; ++q)
-                                d = fmaf(s_hq[e * 2 * h1.adim + hh * h1.dsplit + q], s_hq[e * 2 * h1.adim + h1.adim + hh * h1.dsplit + q], d);
-                            s += tanhf(d / kscale);
-                        }
-                        s /= (float)h1.nchunk;
-                        s_attd[c * E + e] = (s + s) / 2.f;
-                    }
-                    __syncthreads();
+                float* s_deg = s_tmp;                // [cin1][E]; cin1*E <= cg*NN is guarded on the host
+                for (int t = tid; t < h1.cin * E; t += nth) {
+                    const float* Hr = s_h1m + (size_t)t * E;      // row e of channel c: t = c*E + e
+                    float sacc = 0.f;
+                    for (int e2 = 0; e2 < E; ++e2) sacc += Hr[e2];
+                    s_deg[t] = 1.0f / sqrtf(fmaxf(sacc, 1.f));
                 }
+                __syncthreads();
+                for (int t = tid; t < h1.cin * E * qw1; t += nth) {
+                    int c, r, e, d;
+                    dEqw1.divmod(t, c, r);
+                    dqw1.divmod(r, e, d);
+                    const float* Hr = s_h1m + (size_t)(c * E + e) * E;
+                    const float* dg = s_deg + c * E;
+                    const float* pc1 = P1b + c * qw1 + d;
+                    float acc = 0.f;
+                    for (int e2 = 0; e2 < E; ++e2) acc = fmaf(dg[e] * Hr[e2] * dg[e2], pc1[(size_t)e2 * h1.wc], acc);
+                    s_hq[t] = acc + w[h1.bcat + c * qw1 + d];
+                }
+                __syncthreads();
                 for (int e = tid; e < E; e += nth) {
                     float in[CCSD_SMALLW], out[CCSD_SMALLW];
 #pragma unroll
-                    for (int c = 0; c < CCSD_SMALLW; ++c) in[c] = c < h1.cin ? s_attd[c * E + e] : 0.f;
+                    for (int c = 0; c < CCSD_SMALLW; ++c) {
+                        float sacc = 0.f;
+                        if (c < h1.cin) {
+                            const float* q = s_hq + (c * E + e) * qw1;
+                            for (int hh = 0; hh < h1.nchunk; ++hh) {
+                                float d = 0.f;
+                                for (int u = 0; u < h1.dsplit; ++u) d = fmaf(q[hh * h1.dsplit + u], q[h1.adim + hh * h1.dsplit + u], d);
+                                sacc += tanh_f(d / kscale);
+                            }
+                            sacc /= (float)h1.nchunk;
+                            sacc = (sacc + sacc) / 2.f;
+                        }
+                        in[c] = sacc;
+                    }
                     small_mlp<CCSD_SMALLW>(h1.matt, w, in, out);
                     const float fh = s_flags[edges[2 * e]] * s_flags[edges[2 * e + 1]];
 #pragma unroll
                     for (int o = 0; o < CCSD_SMALLW; ++o)
-                        if (o < h1.cout) { const float tv = tanhf(out[o] * fh * fh); s_hd[(p.a_cinit + h0.cout + o) * E + e] = tv + tv; }
+                        if (o < h1.cout) { const float tv = tanh_f(out[o] * fh * fh); s_hd[(p.a_cinit + h0.cout + o) * E + e] = tv + tv; }
                 }
                 __syncthreads();
             }
+            // hodgedual_to_adj (cc_utils.py:1552-1588): scatter the diagonals behind the graph channels
+            for (int t = tid; t < p.a_nch_hodge * NN; t += nth) {
+                int c, ij, i, j;
+                dNN.divmod(t, c, ij);
+                dN.divmod(ij, i, j);
+                float v = 0.f;
+                if (i != j) {
+                    const int lo = i < j ? i : j, hi = i < j ? j : i;
+                    v = s_hd[c * E + lo * N - lo * (lo + 1) / 2 + (hi - lo - 1)];   // row-major triu index
+                }
+                s_chan[(p.a_nch_graph + c) * NN + ij] = v;
+            }
+            __syncthreads();
         }
 
         // ---- final MLP over every (i,j) on [graph channels | hodge channels]  (ScoreNetwork_A_CC.py:318-331)
         const MlpD& m = p.a_fin;
-        for (int p0 = 0; p0 < NN; p0 += pch) {
-            const int rows = (NN - p0) < pch ? (NN - p0) : pch;
+        const int fc = p.pch, ldf = p.ldp;
+        float* f0 = s_R;
+        float* f1 = s_R + m.hid * ldf;
+        for (int p0 = 0; p0 < NN; p0 += fc) {
+            const int rows = (NN - p0) < fc ? (NN - p0) : fc;
+            block_linear<1>(f0, ldf, s_chan + p0, NN, s_chan + p0, m.in, w + m.w[0], w + m.b[0], m.in, m.hid, rows);
             __syncthreads();
-            for (int t = tid; t < p.a_fdim * rows; t += nth) {
-                const int f = t / rows, r = t % rows, ij = p0 + r, i = ij / N, j = ij % N;
-                float v;
-                if (f < p.a_nch_graph) v = s_chan[f * NN + ij];
-                else if (i == j) v = 0.f;                              // hodgedual_to_adj leaves the diagonal 0
-                else {
-                    const int lo = i < j ? i : j, hi = i < j ? j : i;
-                    const int e = lo * N - lo * (lo + 1) / 2 + (hi - lo - 1);   // row-major triu index
-                    v = s_hd[(f - p.a_nch_graph) * E + e];
-                }
-                s_c0[f * ldp + r] = v;
-            }
+            block_linear<1>(f1, ldf, f0, ldf, f0, m.hid, w + m.w[1], w + m.b[1], m.hid, m.hid, rows);
             __syncthreads();
-            block_linear<1>(s_c1, s_c0, w + m.w[0], w + m.b[0], m.in, m.hid, rows, ldp);
-            __syncthreads();
-            block_linear<1>(s_c0, s_c1, w + m.w[1], w + m.b[1], m.hid, m.hid, rows, ldp);
-            __syncthreads();
-            block_linear<0>(s_c1, s_c0, w + m.w[2], w + m.b[2], m.hid, 1, rows, ldp);
+            block_linear<0>(f0, ldf, f1, ldf, f1, m.hid, w + m.w[2], w + m.b[2], m.hid, 1, rows);
             __syncthreads();
             for (int r = tid; r < rows; r += nth) {
-                const int ij = p0 + r, i = ij / N, j = ij % N;
+                const int ij = p0 + r;
+                int i, j;
+                dN.divmod(ij, i, j);
                 const float fm = s_flags[i] * s_flags[j];
-                const float net = (i == j) ? 0.f : s_c1[r] * fm;       // * no-diag mask, then mask_adjs
+                const float net = (i == j) ? 0.f : f0[r] * fm;         // * no-diag mask, then mask_adjs
                 const size_t gi = (size_t)b * NN + ij;
                 if (xa.mode == MODE_SCORE) {
                     xa.out_a[gi] = xa.ss_a * net;
@@ -959,6 +1036,7 @@ __global__ __launch_bounds__(256) void k_xa(const PlanD* __restrict__ plan, cons
                     }
                 }
             }
+            __syncthreads();
         }
     }
     if (xa.mode == MODE_NORMS) {

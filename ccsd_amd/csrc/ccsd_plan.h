@@ -52,7 +52,8 @@ struct PlanD {
     MlpD fl[CCSD_MAXFL];
     MlpD f_fin;
     // k_xa LDS carve-up (float offsets) and strides
-    int ldn, ldp, pch;          // node-row stride, pair-chunk stride, pairs per chunk
+    int ldn, ldp, pch;          // node-row stride; final-MLP chunk: stride, pairs per chunk
+    int cg, pchp, ldpp, pw_pair; // attention channels per group; edge-MLP chunk: pairs, stride, widest hidden layer
     int o_flags, o_x, o_adj, o_an, o_xw, o_qkv, o_tmp, o_xcat, o_h1, o_h2, o_chan, o_att, o_xcur, o_xnext,
         o_vcat, o_c0, o_c1, o_acoef, o_hq, o_hatt, o_h1m, o_hd, o_red;
     int xa_lds_floats;
@@ -213,61 +214,76 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     const int NN = N * N;
     p->ldn = round_ld(N);
     int fmaxA = F > c->a_nhid ? F : c->a_nhid;
-    int colmax = 0, mchid = 0, pairw = 0, cinmax = 0;
+    int colmax = 0, mchid = 0, cinmax = 0;
     for (int l = 0; l < p->a_L; ++l) {
         const AttnLayerD& a = p->al[l];
         int cols = 2 * a.adim + a.fout; if (cols > colmax) colmax = cols;
         if (a.mc.hid > mchid) mchid = a.mc.hid;
-        int w = 2 * a.cin; if (a.mlp.hid > w) w = a.mlp.hid; if (a.cout > w) w = a.cout; if (w > pairw) pairw = w;
         if (a.cin > cinmax) cinmax = a.cin;
     }
-    if (2 * p->a_fdim > pairw) pairw = 2 * p->a_fdim;
-    int o = 0;
-    auto carve = [&](int n) { int r = o; o += (n + 3) / 4 * 4; return r; };
-    p->o_flags = carve(N);
-    p->o_x = carve(N * F);
-    p->o_adj = carve(NN);
-    p->o_an = carve(NN);
-    p->o_tmp = carve(NN);
-    int xwcols = colmax > c->x_nhid ? colmax : c->x_nhid;
-    p->o_xw = carve(N * xwcols);
-    p->o_qkv = carve(N * xwcols);
-    p->o_red = carve(64);
-    const int phase0 = o;
-    // X-network phase buffers ...
-    p->o_xcat = carve(p->x_fdim * p->ldn);
-    p->o_h1 = carve(2 * p->x_fdim * p->ldn);
-    p->o_h2 = carve(2 * p->x_fdim * p->ldn);
-    const int xphase_end = o;
-    // ... are dead when the A-network phase starts: alias them
-    o = phase0;
-    p->o_chan = carve(p->a_nch_graph * NN);
-    p->o_att = carve(cinmax * NN);
-    p->o_xcur = carve(fmaxA * p->ldn);
-    p->o_xnext = carve(fmaxA * p->ldn);
-    p->o_vcat = carve(mchid * p->ldn);          // hidden layer of multi_channel
-    if (p->h_L) {
-        if (E > NN) { pb.fail(CCSD_ERR_UNSUPPORTED, "E > N*N"); return 0; }
-        p->o_acoef = carve(c->a_c_init * E);
-        int adm = p->hl[0].adim; if (p->h_L > 1 && p->hl[1].adim > adm) adm = p->hl[1].adim;
-        p->o_hq = carve(E * 2 * adm);
-        p->o_hd = carve(p->a_nch_hodge * E);
-        p->o_hatt = carve(CCSD_SMALLW * E);     // per-channel attention diagonals
-        if (p->h_L > 1) p->o_h1m = carve((p->hl[0].cin + p->hl[0].cout) * E * E);  // dense layer-0 attention + output
-    }
-    // pair-chunk buffers: grow the chunk while the workgroup stays <= 64 KB (2+ workgroups per CU);
-    // if even 48 pairs do not fit, keep growing up to the CU's 160 KB (minus a margin)
+    int pw_pair = 1;   // widest hidden activation of the per-layer edge MLPs
+    for (int l = 0; l < p->a_L; ++l) if (p->al[l].mlp.n > 1 && p->al[l].mlp.hid > pw_pair) pw_pair = p->al[l].mlp.hid;
+    const int pw_fin = 2 * p->a_fdim;
+    p->pw_pair = pw_pair;
     const int NNpad = (NN + 15) / 16 * 16;
-    auto total_with = [&](int pc) { return o + 2 * ((pairw * round_ld(pc) + 3) / 4 * 4); };
-    int pch = 16;
-    while (pch + 16 <= NNpad && total_with(pch + 16) * 4 <= 64 * 1024) pch += 16;
-    while (pch < 48 && pch + 16 <= NNpad && total_with(pch + 16) * 4 <= 152 * 1024) pch += 16;
-    p->pch = pch; p->ldp = round_ld(pch);
-    p->o_c0 = carve(pairw * p->ldp);
-    p->o_c1 = carve(pairw * p->ldp);
-    if (xphase_end > o) o = xphase_end;
-    p->xa_lds_floats = o;
-    if ((size_t)o * 4 > 160 * 1024) pb.fail(CCSD_ERR_UNSUPPORTED, "graph-network working set exceeds the 160 KB LDS of a CU");
+    int hq_floats = 0, h1m_floats = 0;
+    if (p->h_L) {
+        for (int l = 0; l < p->h_L; ++l) { int v = p->hl[l].cin * E * 2 * p->hl[l].adim; if (v > hq_floats) hq_floats = v; }
+        if (p->h_L > 1) h1m_floats = p->hl[0].cout * E * E;
+        if (E > NN) { pb.fail(CCSD_ERR_UNSUPPORTED, "E > N*N"); return 0; }
+    }
+    // Two passes: aim for <= 64 KB per workgroup (2-3 workgroups per CU); if the network does not fit, use
+    // up to 152 KB (one workgroup per CU).  Within a budget take the largest channel group / chunk sizes.
+    int best_total = -1;
+    for (int pass = 0; pass < 2 && best_total < 0; ++pass) {
+        const int budget = (pass == 0 ? 64 : 152) * 1024 / 4;
+        for (int cg = cinmax; cg >= 1 && best_total < 0; --cg) {
+            int o = 0;
+            auto carve = [&](int n) { int r = o; o += (n + 3) / 4 * 4; return r; };
+            p->o_flags = carve(N);
+            p->o_x = carve(N * F);
+            p->o_adj = carve(NN);
+            p->o_an = carve(cg * N > N ? cg * N : N);                       // D^-1/2 per channel of the group
+            int tmpf = cg * NN; if (p->h_L > 1 && p->hl[1].cin * E > tmpf) tmpf = p->hl[1].cin * E;
+            p->o_tmp = carve(tmpf);
+            p->o_red = carve(64);
+            const int phase0 = o;
+            p->o_xcat = carve(p->x_fdim * p->ldn);                          // X-network phase ...
+            p->o_h1 = carve(2 * p->x_fdim * p->ldn);
+            p->o_h2 = carve(2 * p->x_fdim * p->ldn);
+            const int xphase_end = o;
+            o = phase0;                                                     // ... aliased by the A-network phase
+            p->o_chan = carve(p->a_fdim * NN);
+            p->o_att = carve(cinmax * NN);
+            p->o_xcur = carve(fmaxA * p->ldn);
+            p->o_xnext = carve(fmaxA * p->ldn);
+            p->o_vcat = carve(mchid * p->ldn);                              // hidden layer of multi_channel
+            if (p->h_L) {
+                p->o_acoef = carve(c->a_c_init * E);
+                p->o_hq = carve(hq_floats);
+                p->o_hd = carve(p->a_nch_hodge * E);
+                p->o_hatt = carve(4);
+            }
+            if (xphase_end > o) o = xphase_end;
+            // shared region R: GCN scratch of a channel group | hidden activations of the MLPs | dense hodge layer
+            int rmin = 2 * cg * N * colmax;
+            if (N * c->x_nhid > rmin) rmin = N * c->x_nhid;
+            if (h1m_floats > rmin) rmin = h1m_floats;
+            if (o + rmin + 2 * pw_fin * 16 > budget) continue;
+            int pch = 16, pchp = 16;
+            while (pch + 16 <= NNpad && o + 2 * pw_fin * round_ld(pch + 16) <= budget) pch += 16;
+            while (pchp + 16 <= NNpad && o + 2 * pw_pair * round_ld(pchp + 16) <= budget) pchp += 16;
+            int r = rmin;
+            if (2 * pw_fin * round_ld(pch) > r) r = 2 * pw_fin * round_ld(pch);
+            if (2 * pw_pair * round_ld(pchp) > r) r = 2 * pw_pair * round_ld(pchp);
+            p->cg = cg; p->pch = pch; p->ldp = round_ld(pch); p->pchp = pchp; p->ldpp = round_ld(pchp);
+            p->o_c0 = carve(r); p->o_c1 = p->o_c0;
+            p->xa_lds_floats = o;
+            best_total = o;
+        }
+    }
+    if (best_total < 0 || (size_t)best_total * 4 > 160 * 1024)
+        pb.fail(CCSD_ERR_UNSUPPORTED, "graph-network working set exceeds the 160 KB LDS of a CU");
     return nweights;
 }
 
