@@ -5,6 +5,7 @@
 #pragma once
 #include "ccsd_kernels.h"
 #include <stdio.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -20,6 +21,9 @@ struct ccsd_plan {
     unsigned long long* cells = nullptr;
     std::vector<ccsd_step_coef_t> coef;  // [diff_steps][3]
     size_t nweights = 0;
+    // fused rank-2 kernel (k_r2): eligibility and LDS geometry
+    int fused_r2 = 0, r2_ldk = 0, r2_ldh = 0;
+    size_t r2_lds = 0;
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     int prof_kernel = -1;
     size_t prof_used = 0;
@@ -28,7 +32,7 @@ struct ccsd_plan {
 #endif
 };
 
-enum { KID_XA = 0, KID_GEMM_P = 1, KID_HF = 2, KID_GEMM_H = 3, KID_LANGEVIN = 4 };
+enum { KID_XA = 0, KID_GEMM_P = 1, KID_HF = 2, KID_GEMM_H = 3, KID_LANGEVIN = 4, KID_R2 = 5 };
 static void prof_mark(ccsd_plan* pl, int kid, void* stream) {
 #ifndef CCSD_EMU
     if (pl->prof_kernel != kid) return;
@@ -160,8 +164,22 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     PC(rt_h2d(pl->edges, edges.data(), edges.size()));
     PC(rt_malloc((void**)&pl->cells, cells.size() * sizeof(unsigned long long)));
     PC(rt_h2d(pl->cells, cells.data(), cells.size() * sizeof(unsigned long long)));
+    // fused rank-2 path: one complex's rank2 block (E x K) LDS-resident, E <= 64
+    if (cfg->is_cc && E <= 64 && getenv("CCSD_NO_FUSED_R2") == nullptr) {
+        const PlanD& p = pl->h;
+        const int Kp4 = (K + 3) & ~3, Ep4 = (E + 3) & ~3;
+        int ldk = Kp4; while (ldk % 32 != 2) ++ldk;       // == 2 mod 32: conflict-free 16x4 fragment reads
+        int ldh = Ep4; while (ldh % 32 != 2) ++ldh;
+        while (E * ldh < 1024) ldh += 32;                  // doubles as scratch for a 512-thread reduction
+        const size_t fl = (size_t)E * ldk + (size_t)E * ldh + Kp4 + 64 * 3 + (size_t)p.a_cinit * E + 3 * N * N + 64;
+        const bool wc_ok = p.h_L < 2 || p.hl[1].wc <= 64;
+        if (fl * 4 + 64 <= 160 * 1024 && wc_ok) {
+            pl->fused_r2 = 1; pl->r2_ldk = ldk; pl->r2_ldh = ldh; pl->r2_lds = fl * 4;
+        }
+    }
 #ifndef CCSD_EMU
     if ((size_t)pl->h.xa_lds_floats * 4 > 64 * 1024) PC(rt_set_max_dyn_smem((const void*)k_xa, (size_t)pl->h.xa_lds_floats * 4));
+    if (pl->fused_r2 && pl->r2_lds > 64 * 1024) PC(rt_set_max_dyn_smem((const void*)k_r2, pl->r2_lds));
 #endif
 #undef PC
     *out = pl;
@@ -285,6 +303,19 @@ static int launch_hf(const ccsd_plan* pl, int B, const float* rank2, RankEpi& ep
     return CCSD_OK;
 }
 
+static int launch_r2(const ccsd_plan* pl, int B, const float* rank2, const float* adj, const float* flags, int want_p,
+                     RankEpi& ep, NoiseArgs& na, Workspace& w, void* stream) {
+    R2Args ra{};
+    ra.rank2 = rank2; ra.adj = adj; ra.flags = flags; ra.P0 = w.P0; ra.P1 = w.P1; ra.want_p = want_p;
+    ra.ldk = pl->r2_ldk; ra.ldh = pl->r2_ldh;
+    prof_mark(const_cast<ccsd_plan*>(pl), KID_R2, stream);
+    CCSD_LAUNCH(k_r2, dim3(B), dim3(CCSD_NTHREADS == 1 ? 1 : 512), pl->r2_lds, stream, (const PlanD*)pl->d, (const float*)pl->w,
+                (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, ra, ep, na);
+    prof_mark(const_cast<ccsd_plan*>(pl), KID_R2, stream);
+    LAUNCH_CHECK();
+    return CCSD_OK;
+}
+
 static unsigned int draw_base(const ccsd_plan* pl, int step, int phase) {
     return 3u + (unsigned)((step * (pl->cfg.n_corr_steps + 1) + phase) * 3);
 }
@@ -316,9 +347,10 @@ extern "C" int ccsd_score(ccsd_plan_t* pl, int32_t target, int32_t B, const ccsd
     }
     if (target == CCSD_TARGET_RANK2) {
         if (!pl->h.is_cc) return set_err(CCSD_ERR_INVALID, "rank2 score requested from a graph-only plan");
-        if ((st = launch_h(pl, B, in->rank2, w, stream))) return st;
         RankEpi ep{};
         ep.mode = MODE_SCORE; ep.sscale = sscale; ep.out = out;
+        if (pl->fused_r2) return launch_r2(pl, B, in->rank2, in->adj, flags, 0, ep, na, w, stream);
+        if ((st = launch_h(pl, B, in->rank2, w, stream))) return st;
         return launch_hf(pl, B, in->rank2, ep, na, w, stream);
     }
     return set_err(CCSD_ERR_UNSUPPORTED, "Object not yet supported. Select from [x, adj, rank2].");
@@ -356,21 +388,30 @@ static int corrector_norms(ccsd_plan* pl, int B, int step, int it, const ccsd_st
     const PlanD& p = pl->h;
     int st;
     NoiseArgs na = make_noise(noise, seed, off, draw_base(pl, step, it));
-    // A-net sees (x_0, adj_cur, rank2_0): hodge projections from the base rank2, edge coefficients from adj_cur
-    if ((st = launch_p(pl, B, cur->adj, base->rank2, w, stream))) return st;
+    // A-net sees (x_0, adj_cur, rank2_0): hodge projections from the base rank2, edge coefficients from adj_cur.
+    // When the rank2 iterate is still the base state the fused kernel serves both the A-net's projections
+    // and ScoreNetworkF in one pass over rank2.
+    const bool fused = pl->fused_r2 && p.is_cc && cur->rank2 == base->rank2;
+    int ntiles = w.ntiles;
+    if (fused) {
+        RankEpi ep{};
+        ep.mode = MODE_NORMS; ep.out = w.net_r; ep.part = w.part;
+        if ((st = launch_r2(pl, B, cur->rank2, cur->adj, flags, 1, ep, na, w, stream))) return st;
+        ntiles = 1;
+    } else if ((st = launch_p(pl, B, cur->adj, base->rank2, w, stream))) return st;
     XaArgs xa{};
     xa.xX = cur->x; xa.adjX = base->adj;      // score_x(x_cur, adj_0)      solver.py:761
     xa.xA = base->x; xa.adjA = cur->adj;      // score_adj(x_0, adj_cur)    solver.py:775
     xa.flags = flags; xa.do_x = xa.do_a = 1; xa.mode = MODE_NORMS;
     xa.out_x = w.net_x; xa.out_a = w.net_adj; xa.norm2 = w.norm2;
     if ((st = launch_xa(pl, B, xa, na, w, stream))) return st;
-    if (p.is_cc) {
+    if (p.is_cc && !fused) {
         if ((st = launch_h(pl, B, cur->rank2, w, stream))) return st;
         RankEpi ep{};
         ep.mode = MODE_NORMS; ep.out = w.net_r; ep.part = w.part;
         if ((st = launch_hf(pl, B, cur->rank2, ep, na, w, stream))) return st;
     }
-    CCSD_LAUNCH(k_normsum, dim3(1), dim3(CCSD_NTHREADS), 0, stream, (const float*)w.norm2, (const float*)w.part, B, w.ntiles,
+    CCSD_LAUNCH(k_normsum, dim3(1), dim3(CCSD_NTHREADS), 0, stream, (const float*)w.norm2, (const float*)w.part, B, ntiles,
                 p.is_cc, sums);
     LAUNCH_CHECK();
     return CCSD_OK;
@@ -403,7 +444,13 @@ static int predictor(ccsd_plan* pl, int B, int step, const ccsd_state_t* in, con
     int st;
     NoiseArgs na = make_noise(noise, seed, off, draw_base(pl, step, pl->cfg.n_corr_steps));
     const ccsd_step_coef_t* c = &pl->coef[(size_t)step * 3];
-    if ((st = launch_p(pl, B, in->adj, in->rank2, w, stream))) return st;
+    const bool fused = pl->fused_r2 && p.is_cc;
+    if (fused) {
+        RankEpi ep{};
+        ep.mode = MODE_PRED; ep.pa = c[2].pa; ep.pb = c[2].pb; ep.pc = c[2].pc;
+        ep.out = out->rank2; ep.mean = mean ? mean->rank2 : nullptr;
+        if ((st = launch_r2(pl, B, in->rank2, in->adj, flags, 1, ep, na, w, stream))) return st;
+    } else if ((st = launch_p(pl, B, in->adj, in->rank2, w, stream))) return st;
     XaArgs xa{};
     xa.xX = xa.xA = in->x; xa.adjX = xa.adjA = in->adj; xa.flags = flags;
     xa.do_x = xa.do_a = 1; xa.mode = MODE_PRED;
@@ -412,7 +459,7 @@ static int predictor(ccsd_plan* pl, int B, int step, const ccsd_state_t* in, con
     xa.out_x = out->x; xa.out_a = out->adj;
     xa.mean_x = mean ? mean->x : nullptr; xa.mean_a = mean ? mean->adj : nullptr;
     if ((st = launch_xa(pl, B, xa, na, w, stream))) return st;
-    if (p.is_cc) {
+    if (p.is_cc && !fused) {
         if ((st = launch_h(pl, B, in->rank2, w, stream))) return st;
         RankEpi ep{};
         ep.mode = MODE_PRED; ep.pa = c[2].pa; ep.pb = c[2].pb; ep.pc = c[2].pc;

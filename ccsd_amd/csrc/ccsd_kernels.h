@@ -93,14 +93,21 @@ CCSD_DEV void philox_normal4(unsigned long long seed, unsigned int draw, long lo
     unsigned int r[4];
     philox4(g, (unsigned int)b, draw, (unsigned int)((unsigned long long)b >> 32), (unsigned int)seed,
             (unsigned int)(seed >> 32), r);
-    const float inv24 = 1.0f / 16777216.0f, twopi = 6.283185307179586f;
+    const float inv24 = 1.0f / 16777216.0f;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const float u1 = (float)((r[2 * h] >> 8) + 1u) * inv24;
-        const float u2 = (float)(r[2 * h + 1] >> 8) * inv24;
+        const float u1 = (float)((r[2 * h] >> 8) + 1u) * inv24;    // (0, 1]
+        const float u2 = (float)(r[2 * h + 1] >> 8) * inv24;       // [0, 1)
+#ifdef CCSD_EMU
         const float rad = sqrtf(-2.0f * logf(u1));
-        n[2 * h] = rad * cosf(twopi * u2);
-        n[2 * h + 1] = rad * sinf(twopi * u2);
+        n[2 * h] = rad * cosf(6.283185307179586f * u2);
+        n[2 * h + 1] = rad * sinf(6.283185307179586f * u2);
+#else
+        // v_log_f32 is log2, v_sin/v_cos take their argument in revolutions: no range reduction needed
+        const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+        n[2 * h] = rad * __builtin_amdgcn_cosf(u2);
+        n[2 * h + 1] = rad * __builtin_amdgcn_sinf(u2);
+#endif
     }
 }
 CCSD_DEV float philox_normal1(unsigned long long seed, unsigned int draw, long long b, unsigned int idx) {
@@ -568,6 +575,302 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
             ep.part[((size_t)b * nt + tile) * 2 + 0] = tn;
             ep.part[((size_t)b * nt + tile) * 2 + 1] = tz;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_r2: the whole rank-2 side of one joint score evaluation for ONE complex per workgroup, with the
+// complex's rank2 block resident in LDS (E x K fp32 = 67 KB for qm9_CC): one HBM read and one HBM
+// write of rank2 per half-step.  Used when E <= 64 and the block fits (ccsd_plan::fused_r2).
+//   phase 0  load F -> LDS (row stride ldk == 2 mod 32: conflict-free MFMA fragment reads), cell masks,
+//            adjacency powers' upper triangle (adj_to_hodgedual inputs)
+//   phase 1  MFMA tiles over the full K:  H = F F^T (upper-triangle tiles, mirrored),
+//            P_0 = F Wcat_0,  P_1 = rank2' Wcat_1  (hodge projections for k_xa, written to HBM)
+//   phase 2  per 16-column tile: (H F) on MFMA, ScoreNetworkF element-wise, epilogue in place in LDS
+//   phase 3  coalesced LDS -> HBM copy of the result
+// Same arithmetic as k_gemm_h / k_gemm_p / k_hf_score (those remain the general path).
+// ---------------------------------------------------------------------------------------------
+template <class LA, class LB, class EP>
+CCSD_DEV void wave_tile(int m0, int n0, int ks, LA la, LB lb, EP ep) {
+#ifdef CCSD_EMU
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+            float acc = 0.f;
+            for (int k = 0; k < 4 * ks; ++k) acc = fmaf(la(m0 + i, k), lb(k, n0 + j), acc);
+            ep(m0 + i, n0 + j, acc);
+        }
+#else
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 4 <= ks; s += 4) {          // issue the 8 operand loads of four k-steps before the MFMAs consume them
+        float a[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = la(m0 + l15, 4 * (s + u) + kq); bv[u] = lb(4 * (s + u) + kq, n0 + l15); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bv[u], acc, 0, 0, 0);
+    }
+    for (; s < ks; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(la(m0 + l15, 4 * s + kq), lb(4 * s + kq, n0 + l15), acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ep(m0 + 4 * kq + r, n0 + l15, acc[r]);
+#endif
+}
+
+// All `mt` (<= 4) 16-row tiles of one 16-column block: accumulate every tile first, run the epilogue
+// afterwards (the epilogue may overwrite the B operand in place).
+template <class LA, class LB, class EP>
+CCSD_DEV void wave_coltile(int n0, int mt, int ks, LA la, LB lb, EP ep4) {
+#ifdef CCSD_EMU
+    float acc[64][16];
+    for (int i = 0; i < 16 * mt; ++i)
+        for (int j = 0; j < 16; ++j) {
+            float a = 0.f;
+            for (int k = 0; k < 4 * ks; ++k) a = fmaf(la(i, k), lb(k, n0 + j), a);
+            acc[i][j] = a;
+        }
+    for (int i = 0; i < 16 * mt; i += 4)
+        for (int j = 0; j < 16; ++j) {
+            const float v[4] = {acc[i][j], acc[i + 1][j], acc[i + 2][j], acc[i + 3][j]};
+            ep4(i, n0 + j, v);
+        }
+#else
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < ks; ++s) {
+        const float bv = lb(4 * s + kq, n0 + l15);
+        float a[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = t < mt ? la(16 * t + l15, 4 * s + kq) : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (t < mt) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bv, acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (t < mt) {
+            const float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+            ep4(16 * t + 4 * kq, n0 + l15, v);
+        }
+#endif
+}
+
+CCSD_DEV float raw_noise_r1(const NoiseArgs& na, int b, int e, int k, int E, int K) {
+    if (na.zr) return na.zr[((size_t)b * E + e) * K + k];
+    float n[4];
+    philox_normal4(na.seed, na.draw_r, na.b_off + b, (unsigned)((e >> 2) * K + k), n);
+    const int s = e & 3;
+    return s == 0 ? n[0] : s == 1 ? n[1] : s == 2 ? n[2] : n[3];
+}
+
+struct R2Args {
+    const float* rank2; const float* adj; const float* flags;
+    float* P0; float* P1;
+    int want_p;            // write the hodge projections (the A-network will run on the same state)
+    int ldk, ldh;
+};
+
+__global__ __launch_bounds__(512) void k_r2(const PlanD* __restrict__ plan, const float* __restrict__ w,
+                                            const unsigned char* __restrict__ edges,
+                                            const unsigned long long* __restrict__ cells, R2Args ra, RankEpi ep,
+                                            NoiseArgs na) {
+    CCSD_DYN_SMEM(sm);
+    const PlanD& p = *plan;
+    const int E = p.E, K = p.K, N = p.N, NN = N * N, ldk = ra.ldk, ldh = ra.ldh;
+    const int b = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    const int wave = tid >> 6, nw = nth >= 64 ? nth >> 6 : 1;
+    const int Kp4 = (K + 3) & ~3, Ep4 = (E + 3) & ~3;
+    float* sF = sm;                        // [E][ldk]
+    float* sH = sF + E * ldk;              // [E][ldh]
+    float* sFr = sH + E * ldh;             // [Kp4] flags_right (cell masks), zero in the pad
+    float* sFl = sFr + Kp4;                // [64]  flags_left (edge masks)
+    float* sRow = sFl + 64;                // [64]  per-row scale of rank2' (linear mlp_value)
+    float* sU = sRow + 64;                 // [wc1 <= 64] fr . Wcat_1
+    float* sAco = sU + 64;                 // [cinit][E] adjacency powers' upper triangle
+    float* sAdj = sAco + p.a_cinit * E;    // 3 x [N*N] scratch for the powers
+    float* sRed = sAdj + 3 * NN;           // [64]
+    __shared__ unsigned long long s_off;
+    const float* Fg = ra.rank2 + (size_t)b * E * K;
+    const FastDiv dK(K);
+
+    // ---- phase 0
+    if (tid == 0) {
+        unsigned long long m = 0;
+        for (int n = 0; n < N; ++n)
+            if (ra.flags[(size_t)b * N + n] == 0.f) m |= 1ull << n;
+        s_off = m;
+    }
+    for (int t = tid; t < E * K; t += nth) {
+        int e, k;
+        dK.divmod(t, e, k);
+        sF[e * ldk + k] = Fg[t];
+    }
+    for (int t = tid; t < E * (Kp4 - K); t += nth) { const int e = t / (Kp4 - K), k = K + t % (Kp4 - K); sF[e * ldk + k] = 0.f; }
+    const int hodge2 = (p.h_L > 1) && ra.want_p;
+    if (hodge2)
+        for (int i = tid; i < NN; i += nth) { const float v = ra.adj[(size_t)b * NN + i]; sAdj[i] = v; sAdj[NN + i] = v; }
+    __syncthreads();
+    const unsigned long long off = s_off;
+    for (int k = tid; k < Kp4; k += nth) sFr[k] = k < K ? cell_on(off, cells, k) : 0.f;
+    for (int e = tid; e < 64; e += nth) sFl[e] = e < E ? edge_on(off, edges, e) : 0.f;
+    if (hodge2) {
+        // acoef[c][e] = (adj^(c+1))[i_e][j_e]   (pow_tensor + adj_to_hodgedual, graph_utils.py:285-292, cc_utils.py:1525-1536)
+        float* A = sAdj; float* P0_ = sAdj + NN; float* P1_ = sAdj + 2 * NN;
+        for (int c = 0; c < p.a_cinit; ++c) {
+            for (int e = tid; e < E; e += nth) sAco[c * E + e] = P0_[edges[2 * e] * N + edges[2 * e + 1]];
+            if (c + 1 < p.a_cinit) {
+                for (int i = tid; i < NN; i += nth) {
+                    const int r = i / N, cc = i % N;
+                    float acc = 0.f;
+                    for (int kk = 0; kk < N; ++kk) acc = fmaf(P0_[r * N + kk], A[kk * N + cc], acc);
+                    P1_[i] = acc;
+                }
+                __syncthreads();
+                float* t2 = P0_; P0_ = P1_; P1_ = t2;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    const HodgeLayerD& h0 = p.hl[0];
+    const HodgeLayerD& h1 = p.hl[1];
+    const bool lin1 = hodge2 && h0.mval.n == 1;      // rank2' is affine in rank2: fold it around the GEMM
+    if (hodge2 && lin1) {
+        // rank2'[e,k] = fl[e] fr[k] (sum_c w_c a_c[e] F[e,k] + b)  ->  P_1[e,:] = fl[e] (s[e] ((F.fr) W_1)[e,:] + b (fr W_1))
+        for (int e = tid; e < E; e += nth) {
+            float sc = 0.f;
+            for (int c = 0; c < h0.cin; ++c) sc = fmaf(w[h0.mval.w[0] + c], sAco[c * E + e], sc);
+            sRow[e] = sc;
+        }
+        // u[n] = sum_k fr[k] Wcat_1[k][n]: threads = wc1 columns x k-segments, partials through LDS (sH is still free)
+        const int wc = h1.wc, seg = (nth / wc) > 0 ? (nth / wc) : 1;
+        for (int t = tid; t < wc * seg; t += nth) {
+            const int n = t % wc, sg = t / wc;
+            float acc = 0.f;
+            for (int k = sg; k < K; k += seg) acc = fmaf(sFr[k], w[h1.wcat + (size_t)k * wc + n], acc);
+            sH[sg * wc + n] = acc;
+        }
+        __syncthreads();
+        for (int n = tid; n < wc; n += nth) {
+            float acc = 0.f;
+            for (int sg = 0; sg < seg; ++sg) acc += sH[sg * wc + n];
+            sU[n] = acc;
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 1: tiles over the full K
+    const int mt = (E + 15) >> 4, ks = Kp4 >> 2;
+    const int nH = p.f_cnum == 2 ? mt * (mt + 1) / 2 : 0;
+    const int nt0 = ra.want_p && p.h_L > 0 ? (h0.wc + 15) >> 4 : 0;
+    const int nt1 = hodge2 ? (h1.wc + 15) >> 4 : 0;
+    const int ntask = nH + mt * nt0 + mt * nt1;
+    auto ldF = [&](int r, int k) { return sF[(r < E ? r : E - 1) * ldk + k]; };   // rows >= E are never stored
+    for (int task = wave; task < ntask; task += nw) {
+        if (task < nH) {
+            int ti = 0, tj = 0, c = task;           // upper-triangle tile index -> (ti <= tj)
+            while (c >= mt - ti) { c -= mt - ti; ++ti; }
+            tj = ti + c;
+            wave_tile(ti * 16, tj * 16, ks, ldF, [&](int k, int n) { return ldF(n, k); },
+                      [&](int m, int n, float v) {
+                          if (m < E && n < E) {
+                              const float hv = (p.f_hmask && m == n) ? 0.f : v;   // hodge_mask zeroes the diagonal
+                              sH[m * ldh + n] = hv;
+                              sH[n * ldh + m] = hv;
+                          }
+                      });
+        } else if (task < nH + mt * nt0) {
+            const int t = task - nH, ti = t % mt, tn = t / mt;
+            const float* Wc = w + h0.wcat;
+            const int wc = h0.wc;
+            float* Pg = ra.P0 + (size_t)b * E * wc;
+            wave_tile(ti * 16, tn * 16, ks, ldF,
+                      [&](int k, int n) { return (k < K && n < wc) ? Wc[(size_t)k * wc + n] : 0.f; },
+                      [&](int m, int n, float v) { if (m < E && n < wc) Pg[(size_t)m * wc + n] = v; });
+        } else {
+            const int t = task - nH - mt * nt0, ti = t % mt, tn = t / mt;
+            const float* Wc = w + h1.wcat;
+            const int wc = h1.wc;
+            float* Pg = ra.P1 + (size_t)b * E * wc;
+            if (lin1) {
+                const float bb = w[h0.mval.b[0]];
+                wave_tile(ti * 16, tn * 16, ks, [&](int r, int k) { return ldF(r, k) * sFr[k]; },
+                          [&](int k, int n) { return (k < K && n < wc) ? Wc[(size_t)k * wc + n] : 0.f; },
+                          [&](int m, int n, float v) {
+                              if (m < E && n < wc) Pg[(size_t)m * wc + n] = sFl[m] * fmaf(sRow[m], v, bb * sU[n]);
+                          });
+            } else {
+                // general mlp_value: rank2' element-wise on the fly (hodge_attention.py:322-323)
+                wave_tile(ti * 16, tn * 16, ks,
+                          [&](int r, int k) {
+                              const int e = r < E ? r : E - 1;
+                              const float v = sF[e * ldk + k];
+                              float in[CCSD_SMALLW], out[CCSD_SMALLW];
+#pragma unroll
+                              for (int c = 0; c < CCSD_SMALLW; ++c) in[c] = c < h0.cin ? sAco[c * E + e] * v : 0.f;
+                              small_mlp<CCSD_SMALLW>(h0.mval, w, in, out);
+                              return sFl[e] * out[0] * sFr[k];
+                          },
+                          [&](int k, int n) { return (k < K && n < wc) ? Wc[(size_t)k * wc + n] : 0.f; },
+                          [&](int m, int n, float v) { if (m < E && n < wc) Pg[(size_t)m * wc + n] = v; });
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: (H F) per 16-column tile, ScoreNetworkF element-wise, epilogue in place
+    float s_net = 0.f, s_z = 0.f;
+    const int ntn = (K + 15) >> 4, ksE = Ep4 >> 2;
+    for (int tn = wave; tn < ntn; tn += nw) {
+        {
+            wave_coltile(tn * 16, mt, p.f_cnum == 2 ? ksE : 0,
+                      [&](int m, int k) { return (k < E) ? sH[(m < E ? m : E - 1) * ldh + k] : 0.f; },
+                      [&](int k, int n) { return (k < E && n < K) ? sF[k * ldk + n] : 0.f; },
+                      [&](int e0, int k, const float* hf) {
+                          if (e0 >= E || k >= K) return;
+                          float z[4] = {0.f, 0.f, 0.f, 0.f};
+                          if (ep.mode != MODE_SCORE) raw_noise_r4(na, b, e0 >> 2, k, E, K, z);   // one Philox group = 4 edge rows
+                          const float fr = sFr[k];
+#pragma unroll
+                          for (int r = 0; r < 4; ++r) {
+                              const int e = e0 + r;
+                              if (e >= E) continue;
+                              const float f = sF[e * ldk + k];
+                              const float m = sFl[e] * fr;                         // flags_left * flags_right, cc_utils.py:590
+                              const float net = fnet_element(p, w, f, hf[r], m);
+                              if (ep.mode == MODE_SCORE) {
+                                  sF[e * ldk + k] = ep.sscale * net;
+                              } else {
+                                  const float zz = z[r] * m;                       // gen_noise_rank2, cc_utils.py:613-615
+                                  if (ep.mode == MODE_NORMS) {
+                                      sF[e * ldk + k] = net;
+                                      s_net = fmaf(net, net, s_net);
+                                      s_z = fmaf(zz, zz, s_z);
+                                  } else {
+                                      const float mean = fmaf(ep.pa, f, ep.pb * net);
+                                      if (ep.mean) ep.mean[((size_t)b * E + e) * K + k] = mean;
+                                      sF[e * ldk + k] = fmaf(ep.pc, zz, mean);
+                                  }
+                              }
+                          }
+                      });
+        }
+    }
+    __syncthreads();
+    // ---- phase 3
+    float* og = ep.out + (size_t)b * E * K;
+    for (int t = tid; t < E * K; t += nth) {
+        int e, k;
+        dK.divmod(t, e, k);
+        og[t] = sF[e * ldk + k];
+    }
+    if (ep.mode == MODE_NORMS) {
+        const float tn_ = block_sum(s_net, sRed);
+        const float tz_ = block_sum(s_z, sRed);
+        if (tid == 0) { ep.part[(size_t)b * 2 + 0] = tn_; ep.part[(size_t)b * 2 + 1] = tz_; }
     }
 }
 
