@@ -21,6 +21,7 @@ struct ccsd_plan {
     unsigned long long* cells = nullptr;
     std::vector<ccsd_step_coef_t> coef;  // [diff_steps][3]
     size_t nweights = 0;
+    long long* dbg = nullptr;   // diagnostic cycle stamps (ccsd_debug_stamps)
     // fused rank-2 kernel (k_r2): eligibility and LDS geometry
     int fused_r2 = 0, r2_ldk = 0, r2_ldh = 0;
     size_t r2_lds = 0;
@@ -74,6 +75,11 @@ extern "C" size_t ccsd_weight_count(const ccsd_config_t* cfg) {
     return n;
 }
 
+extern "C" int ccsd_debug_stamps(ccsd_plan_t* plan, void* dev_buffer) {
+    if (!plan) return set_err(CCSD_ERR_INVALID, "NULL plan");
+    plan->dbg = (long long*)dev_buffer;
+    return CCSD_OK;
+}
 extern "C" int ccsd_profile_kernel(ccsd_plan_t* plan, int32_t kernel_id) {
     if (!plan) return set_err(CCSD_ERR_INVALID, "NULL plan");
     plan->prof_kernel = kernel_id;
@@ -167,19 +173,26 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     // fused rank-2 path: one complex's rank2 block (E x K) LDS-resident, E <= 64
     if (cfg->is_cc && E <= 64 && getenv("CCSD_NO_FUSED_R2") == nullptr) {
         const PlanD& p = pl->h;
-        const int Kp4 = (K + 3) & ~3, Ep4 = (E + 3) & ~3;
-        int ldk = Kp4; while (ldk % 32 != 2) ++ldk;       // == 2 mod 32: conflict-free 16x4 fragment reads
-        int ldh = Ep4; while (ldh % 32 != 2) ++ldh;
-        while (E * ldh < 1024) ldh += 32;                  // doubles as scratch for a 512-thread reduction
-        const size_t fl = (size_t)E * ldk + (size_t)E * ldh + Kp4 + 64 * 3 + (size_t)p.a_cinit * E + 3 * N * N + 64;
-        const bool wc_ok = p.h_L < 2 || p.hl[1].wc <= 64;
+        const int Kp4 = (K + 31) & ~31, Ep4 = (E + 3) & ~3;   // K zero-padded to whole 8-step MFMA batches
+        int ldk = Kp4; while ((ldk & 1) || ((ldk >> 1) & 1) == 0) ++ldk;   // ldk/2 odd: conflict-free 16x4 fragment reads
+        int ldh = Ep4 | 1;                                                 // odd stride; H fragments are read once per wave
+        const size_t fl = (size_t)E * ldk + (size_t)E * ldh + 64 * 2 + (size_t)p.a_cinit * E + 3 * N * N + 64 + (Kp4 + 3) / 4 + 4;
+        const bool wc_ok = true;
         if (fl * 4 + 64 <= 160 * 1024 && wc_ok) {
             pl->fused_r2 = 1; pl->r2_ldk = ldk; pl->r2_ldh = ldh; pl->r2_lds = fl * 4;
         }
     }
 #ifndef CCSD_EMU
     if ((size_t)pl->h.xa_lds_floats * 4 > 64 * 1024) PC(rt_set_max_dyn_smem((const void*)k_xa, (size_t)pl->h.xa_lds_floats * 4));
-    if (pl->fused_r2 && pl->r2_lds > 64 * 1024) PC(rt_set_max_dyn_smem((const void*)k_r2, pl->r2_lds));
+    if (pl->fused_r2 && pl->r2_lds > 64 * 1024) {
+        const int MT = (E + 15) / 16;
+        const bool aff = pl->h.f_affine != 0, gen1 = pl->h.h_L > 1 && pl->h.hl[0].mval.n > 1;
+#define R2_FN(MT_) (aff ? (gen1 ? (const void*)k_r2<MT_, true, true> : (const void*)k_r2<MT_, true, false>) \
+                        : (gen1 ? (const void*)k_r2<MT_, false, true> : (const void*)k_r2<MT_, false, false>))
+        const void* fn = MT == 1 ? R2_FN(1) : MT == 2 ? R2_FN(2) : MT == 3 ? R2_FN(3) : R2_FN(4);
+#undef R2_FN
+        PC(rt_set_max_dyn_smem(fn, pl->r2_lds));
+    }
 #endif
 #undef PC
     *out = pl;
@@ -283,7 +296,7 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
     return CCSD_OK;
 }
 static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Workspace& w, void* stream) {
-    xa.P0 = w.P0; xa.P1 = w.P1;
+    xa.P0 = w.P0; xa.P1 = w.P1; xa.dbg = pl->dbg ? pl->dbg + 16 : nullptr;
     prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
     CCSD_LAUNCH(k_xa, dim3(B), dim3(CCSD_NTHREADS == 1 ? 1 : 512), (size_t)pl->h.xa_lds_floats * 4, stream, (const PlanD*)pl->d,
                 (const float*)pl->w, (const unsigned char*)pl->edges, xa, na);
@@ -295,9 +308,14 @@ static int launch_hf(const ccsd_plan* pl, int B, const float* rank2, RankEpi& ep
     const PlanD& p = pl->h;
     dim3 g((p.K + T_BN - 1) / T_BN, (p.E + T_BM - 1) / T_BM, B);
     prof_mark(const_cast<ccsd_plan*>(pl), KID_HF, stream);
-    CCSD_LAUNCH(k_hf_score, g, dim3(CCSD_NTHREADS), 0, stream, (const PlanD*)pl->d, (const float*)pl->w, rank2,
-                (const float*)w.H, (const unsigned long long*)w.offbits, (const unsigned char*)pl->edges,
-                (const unsigned long long*)pl->cells, ep, na);
+    if (p.f_affine)
+        CCSD_LAUNCH(k_hf_score<true>, g, dim3(CCSD_NTHREADS), 0, stream, (const PlanD*)pl->d, (const float*)pl->w, rank2,
+                    (const float*)w.H, (const unsigned long long*)w.offbits, (const unsigned char*)pl->edges,
+                    (const unsigned long long*)pl->cells, ep, na);
+    else
+        CCSD_LAUNCH(k_hf_score<false>, g, dim3(CCSD_NTHREADS), 0, stream, (const PlanD*)pl->d, (const float*)pl->w, rank2,
+                    (const float*)w.H, (const unsigned long long*)w.offbits, (const unsigned char*)pl->edges,
+                    (const unsigned long long*)pl->cells, ep, na);
     prof_mark(const_cast<ccsd_plan*>(pl), KID_HF, stream);
     LAUNCH_CHECK();
     return CCSD_OK;
@@ -307,10 +325,26 @@ static int launch_r2(const ccsd_plan* pl, int B, const float* rank2, const float
                      RankEpi& ep, NoiseArgs& na, Workspace& w, void* stream) {
     R2Args ra{};
     ra.rank2 = rank2; ra.adj = adj; ra.flags = flags; ra.P0 = w.P0; ra.P1 = w.P1; ra.want_p = want_p;
-    ra.ldk = pl->r2_ldk; ra.ldh = pl->r2_ldh;
+    ra.ldk = pl->r2_ldk; ra.ldh = pl->r2_ldh; ra.dbg = pl->dbg;
     prof_mark(const_cast<ccsd_plan*>(pl), KID_R2, stream);
-    CCSD_LAUNCH(k_r2, dim3(B), dim3(CCSD_NTHREADS == 1 ? 1 : 512), pl->r2_lds, stream, (const PlanD*)pl->d, (const float*)pl->w,
-                (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, ra, ep, na);
+    const dim3 blk(CCSD_NTHREADS == 1 ? 1 : 512);
+    const bool aff = pl->h.f_affine != 0, gen1 = pl->h.h_L > 1 && pl->h.hl[0].mval.n > 1;
+#define R2_ARGS (const PlanD*)pl->d, (const float*)pl->w, (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, ra, ep, na
+#define R2_GO(MT_) \
+    do { \
+        if (aff && !gen1) CCSD_LAUNCH((k_r2<MT_, true, false>), dim3(B), blk, pl->r2_lds, stream, R2_ARGS); \
+        else if (aff) CCSD_LAUNCH((k_r2<MT_, true, true>), dim3(B), blk, pl->r2_lds, stream, R2_ARGS); \
+        else if (!gen1) CCSD_LAUNCH((k_r2<MT_, false, false>), dim3(B), blk, pl->r2_lds, stream, R2_ARGS); \
+        else CCSD_LAUNCH((k_r2<MT_, false, true>), dim3(B), blk, pl->r2_lds, stream, R2_ARGS); \
+    } while (0)
+    switch ((pl->h.E + 15) / 16) {
+        case 1: R2_GO(1); break;
+        case 2: R2_GO(2); break;
+        case 3: R2_GO(3); break;
+        default: R2_GO(4); break;
+    }
+#undef R2_GO
+#undef R2_ARGS
     prof_mark(const_cast<ccsd_plan*>(pl), KID_R2, stream);
     LAUNCH_CHECK();
     return CCSD_OK;

@@ -21,6 +21,15 @@
 // ---------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------
+// Diagnostic cycle stamps (ccsd_debug_stamps): thread 0 of every workgroup writes the shader clock at phase
+// boundaries into a caller buffer [workgroup][32].  NULL (the default) compiles to a uniform branch not taken.
+CCSD_DEV void stamp(long long* dbg, int slot) {
+#ifndef CCSD_EMU
+    if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 32 + slot] = (long long)__builtin_readcyclecounter();
+#else
+    (void)dbg; (void)slot;
+#endif
+}
 // exp(x) through the hardware base-2 exponential (v_exp_f32, ~1 ulp)
 CCSD_DEV float fast_exp(float x) {
 #ifdef CCSD_EMU
@@ -222,13 +231,20 @@ CCSD_DEV void block_linear(float* Y, int ldy, const float* X, int ldx, const flo
         const int am = (m0 + l15 < rows) ? m0 + l15 : rows - 1;      // clamp: rows beyond `rows` are never stored
         const float* wr = W + (size_t)(bn < out ? bn : 0) * in;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < ks; ++s) {
-            const int k = 4 * s + kq;
-            const bool kin = k < in;
-            const float* xp = k < ksplit ? X + k * ldx : X2 + (k - ksplit) * ldx;
-            const float a = kin ? xp[am] : 0.f;
-            const float bv = (kin && bn < out) ? wr[k] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
+        for (int s0 = 0; s0 < ks; s0 += 4) {   // weights come from L2: issue the loads of four k-steps before the MFMAs
+            float a[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = 4 * (s0 + u) + kq;
+                const bool kin = k < in;
+                const int kc = kin ? k : 0;
+                const float* xp = kc < ksplit ? X + kc * ldx : X2 + (kc - ksplit) * ldx;
+                a[u] = kin ? xp[am] : 0.f;
+                bv[u] = (kin && bn < out) ? wr[kc] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (s0 + u < ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bv[u], acc, 0, 0, 0);
         }
         if (bn < out) {
             const float bb = bias[bn];
@@ -473,8 +489,9 @@ struct RankEpi {
     float* part;             // NORMS: [B][ntiles][2] partial sums of net^2 and z^2
 };
 
+template <bool AFFINE>
 CCSD_DEV float fnet_element(const PlanD& p, const float* __restrict__ w, float f, float hf, float m) {
-    if (p.f_affine) return m * fmaf(p.f_alpha, f, fmaf(p.f_beta, hf, p.f_gamma));
+    if (AFFINE) return m * fmaf(p.f_alpha, f, fmaf(p.f_beta, hf, p.f_gamma));
     // general path: channels [F, HF] -> L x (MLP, mask) -> concat -> final MLP -> mask
     float ch[CCSD_FW];
 #pragma unroll
@@ -506,6 +523,7 @@ CCSD_DEV float fnet_element(const PlanD& p, const float* __restrict__ w, float f
     return m * out[0];
 }
 
+template <bool AFFINE>
 __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan, const float* __restrict__ w,
                                                   const float* __restrict__ rank2, const float* __restrict__ H,
                                                   const unsigned long long* __restrict__ offbits,
@@ -552,7 +570,7 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
             const size_t gi = ((size_t)b * E + e) * K + k;
             const float f = Fb[(size_t)e * K + k];
             const float m = edge_on(off, edges, e) * fr;          // flags_left * flags_right, cc_utils.py:590
-            const float net = fnet_element(p, w, f, hf[s], m);
+            const float net = fnet_element<AFFINE>(p, w, f, hf[s], m);
             const float zz = z[s] * m;                            // gen_noise_rank2, cc_utils.py:613-615
             if (ep.mode == MODE_SCORE) {
                 ep.out[gi] = ep.sscale * net;
@@ -640,14 +658,26 @@ CCSD_DEV void wave_coltile(int n0, int mt, int ks, LA la, LB lb, EP ep4) {
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < ks; ++s) {
-        const float bv = lb(4 * s + kq, n0 + l15);
-        float a[4];
+    int s = 0;
+    for (; s + 4 <= ks; s += 4) {      // four k-steps: all operand loads first (B may come from L2), then the MFMAs
+        float bv[4], a[4][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) a[t] = t < mt ? la(16 * t + l15, 4 * s + kq) : 0.f;
+        for (int u = 0; u < 4; ++u) bv[u] = lb(4 * (s + u) + kq, n0 + l15);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[u][t] = t < mt ? la(16 * t + l15, 4 * (s + u) + kq) : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (t < mt) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], bv[u], acc[t], 0, 0, 0);
+    }
+    for (; s < ks; ++s) {
+        const float bv = lb(4 * s + kq, n0 + l15);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-            if (t < mt) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bv, acc[t], 0, 0, 0);
+            if (t < mt) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(la(16 * t + l15, 4 * s + kq), bv, acc[t], 0, 0, 0);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -671,9 +701,13 @@ struct R2Args {
     float* P0; float* P1;
     int want_p;            // write the hodge projections (the A-network will run on the same state)
     int ldk, ldh;
+    long long* dbg;
 };
 
-__global__ __launch_bounds__(512) void k_r2(const PlanD* __restrict__ plan, const float* __restrict__ w,
+// MT = ceil(E / 16) row tiles (1..4); AFFINE: ScoreNetworkF folds to alpha F + beta HF + gamma; GEN1: general
+// (non-affine) mlp_value in the hodge branch.  Compile-time so that the common variant carries no general-path code.
+template <int MT, bool AFFINE, bool GEN1>
+__global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, const float* __restrict__ w,
                                             const unsigned char* __restrict__ edges,
                                             const unsigned long long* __restrict__ cells, R2Args ra, RankEpi ep,
                                             NoiseArgs na) {
@@ -681,32 +715,56 @@ __global__ __launch_bounds__(512) void k_r2(const PlanD* __restrict__ plan, cons
     const PlanD& p = *plan;
     const int E = p.E, K = p.K, N = p.N, NN = N * N, ldk = ra.ldk, ldh = ra.ldh;
     const int b = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
-    const int wave = tid >> 6, nw = nth >= 64 ? nth >> 6 : 1;
-    const int Kp4 = (K + 3) & ~3, Ep4 = (E + 3) & ~3;
+    const int Kp4 = (K + 31) & ~31, Ep4 = (E + 3) & ~3;   // K is zero-padded to whole 8-step batches in LDS
     float* sF = sm;                        // [E][ldk]
     float* sH = sF + E * ldk;              // [E][ldh]
-    float* sFr = sH + E * ldh;             // [Kp4] flags_right (cell masks), zero in the pad
-    float* sFl = sFr + Kp4;                // [64]  flags_left (edge masks)
+    float* sFl = sH + E * ldh;             // [64]  flags_left (edge masks)
     float* sRow = sFl + 64;                // [64]  per-row scale of rank2' (linear mlp_value)
-    float* sU = sRow + 64;                 // [wc1 <= 64] fr . Wcat_1
-    float* sAco = sU + 64;                 // [cinit][E] adjacency powers' upper triangle
+    float* sAco = sRow + 64;               // [cinit][E] adjacency powers' upper triangle
     float* sAdj = sAco + p.a_cinit * E;    // 3 x [N*N] scratch for the powers
     float* sRed = sAdj + 3 * NN;           // [64]
+    unsigned char* sFrb = reinterpret_cast<unsigned char*>(sRed + 64);   // [Kp4] flags_right (cell masks) as bytes
     __shared__ unsigned long long s_off;
     const float* Fg = ra.rank2 + (size_t)b * E * K;
     const FastDiv dK(K);
 
-    // ---- phase 0
+    // ---- phase 0: rank2 block -> LDS; masks; adjacency powers
+    stamp(ra.dbg, 0);
     if (tid == 0) {
         unsigned long long m = 0;
         for (int n = 0; n < N; ++n)
             if (ra.flags[(size_t)b * N + n] == 0.f) m |= 1ull << n;
         s_off = m;
     }
-    for (int t = tid; t < E * K; t += nth) {
-        int e, k;
-        dK.divmod(t, e, k);
-        sF[e * ldk + k] = Fg[t];
+    if (((E * K) & 3) == 0) {
+        // the block is 16-byte aligned and a multiple of 16 bytes: batches of four float4 loads in flight per thread
+        const float4* F4 = reinterpret_cast<const float4*>(Fg);
+        const int n4 = (E * K) >> 2;
+        for (int base = tid; base < n4; base += 4 * nth) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i4 = base + u * nth; if (i4 < n4) v[u] = F4[i4]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i4 = base + u * nth;
+                if (i4 < n4) {
+                    int e, k;
+                    dK.divmod(4 * i4, e, k);
+                    const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        sF[e * ldk + k] = vv[q];
+                        if (++k == K) { k = 0; ++e; }
+                    }
+                }
+            }
+        }
+    } else {
+        for (int t = tid; t < E * K; t += nth) {
+            int e, k;
+            dK.divmod(t, e, k);
+            sF[e * ldk + k] = Fg[t];
+        }
     }
     for (int t = tid; t < E * (Kp4 - K); t += nth) { const int e = t / (Kp4 - K), k = K + t % (Kp4 - K); sF[e * ldk + k] = 0.f; }
     const int hodge2 = (p.h_L > 1) && ra.want_p;
@@ -714,7 +772,7 @@ __global__ __launch_bounds__(512) void k_r2(const PlanD* __restrict__ plan, cons
         for (int i = tid; i < NN; i += nth) { const float v = ra.adj[(size_t)b * NN + i]; sAdj[i] = v; sAdj[NN + i] = v; }
     __syncthreads();
     const unsigned long long off = s_off;
-    for (int k = tid; k < Kp4; k += nth) sFr[k] = k < K ? cell_on(off, cells, k) : 0.f;
+    for (int k = tid; k < Kp4; k += nth) sFrb[k] = (k < K && !(cells[k] & off)) ? 1 : 0;
     for (int e = tid; e < 64; e += nth) sFl[e] = e < E ? edge_on(off, edges, e) : 0.f;
     if (hodge2) {
         // acoef[c][e] = (adj^(c+1))[i_e][j_e]   (pow_tensor + adj_to_hodgedual, graph_utils.py:285-292, cc_utils.py:1525-1536)
@@ -735,143 +793,321 @@ __global__ __launch_bounds__(512) void k_r2(const PlanD* __restrict__ plan, cons
         }
     }
     __syncthreads();
+    stamp(ra.dbg, 1);
     const HodgeLayerD& h0 = p.hl[0];
     const HodgeLayerD& h1 = p.hl[1];
-    const bool lin1 = hodge2 && h0.mval.n == 1;      // rank2' is affine in rank2: fold it around the GEMM
-    if (hodge2 && lin1) {
+    const bool doP0 = ra.want_p && p.h_L > 0, doP1 = hodge2;
+    const bool lin1 = doP1 && h0.mval.n == 1;      // rank2' affine in rank2: fold it around the GEMM
+    const int wc0 = doP0 ? h0.wc : 0, wc1 = doP1 ? h1.wc : 0;
+    if (lin1) {
         // rank2'[e,k] = fl[e] fr[k] (sum_c w_c a_c[e] F[e,k] + b)  ->  P_1[e,:] = fl[e] (s[e] ((F.fr) W_1)[e,:] + b (fr W_1))
         for (int e = tid; e < E; e += nth) {
             float sc = 0.f;
             for (int c = 0; c < h0.cin; ++c) sc = fmaf(w[h0.mval.w[0] + c], sAco[c * E + e], sc);
             sRow[e] = sc;
         }
-        // u[n] = sum_k fr[k] Wcat_1[k][n]: threads = wc1 columns x k-segments, partials through LDS (sH is still free)
-        const int wc = h1.wc, seg = (nth / wc) > 0 ? (nth / wc) : 1;
-        for (int t = tid; t < wc * seg; t += nth) {
-            const int n = t % wc, sg = t / wc;
-            float acc = 0.f;
-            for (int k = sg; k < K; k += seg) acc = fmaf(sFr[k], w[h1.wcat + (size_t)k * wc + n], acc);
-            sH[sg * wc + n] = acc;
-        }
-        __syncthreads();
-        for (int n = tid; n < wc; n += nth) {
-            float acc = 0.f;
-            for (int sg = 0; sg < seg; ++sg) acc += sH[sg * wc + n];
-            sU[n] = acc;
-        }
         __syncthreads();
     }
 
-    // ---- phase 1: tiles over the full K
-    const int mt = (E + 15) >> 4, ks = Kp4 >> 2;
-    const int nH = p.f_cnum == 2 ? mt * (mt + 1) / 2 : 0;
-    const int nt0 = ra.want_p && p.h_L > 0 ? (h0.wc + 15) >> 4 : 0;
-    const int nt1 = hodge2 ? (h1.wc + 15) >> 4 : 0;
-    const int ntask = nH + mt * nt0 + mt * nt1;
-    auto ldF = [&](int r, int k) { return sF[(r < E ? r : E - 1) * ldk + k]; };   // rows >= E are never stored
-    for (int task = wave; task < ntask; task += nw) {
-        if (task < nH) {
-            int ti = 0, tj = 0, c = task;           // upper-triangle tile index -> (ti <= tj)
-            while (c >= mt - ti) { c -= mt - ti; ++ti; }
-            tj = ti + c;
-            wave_tile(ti * 16, tj * 16, ks, ldF, [&](int k, int n) { return ldF(n, k); },
-                      [&](int m, int n, float v) {
-                          if (m < E && n < E) {
-                              const float hv = (p.f_hmask && m == n) ? 0.f : v;   // hodge_mask zeroes the diagonal
-                              sH[m * ldh + n] = hv;
-                              sH[n * ldh + m] = hv;
-                          }
-                      });
-        } else if (task < nH + mt * nt0) {
-            const int t = task - nH, ti = t % mt, tn = t / mt;
-            const float* Wc = w + h0.wcat;
-            const int wc = h0.wc;
-            float* Pg = ra.P0 + (size_t)b * E * wc;
-            wave_tile(ti * 16, tn * 16, ks, ldF,
-                      [&](int k, int n) { return (k < K && n < wc) ? Wc[(size_t)k * wc + n] : 0.f; },
-                      [&](int m, int n, float v) { if (m < E && n < wc) Pg[(size_t)m * wc + n] = v; });
-        } else {
-            const int t = task - nH - mt * nt0, ti = t % mt, tn = t / mt;
-            const float* Wc = w + h1.wcat;
-            const int wc = h1.wc;
-            float* Pg = ra.P1 + (size_t)b * E * wc;
-            if (lin1) {
-                const float bb = w[h0.mval.b[0]];
-                wave_tile(ti * 16, tn * 16, ks, [&](int r, int k) { return ldF(r, k) * sFr[k]; },
-                          [&](int k, int n) { return (k < K && n < wc) ? Wc[(size_t)k * wc + n] : 0.f; },
-                          [&](int m, int n, float v) {
-                              if (m < E && n < wc) Pg[(size_t)m * wc + n] = sFl[m] * fmaf(sRow[m], v, bb * sU[n]);
-                          });
-            } else {
-                // general mlp_value: rank2' element-wise on the fly (hodge_attention.py:322-323)
-                wave_tile(ti * 16, tn * 16, ks,
-                          [&](int r, int k) {
-                              const int e = r < E ? r : E - 1;
-                              const float v = sF[e * ldk + k];
-                              float in[CCSD_SMALLW], out[CCSD_SMALLW];
+    // ---- phase 1: H = F F^T (upper-triangle tiles, mirrored), P_0 = F Wcat_0, P_1 = rank2' Wcat_1.
+    // One 16x16 output tile over the full K per task; a wave runs two tasks interleaved (independent MFMA
+    // chains).  Operands of eight k-steps are fetched at once; the weight fragments, which come from L2,
+    // are double-buffered in registers one batch ahead.  No atomics: results are bitwise reproducible.
+    stamp(ra.dbg, 2);
+    const int ks = Kp4 >> 2;
+    const int nH = p.f_cnum == 2 ? MT * (MT + 1) / 2 : 0;
+    const int nt0 = doP0 ? (wc0 + 15) >> 4 : 0, nt1 = doP1 ? (wc1 + 15) >> 4 : 0;
+    const int ntask = nH + MT * nt0 + MT * nt1;
+#ifdef CCSD_EMU
+    (void)ks; (void)ntask;
+    for (int m = 0; m < E; ++m) {
+        for (int n = 0; n < E; ++n) {
+            float acc = 0.f;
+            if (p.f_cnum == 2) for (int kk = 0; kk < K; ++kk) acc = fmaf(sF[m * ldk + kk], sF[n * ldk + kk], acc);
+            sH[m * ldh + n] = (p.f_hmask && m == n) ? 0.f : acc;
+        }
+        for (int n = 0; n < wc0; ++n) {
+            float acc = 0.f;
+            for (int kk = 0; kk < K; ++kk) acc = fmaf(sF[m * ldk + kk], w[h0.wcat + (size_t)kk * wc0 + n], acc);
+            ra.P0[((size_t)b * E + m) * wc0 + n] = acc;
+        }
+        for (int n = 0; n < wc1; ++n) {
+            float acc = 0.f, un = 0.f;
+            for (int kk = 0; kk < K; ++kk) {
+                const float frk = (float)sFrb[kk], wv = w[h1.wcat + (size_t)kk * wc1 + n];
+                float a;
+                if (lin1) a = sF[m * ldk + kk] * frk;
+                else {
+                    float in[CCSD_SMALLW], out[CCSD_SMALLW];
+                    for (int c = 0; c < CCSD_SMALLW; ++c) in[c] = c < h0.cin ? sAco[c * E + m] * sF[m * ldk + kk] : 0.f;
+                    small_mlp<CCSD_SMALLW>(h0.mval, w, in, out);
+                    a = sFl[m] * out[0] * frk;
+                }
+                acc = fmaf(a, wv, acc);
+                un = fmaf(frk, wv, un);
+            }
+            ra.P1[((size_t)b * E + m) * wc1 + n] = lin1 ? sFl[m] * fmaf(sRow[m], acc, w[h0.mval.b[0]] * un) : acc;
+        }
+    }
+#else
+    {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const int wave = tid >> 6, nw = nth >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+        // wave -> pairs of tasks.  H tasks first (both operands from LDS), then projection tasks (B from L2).
+        const int nP = MT * (nt0 + nt1);
+        const int pairsH = (nH + 1) >> 1, pairsP = (nP + 1) >> 1;
+        for (int pr = wave; pr < pairsH + pairsP; pr += nw) {
+            const bool isH = pr < pairsH;
+            int ti[2], tj[2], rowA[2], rowB[2], wcn[2];
+            float okA[2], okB[2], usefr[2];
+            const float* Wp[2];
+            bool live[2];
 #pragma unroll
-                              for (int c = 0; c < CCSD_SMALLW; ++c) in[c] = c < h0.cin ? sAco[c * E + e] * v : 0.f;
-                              small_mlp<CCSD_SMALLW>(h0.mval, w, in, out);
-                              return sFl[e] * out[0] * sFr[k];
-                          },
-                          [&](int k, int n) { return (k < K && n < wc) ? Wc[(size_t)k * wc + n] : 0.f; },
-                          [&](int m, int n, float v) { if (m < E && n < wc) Pg[(size_t)m * wc + n] = v; });
+            for (int q = 0; q < 2; ++q) {
+                ti[q] = 0; tj[q] = 0; Wp[q] = w; wcn[q] = 1; usefr[q] = 0.f;
+                if (isH) {
+                    const int t = 2 * pr + q;
+                    live[q] = t < nH;
+                    int c = live[q] ? t : 0, i = 0;
+                    while (c >= MT - i) { c -= MT - i; ++i; }
+                    ti[q] = i; tj[q] = i + c;
+                } else {
+                    const int t = 2 * (pr - pairsH) + q;
+                    live[q] = t < nP;
+                    const int tt = live[q] ? t : 0;
+                    if (tt < MT * nt0) { ti[q] = tt % MT; tj[q] = tt / MT; Wp[q] = w + h0.wcat; wcn[q] = wc0; }
+                    else { const int u = tt - MT * nt0; ti[q] = u % MT; tj[q] = u / MT; Wp[q] = w + h1.wcat; wcn[q] = wc1; usefr[q] = 1.f; }
+                }
+                const int ra_ = 16 * ti[q] + l15, rb_ = 16 * tj[q] + l15;
+                rowA[q] = (ra_ < E ? ra_ : E - 1) * ldk; okA[q] = (ra_ < E && live[q]) ? 1.f : 0.f;
+                rowB[q] = (rb_ < E ? rb_ : E - 1) * ldk; okB[q] = rb_ < E ? 1.f : 0.f;
+            }
+            f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+            float upart[2] = {0.f, 0.f};
+            if (isH) {
+                for (int s0 = 0; s0 < ks; s0 += 8) {
+                    float av[2][8], bv[2][8];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int kk = 4 * (s0 + u) + kq;            // < Kp4 <= ldk: zero padded, no predicate needed
+                            av[q][u] = sF[rowA[q] + kk] * okA[q];
+                            bv[q][u] = sF[rowB[q] + kk] * okB[q];
+                        }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u], bv[0][u], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][u], bv[1][u], acc[1], 0, 0, 0);
+                    }
+                }
+            } else {
+                // weight fragments: always-valid clamped addresses (rows >= K meet zero-padded F, columns >= wc are
+                // never stored), so the loads carry no predicate and no branch
+                float wnext[2][8];
+                int wcol[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { const int n = 16 * tj[q] + l15; wcol[q] = n < wcn[q] ? n : wcn[q] - 1; }
+                auto load_w = [&](int q, int s0, float* dst) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        int kk = 4 * (s0 + u) + kq;
+                        kk = kk < K ? kk : K - 1;
+                        dst[u] = Wp[q][kk * wcn[q] + wcol[q]];
+                    }
+                };
+                load_w(0, 0, wnext[0]);
+                load_w(1, 0, wnext[1]);
+                for (int s0 = 0; s0 < ks; s0 += 8) {
+                    float av[2][8], wcur[2][8];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) wcur[q][u] = wnext[q][u];
+                    if (s0 + 8 < ks) { load_w(0, s0 + 8, wnext[0]); load_w(1, s0 + 8, wnext[1]); }   // next batch: in flight during the MFMAs
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int kk = 4 * (s0 + u) + kq;
+                            const float f = sF[rowA[q] + kk] * okA[q];
+                            const float frk = (float)sFrb[kk];
+                            if (GEN1) {   // general mlp_value: rank2' element-wise on the fly (hodge_attention.py:322-323)
+                                if (usefr[q] != 0.f) {
+                                    const int r = 16 * ti[q] + l15, e = r < E ? r : E - 1;
+                                    float iin[CCSD_SMALLW], out[CCSD_SMALLW];
+#pragma unroll
+                                    for (int c = 0; c < CCSD_SMALLW; ++c) iin[c] = c < h0.cin ? sAco[c * E + e] * f : 0.f;
+                                    small_mlp<CCSD_SMALLW>(h0.mval, w, iin, out);
+                                    av[q][u] = sFl[e] * out[0] * frk * okA[q];
+                                } else av[q][u] = f;
+                            } else {
+                                av[q][u] = f * fmaf(usefr[q], frk - 1.0f, 1.0f);     // f * frk for P_1, f for P_0
+                            }
+                            upart[q] = fmaf(frk * usefr[q], wcur[q][u], upart[q]);
+                        }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u], wcur[0][u], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][u], wcur[1][u], acc[1], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float un = upart[q];                       // fr . Wcat_1 column: reduce the four k residue classes
+                un += __shfl_xor(un, 16, 64);
+                un += __shfl_xor(un, 32, 64);
+                if (!live[q]) continue;
+                const int n = 16 * tj[q] + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * ti[q] + 4 * kq + r;
+                    const float v = acc[q][r];
+                    if (m >= E) continue;
+                    if (isH) {
+                        if (n < E) {
+                            const float hv = (p.f_hmask && m == n) ? 0.f : v;   // hodge_mask zeroes the diagonal (cc_utils.py:964-969)
+                            sH[m * ldh + n] = hv;
+                            sH[n * ldh + m] = hv;
+                        }
+                    } else if (usefr[q] == 0.f) {
+                        if (n < wc0) ra.P0[((size_t)b * E + m) * wc0 + n] = v;
+                    } else if (n < wc1) {
+                        // rank2'[e,k] = fl[e] fr[k] (s[e] F[e,k] + b)  ->  P_1[e,:] = fl[e] (s[e] ((F.fr) W_1)[e,:] + b (fr W_1))
+                        ra.P1[((size_t)b * E + m) * wc1 + n] = GEN1 ? v : sFl[m] * fmaf(sRow[m], v, w[h0.mval.b[0]] * un);
+                    }
+                }
             }
         }
     }
+#endif
     __syncthreads();
 
-    // ---- phase 2: (H F) per 16-column tile, ScoreNetworkF element-wise, epilogue in place
+    // ---- phase 2: (H F) per 16-column tile, ScoreNetworkF element-wise, epilogue in place in LDS.
+    // H's A-fragments live in registers for the whole phase.
+    stamp(ra.dbg, 3);
     float s_net = 0.f, s_z = 0.f;
     const int ntn = (K + 15) >> 4, ksE = Ep4 >> 2;
-    for (int tn = wave; tn < ntn; tn += nw) {
-        {
-            wave_coltile(tn * 16, mt, p.f_cnum == 2 ? ksE : 0,
-                      [&](int m, int k) { return (k < E) ? sH[(m < E ? m : E - 1) * ldh + k] : 0.f; },
-                      [&](int k, int n) { return (k < E && n < K) ? sF[k * ldk + n] : 0.f; },
-                      [&](int e0, int k, const float* hf) {
-                          if (e0 >= E || k >= K) return;
-                          float z[4] = {0.f, 0.f, 0.f, 0.f};
-                          if (ep.mode != MODE_SCORE) raw_noise_r4(na, b, e0 >> 2, k, E, K, z);   // one Philox group = 4 edge rows
-                          const float fr = sFr[k];
+    auto epi4 = [&](int e0, int k, const float* hf) {
+        if (e0 >= E || k >= K) return;
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ep.mode != MODE_SCORE) raw_noise_r4(na, b, e0 >> 2, k, E, K, z);   // one Philox group = 4 edge rows
+        const float fr = (float)sFrb[k];
 #pragma unroll
-                          for (int r = 0; r < 4; ++r) {
-                              const int e = e0 + r;
-                              if (e >= E) continue;
-                              const float f = sF[e * ldk + k];
-                              const float m = sFl[e] * fr;                         // flags_left * flags_right, cc_utils.py:590
-                              const float net = fnet_element(p, w, f, hf[r], m);
-                              if (ep.mode == MODE_SCORE) {
-                                  sF[e * ldk + k] = ep.sscale * net;
-                              } else {
-                                  const float zz = z[r] * m;                       // gen_noise_rank2, cc_utils.py:613-615
-                                  if (ep.mode == MODE_NORMS) {
-                                      sF[e * ldk + k] = net;
-                                      s_net = fmaf(net, net, s_net);
-                                      s_z = fmaf(zz, zz, s_z);
-                                  } else {
-                                      const float mean = fmaf(ep.pa, f, ep.pb * net);
-                                      if (ep.mean) ep.mean[((size_t)b * E + e) * K + k] = mean;
-                                      sF[e * ldk + k] = fmaf(ep.pc, zz, mean);
-                                  }
-                              }
-                          }
-                      });
+        for (int r = 0; r < 4; ++r) {
+            const int e = e0 + r;
+            if (e >= E) continue;
+            const float f = sF[e * ldk + k];
+            const float m = sFl[e] * fr;                         // flags_left * flags_right, cc_utils.py:590
+            const float net = fnet_element<AFFINE>(p, w, f, hf[r], m);
+            if (ep.mode == MODE_SCORE) {
+                sF[e * ldk + k] = ep.sscale * net;
+            } else {
+                const float zz = z[r] * m;                       // gen_noise_rank2, cc_utils.py:613-615
+                if (ep.mode == MODE_NORMS) {
+                    sF[e * ldk + k] = net;
+                    s_net = fmaf(net, net, s_net);
+                    s_z = fmaf(zz, zz, s_z);
+                } else {
+                    const float mean = fmaf(ep.pa, f, ep.pb * net);
+                    if (ep.mean) ep.mean[((size_t)b * E + e) * K + k] = mean;
+                    sF[e * ldk + k] = fmaf(ep.pc, zz, mean);
+                }
+            }
+        }
+    };
+#ifdef CCSD_EMU
+    for (int tn = 0; tn < ntn; ++tn) {
+        float hfv[64][16];
+        for (int e = 0; e < E; ++e)
+            for (int j = 0; j < 16; ++j) {
+                const int k = 16 * tn + j;
+                float acc = 0.f;
+                if (p.f_cnum == 2 && k < K)
+                    for (int e2 = 0; e2 < E; ++e2) acc = fmaf(sH[e * ldh + e2], sF[e2 * ldk + k], acc);
+                hfv[e][j] = acc;
+            }
+        for (int e0 = 0; e0 < E; e0 += 4)
+            for (int j = 0; j < 16; ++j) {
+                const float v[4] = {hfv[e0][j], e0 + 1 < E ? hfv[e0 + 1][j] : 0.f, e0 + 2 < E ? hfv[e0 + 2][j] : 0.f, e0 + 3 < E ? hfv[e0 + 3][j] : 0.f};
+                epi4(e0, 16 * tn + j, v);
+            }
+    }
+#else
+    {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const int wave = tid >> 6, nw = nth >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+        constexpr int KSE = 4 * MT;                        // ceil(16*MT / 4) k-steps cover E <= 16*MT
+        float hA[MT][KSE];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int s0 = 0; s0 < KSE; ++s0) {
+                const int r = 16 * i + l15, c = 4 * s0 + kq;
+                const float v = sH[(r < E ? r : E - 1) * ldh + (c < E ? c : E - 1)];
+                hA[i][s0] = (r < E && c < E) ? v : 0.f;
+            }
+        for (int tn = wave; tn < ntn; tn += nw) {
+            const int n = 16 * tn + l15;
+            const bool nin = n < K;
+            f32x4 acc[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p.f_cnum == 2) {
+                float bv[KSE];
+#pragma unroll
+                for (int s0 = 0; s0 < KSE; ++s0) {
+                    const int kk = 4 * s0 + kq;
+                    const float v = sF[(kk < E ? kk : E - 1) * ldk + (nin ? n : K - 1)];
+                    bv[s0] = (kk < E && nin) ? v : 0.f;
+                }
+#pragma unroll
+                for (int s0 = 0; s0 < KSE; ++s0)
+                    if (s0 < ksE) {
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(hA[i][s0], bv[s0], acc[i], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const float v[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+                epi4(16 * i + 4 * kq, n, v);
+            }
         }
     }
+#endif
     __syncthreads();
     // ---- phase 3
+    stamp(ra.dbg, 4);
     float* og = ep.out + (size_t)b * E * K;
-    for (int t = tid; t < E * K; t += nth) {
-        int e, k;
-        dK.divmod(t, e, k);
-        og[t] = sF[e * ldk + k];
+    if (((E * K) & 3) == 0) {
+        float4* O4 = reinterpret_cast<float4*>(og);
+        const int n4 = (E * K) >> 2;
+        for (int i4 = tid; i4 < n4; i4 += nth) {
+            int e, k;
+            dK.divmod(4 * i4, e, k);
+            float vv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                vv[q] = sF[e * ldk + k];
+                if (++k == K) { k = 0; ++e; }
+            }
+            O4[i4] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        }
+    } else {
+        for (int t = tid; t < E * K; t += nth) {
+            int e, k;
+            dK.divmod(t, e, k);
+            og[t] = sF[e * ldk + k];
+        }
     }
     if (ep.mode == MODE_NORMS) {
         const float tn_ = block_sum(s_net, sRed);
         const float tz_ = block_sum(s_z, sRed);
         if (tid == 0) { ep.part[(size_t)b * 2 + 0] = tn_; ep.part[(size_t)b * 2 + 1] = tz_; }
     }
+    stamp(ra.dbg, 5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -891,6 +1127,7 @@ struct XaArgs {
     float* out_x; float* out_a;           // SCORE: scores; NORMS: raw nets; PRED: new state
     float* mean_x; float* mean_a;         // PRED, nullable
     float* norm2;                         // NORMS: [B][4] = |net_x|^2, |net_adj|^2, |z_x|^2, |z_adj|^2
+    long long* dbg;
 };
 
 // clamp(rowsum(A with unit diagonal), 1)^-1/2 for `nc` channels   (DenseGCNConv, layers.py:139-145)
@@ -921,6 +1158,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
     float* s_R = sm + p.o_c0;            // shared region: GCN scratch | MLP hidden activations | dense hodge layer
     const FastDiv dN(N), dNN(NN), dF(F), dE(E > 0 ? E : 1);
 
+    stamp(xa.dbg, 0);
     for (int i = tid; i < N; i += nth) s_flags[i] = xa.flags[(size_t)b * N + i];
     float nx_net = 0.f, nx_z = 0.f, na_net = 0.f, na_z = 0.f;
 
@@ -947,6 +1185,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
                 int j, o;
                 dH.divmod(t, j, o);
                 float acc = 0.f;
+#pragma unroll 4
                 for (int k = 0; k < fin; ++k) acc = fmaf(src[k * ldn + j], W[k * H + o], acc);
                 s_xw[t] = acc * s_dinv[j];
             }
@@ -992,6 +1231,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
         __syncthreads();
     }
 
+    stamp(xa.dbg, 1);
     // ================= ScoreNetworkA / ScoreNetworkA_CC =================
     if (xa.do_a) {
         float* s_chan = sm + p.o_chan;
@@ -1020,6 +1260,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
         }
         // ---- AttentionLayer stack (attention.py:270-304); channels are processed `cg` at a time
         for (int l = 0; l < p.a_L; ++l) {
+            if (l < 3) stamp(xa.dbg, 2 + 3 * l);
             const AttnLayerD& L = p.al[l];
             const int cols = 2 * L.adim + L.fout;
             const FastDiv dcols(cols), dNcols(N * cols);
@@ -1043,6 +1284,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
                     else if (col < 2 * L.adim) { W = wb + L.fin * L.adim + L.adim; o = col - L.adim; ow = L.adim; }
                     else { W = wb + 2 * (L.fin * L.adim + L.adim); o = col - 2 * L.adim; ow = L.fout; }
                     float acc = 0.f;
+#pragma unroll 4
                     for (int k = 0; k < L.fin; ++k) acc = fmaf(s_xcur[k * ldn + j], W[k * ow + o], acc);
                     s_xw[t] = acc * s_dinv[c * N + j];
                 }
@@ -1055,6 +1297,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
                     const float* arow = ac + c * NN + i * N;
                     const float* xc = s_xw + c * N * cols + col;
                     float acc = 0.f;
+#pragma unroll 4
                     for (int j = 0; j < N; ++j) acc = fmaf((i == j) ? 1.f : arow[j], xc[j * cols], acc);
                     const float bb = col < L.adim ? wb[L.fin * L.adim + col]
                                    : col < 2 * L.adim ? wb[2 * L.fin * L.adim + L.adim + (col - L.adim)]
@@ -1084,6 +1327,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
                     for (int c = 0; c < gc; ++c) {
                         const float* w0 = w + L.mc.w[0] + hh * L.mc.in + (c0 + c) * L.fout;
                         const float* v = s_qkv + c * N * cols + i * cols + 2 * L.adim;
+#pragma unroll 4
                         for (int o = 0; o < L.fout; ++o) acc = fmaf(v[o], w0[o], acc);
                     }
                     s_mch[hh * ldn + i] = acc;
@@ -1101,6 +1345,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
             }
             // node update: tanh(mask_x(multi_channel(cat V_c)))  (attention.py:292-293); the first Linear of the
             // edge MLP (input [attention_c | adj_c] per (i,j), attention.py:295-300) shares the barrier interval
+            if (l < 3) stamp(xa.dbg, 3 + 3 * l);
             float* chan_out = s_chan + L.co0 * NN;
             const float* adj_in = s_chan + L.ci0 * NN;
             const int pc = p.pchp, ldpp = p.ldpp;
@@ -1122,6 +1367,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
                     cur = y; cur2 = y; ldc = ldy; ksp = mlp_out(L.mlp, i);
                 }
             }
+            if (l < 3) stamp(xa.dbg, 4 + 3 * l);
             // _adj + _adj^T, then mask_adjs (attention.py:301-302), in place per unordered pair; node tanh/mask
             for (int t = tid; t < L.cout * NN; t += nth) {
                 int o, ij, i, j;
@@ -1142,6 +1388,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
             float* t3 = s_xcur; s_xcur = s_xnext; s_xnext = t3;
         }
 
+        stamp(xa.dbg, 12);
         // ---- hodge branch of ScoreNetworkA_CC (ScoreNetwork_A_CC.py:295-316)
         if (p.h_L > 0) {
             float* s_hd = sm + p.o_hd;          // [hodge channel][E]: diagonals that reach the final MLP
@@ -1260,6 +1507,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
                     const float* dg = s_deg + c * E;
                     const float* pc1 = P1b + c * qw1 + d;
                     float acc = 0.f;
+#pragma unroll 4
                     for (int e2 = 0; e2 < E; ++e2) acc = fmaf(dg[e] * Hr[e2] * dg[e2], pc1[(size_t)e2 * h1.wc], acc);
                     s_hq[t] = acc + w[h1.bcat + c * qw1 + d];
                 }
@@ -1304,6 +1552,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
             __syncthreads();
         }
 
+        stamp(xa.dbg, 13);
         // ---- final MLP over every (i,j) on [graph channels | hodge channels]  (ScoreNetwork_A_CC.py:318-331)
         const MlpD& m = p.a_fin;
         const int fc = p.pch, ldf = p.ldp;
@@ -1342,6 +1591,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
             __syncthreads();
         }
     }
+    stamp(xa.dbg, 14);
     if (xa.mode == MODE_NORMS) {
         __syncthreads();
         const float t0 = block_sum(nx_net, s_red), t1 = block_sum(na_net, s_red);

@@ -27,6 +27,8 @@ struct dim3 {
     unsigned x, y, z;
     dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
 };
+struct float4 { float x, y, z, w; };
+static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
 static dim3 threadIdx(0, 0, 0), blockIdx(0, 0, 0), blockDim(1, 1, 1), gridDim(1, 1, 1);
 static inline void __syncthreads() {}
 static float* emu_smem = nullptr;
@@ -57,7 +59,7 @@ static inline void emu_launch(dim3 grid, size_t smem, F body) {
                 body();
             }
 }
-#define CCSD_LAUNCH(kern, grid, block, smem, stream, ...) emu_launch(grid, smem, [&] { kern(__VA_ARGS__); })
+#define CCSD_LAUNCH(kern, grid, block, smem, stream, ...) emu_launch(grid, smem, [&] { (kern)(__VA_ARGS__); })
 #define CCSD_NTHREADS 1
 #else
 #include <hip/hip_runtime.h>

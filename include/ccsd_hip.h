@@ -166,6 +166,9 @@ int ccsd_quantize(const float* in_dev, int64_t n, float thr, int64_t* out_dev, v
  * kernel_id: 0 k_xa, 1 k_gemm_p, 2 k_hf_score, 3 k_gemm_h, 4 k_langevin_apply; -1 disables.
  * ccsd_profile_read synchronises on the recorded events and returns launches + summed milliseconds. */
 int ccsd_profile_kernel(ccsd_plan_t* plan, int32_t kernel_id);
+/* Diagnostic: when dev_buffer (B x 32 int64, device) is non-NULL, thread 0 of every workgroup of k_r2 (slots 0-15)
+ * and k_xa (slots 16-31, offset by 16) stores the shader clock at its phase boundaries.  NULL disables. */
+int ccsd_debug_stamps(ccsd_plan_t* plan, void* dev_buffer);
 int ccsd_profile_read(ccsd_plan_t* plan, int64_t* launches, double* total_ms);
 
 #ifdef __cplusplus

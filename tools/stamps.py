@@ -1,0 +1,40 @@
+"""Diagnostic: per-phase shader-clock stamps of k_r2 / k_xa on the qm9_CC workload (run on the GPU box)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, numpy as np, ctypes as C
+import bench
+from ccsd_amd import loader
+from ccsd_amd.engine import PCEngine
+
+meta, parts = bench.load_qm9()
+cfg = meta["config"]
+sdes = [loader.load_sde(cfg["sde"][p]) for p in ("x", "adj", "rank2")]
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+eng = PCEngine(meta["params_x"], parts["x"], meta["params_adj"], parts["adj"], meta["params_rank2"], parts["rank2"],
+               N=9, F=4, is_cc=True, d_min=3, d_max=9, sdes=sdes, predictor="Reverse", corrector="Langevin", snr=0.2,
+               scale_eps=0.7, n_steps=1, denoise=True, eps=1e-4, device="cuda:0")
+flags = bench.qm9_flags(B).cuda()
+st, sc, rs = eng.alloc_state(B), eng.alloc_state(B), eng.alloc_state(B)
+eng.init_state(flags, st, None, 1, 0)
+eng.run(flags, st, sc, rs, 1, 0, 0, 3)
+dbg = torch.zeros(B, 32, dtype=torch.int64, device="cuda")
+eng.lib.check(eng.lib.ccsd_debug_stamps(eng.handle, C.c_void_p(dbg.data_ptr())))
+eng.predictor(5, st, flags, None, 1, 0, sc, None)
+torch.cuda.synchronize()
+d = dbg.cpu().numpy()
+names_r2 = ["load", "prep(masks,acoef,u)", "->phase1", "gemm tiles (H,P)", "HF+epilogue", "store"]
+print("k_r2 per-phase cycles (median over workgroups), total", np.median(d[:, 5] - d[:, 0]))
+for i in range(5):
+    print(f"  {names_r2[i]:24s} {np.median(d[:, i + 1] - d[:, i]):10.0f}")
+x = d[:, 16:]
+lab = {0: "start", 1: "X-net done", 2: "L0 start", 3: "L0 gcn/att done", 4: "L0 edge MLP done", 5: "L1 start", 6: "L1 gcn/att done",
+       7: "L1 edge MLP done", 8: "L2 start", 9: "L2 gcn/att done", 10: "L2 edge MLP done", 12: "hodge start", 13: "final MLP start", 14: "end"}
+print("k_xa total", np.median(x[:, 14] - x[:, 0]))
+prev = 0
+for k in sorted(lab):
+    if k == 0:
+        continue
+    print(f"  {lab[prev]:18s} -> {lab[k]:18s} {np.median(x[:, k] - x[:, prev]):10.0f}")
+    prev = k
+span = (d[:, 5].max() - d[:, 0].min())
+print("k_r2 first-start to last-end cycles:", span, " k_xa:", x[:, 14].max() - x[:, 0].min())
