@@ -231,20 +231,20 @@ CCSD_DEV void block_linear(float* Y, int ldy, const float* X, int ldx, const flo
         const int am = (m0 + l15 < rows) ? m0 + l15 : rows - 1;      // clamp: rows beyond `rows` are never stored
         const float* wr = W + (size_t)(bn < out ? bn : 0) * in;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int s0 = 0; s0 < ks; s0 += 4) {   // weights come from L2: issue the loads of four k-steps before the MFMAs
-            float a[4], bv[4];
+        const float nok = bn < out ? 1.f : 0.f;
+        for (int s0 = 0; s0 < ks; s0 += 4) {   // weights come from L2: issue the loads of four k-steps before the MFMAs.
+            float a[4], bv[4];                 // Loads are unconditional (clamped addresses); out-of-range lanes get a zero weight.
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int k = 4 * (s0 + u) + kq;
-                const bool kin = k < in;
-                const int kc = kin ? k : 0;
-                const float* xp = kc < ksplit ? X + kc * ldx : X2 + (kc - ksplit) * ldx;
-                a[u] = kin ? xp[am] : 0.f;
-                bv[u] = (kin && bn < out) ? wr[kc] : 0.f;
+                const int kc = k < in ? k : in - 1;
+                const int off = kc < ksplit ? kc * ldx : (kc - ksplit) * ldx;
+                const float* xb = kc < ksplit ? X : X2;
+                a[u] = xb[off + am];
+                bv[u] = wr[kc] * (k < in ? nok : 0.f);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (s0 + u < ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bv[u], acc, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bv[u], acc, 0, 0, 0);
         }
         if (bn < out) {
             const float bb = bias[bn];
