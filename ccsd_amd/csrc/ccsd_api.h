@@ -183,7 +183,8 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
         }
     }
 #ifndef CCSD_EMU
-    if ((size_t)pl->h.xa_lds_floats * 4 > 64 * 1024) PC(rt_set_max_dyn_smem((const void*)k_xa, (size_t)pl->h.xa_lds_floats * 4));
+    if ((size_t)pl->h.xa_lds_floats * 4 > 64 * 1024)
+        PC(rt_set_max_dyn_smem(pl->h.wst_floats > 0 ? (const void*)k_xa<true> : (const void*)k_xa<false>, (size_t)pl->h.xa_lds_floats * 4));
     if (pl->fused_r2 && pl->r2_lds > 64 * 1024) {
         const int MT = (E + 15) / 16;
         const bool aff = pl->h.f_affine != 0, gen1 = pl->h.h_L > 1 && pl->h.hl[0].mval.n > 1;
@@ -298,8 +299,12 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
 static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Workspace& w, void* stream) {
     xa.P0 = w.P0; xa.P1 = w.P1; xa.dbg = pl->dbg ? pl->dbg + 16 : nullptr;
     prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
-    CCSD_LAUNCH(k_xa, dim3(B), dim3(CCSD_NTHREADS == 1 ? 1 : 512), (size_t)pl->h.xa_lds_floats * 4, stream, (const PlanD*)pl->d,
-                (const float*)pl->w, (const unsigned char*)pl->edges, xa, na);
+    if (pl->h.wst_floats > 0)
+        CCSD_LAUNCH(k_xa<true>, dim3(B), dim3(CCSD_NTHREADS == 1 ? 1 : 512), (size_t)pl->h.xa_lds_floats * 4, stream,
+                    (const PlanD*)pl->d, (const float*)pl->w, (const unsigned char*)pl->edges, xa, na);
+    else
+        CCSD_LAUNCH(k_xa<false>, dim3(B), dim3(CCSD_NTHREADS == 1 ? 1 : 512), (size_t)pl->h.xa_lds_floats * 4, stream,
+                    (const PlanD*)pl->d, (const float*)pl->w, (const unsigned char*)pl->edges, xa, na);
     prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
     LAUNCH_CHECK();
     return CCSD_OK;

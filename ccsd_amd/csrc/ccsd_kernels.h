@@ -1143,6 +1143,9 @@ CCSD_DEV void gcn_dinv(const float* a, float* dinv, int nc, int N) {
     }
 }
 
+// STAGE: every section's weights (X-network, each AttentionLayer, final MLP: contiguous blob ranges) are copied
+// into LDS once and read from there; otherwise they are read from L2 in place.
+template <bool STAGE>
 __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, const float* __restrict__ w,
                                             const unsigned char* __restrict__ edges, XaArgs xa, NoiseArgs na) {
     CCSD_DYN_SMEM(sm);
@@ -1157,6 +1160,13 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
     float* s_red = sm + p.o_red;
     float* s_R = sm + p.o_c0;            // shared region: GCN scratch | MLP hidden activations | dense hodge layer
     const FastDiv dN(N), dNN(NN), dF(F), dE(E > 0 ? E : 1);
+    float* s_wst = sm + p.o_wst;
+    // copy blob range [lo, hi) into LDS and return a pointer that is indexed with the ORIGINAL blob offsets
+    auto stage_w = [&](int lo, int hi) -> const float* {
+        if (!STAGE) return w;
+        for (int t = tid; t < hi - lo; t += nth) s_wst[t] = w[lo + t];
+        return s_wst - lo;
+    };
 
     stamp(xa.dbg, 0);
     for (int i = tid; i < N; i += nth) s_flags[i] = xa.flags[(size_t)b * N + i];
@@ -1168,6 +1178,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
         float* s_h1 = sm + p.o_h1;
         float* s_h2 = sm + p.o_h2;
         float* s_xw = s_R;
+        const float* wx = stage_w(p.x_wlo, p.x_whi);   // visible after the barrier below
         for (int i = tid; i < N * F; i += nth) s_x[i] = xa.xX[(size_t)b * N * F + i];
         for (int i = tid; i < NN; i += nth) s_adj[i] = xa.adjX[(size_t)b * NN + i];
         __syncthreads();
@@ -1179,8 +1190,8 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
         for (int l = 0; l < p.x_depth; ++l) {
             const int fin = l ? H : F;
             const float* src = s_xcat + (l ? (F + (l - 1) * H) : 0) * ldn;
-            const float* W = w + p.x_gw[l];
-            const float* B = w + p.x_gb[l];
+            const float* W = wx + p.x_gw[l];
+            const float* B = wx + p.x_gb[l];
             for (int t = tid; t < N * H; t += nth) {  // d_j * (x @ W)[j]
                 int j, o;
                 dH.divmod(t, j, o);
@@ -1201,11 +1212,11 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
             __syncthreads();
         }
         const MlpD& m = p.x_fin;
-        block_linear<1>(s_h1, ldn, s_xcat, ldn, s_xcat, m.in, w + m.w[0], w + m.b[0], m.in, m.hid, N);
+        block_linear<1>(s_h1, ldn, s_xcat, ldn, s_xcat, m.in, wx + m.w[0], wx + m.b[0], m.in, m.hid, N);
         __syncthreads();
-        block_linear<1>(s_h2, ldn, s_h1, ldn, s_h1, m.hid, w + m.w[1], w + m.b[1], m.hid, m.hid, N);
+        block_linear<1>(s_h2, ldn, s_h1, ldn, s_h1, m.hid, wx + m.w[1], wx + m.b[1], m.hid, m.hid, N);
         __syncthreads();
-        block_linear<0>(s_h1, ldn, s_h2, ldn, s_h2, m.hid, w + m.w[2], w + m.b[2], m.hid, m.out, N);
+        block_linear<0>(s_h1, ldn, s_h2, ldn, s_h2, m.hid, wx + m.w[2], wx + m.b[2], m.hid, m.out, N);
         __syncthreads();
         for (int t = tid; t < N * F; t += nth) {
             int i, f;
@@ -1265,8 +1276,10 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
             const int cols = 2 * L.adim + L.fout;
             const FastDiv dcols(cols), dNcols(N * cols);
             const float inv_scale = (float)sqrt((double)L.fout);  // attention.py:121: / math.sqrt(out_dim)
+            const float* wl = stage_w(L.w_lo, L.w_hi);
+            if (STAGE) __syncthreads();
             // multi_channel MLP, first Linear: its input is cat_c V_c, accumulated group by group
-            for (int t = tid; t < L.mc.hid * N; t += nth) { int hh, i; dN.divmod(t, hh, i); s_mch[hh * ldn + i] = w[L.mc.b[0] + hh]; }
+            for (int t = tid; t < L.mc.hid * N; t += nth) { int hh, i; dN.divmod(t, hh, i); s_mch[hh * ldn + i] = wl[L.mc.b[0] + hh]; }
             for (int c0 = 0; c0 < L.cin; c0 += p.cg) {
                 const int gc = (L.cin - c0) < p.cg ? (L.cin - c0) : p.cg;
                 float* s_xw = s_R;
@@ -1278,7 +1291,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
                     int c, r, j, col;
                     dNcols.divmod(t, c, r);
                     dcols.divmod(r, j, col);
-                    const float* wb = w + L.attn_base + (c0 + c) * L.attn_stride;
+                    const float* wb = wl + L.attn_base + (c0 + c) * L.attn_stride;
                     const float* W; int o, ow;
                     if (col < L.adim) { W = wb; o = col; ow = L.adim; }
                     else if (col < 2 * L.adim) { W = wb + L.fin * L.adim + L.adim; o = col - L.adim; ow = L.adim; }
@@ -1293,7 +1306,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
                     int c, r, i, col;
                     dNcols.divmod(t, c, r);
                     dcols.divmod(r, i, col);
-                    const float* wb = w + L.attn_base + (c0 + c) * L.attn_stride;
+                    const float* wb = wl + L.attn_base + (c0 + c) * L.attn_stride;
                     const float* arow = ac + c * NN + i * N;
                     const float* xc = s_xw + c * N * cols + col;
                     float acc = 0.f;
@@ -1325,7 +1338,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
                     dN.divmod(t, hh, i);
                     float acc = s_mch[hh * ldn + i];
                     for (int c = 0; c < gc; ++c) {
-                        const float* w0 = w + L.mc.w[0] + hh * L.mc.in + (c0 + c) * L.fout;
+                        const float* w0 = wl + L.mc.w[0] + hh * L.mc.in + (c0 + c) * L.fout;
                         const float* v = s_qkv + c * N * cols + i * cols + 2 * L.adim;
 #pragma unroll 4
                         for (int o = 0; o < L.fout; ++o) acc = fmaf(v[o], w0[o], acc);
@@ -1359,10 +1372,10 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
                     const bool last = i == L.mlp.n - 1;
                     float* y = last ? chan_out + p0 : bufs[i & 1];
                     const int ldy = last ? NN : ldpp;
-                    if (!last) block_linear<1>(y, ldy, cur, ldc, cur2, ksp, w + L.mlp.w[i], w + L.mlp.b[i], mlp_in(L.mlp, i), mlp_out(L.mlp, i), rows);
-                    else block_linear<0>(y, ldy, cur, ldc, cur2, ksp, w + L.mlp.w[i], w + L.mlp.b[i], mlp_in(L.mlp, i), mlp_out(L.mlp, i), rows);
+                    if (!last) block_linear<1>(y, ldy, cur, ldc, cur2, ksp, wl + L.mlp.w[i], wl + L.mlp.b[i], mlp_in(L.mlp, i), mlp_out(L.mlp, i), rows);
+                    else block_linear<0>(y, ldy, cur, ldc, cur2, ksp, wl + L.mlp.w[i], wl + L.mlp.b[i], mlp_in(L.mlp, i), mlp_out(L.mlp, i), rows);
                     if (p0 == 0 && i == 0)
-                        block_linear<0>(s_xnext, ldn, s_mch, ldn, s_mch, L.mc.hid, w + L.mc.w[1], w + L.mc.b[1], L.mc.hid, L.mc.out, N);
+                        block_linear<0>(s_xnext, ldn, s_mch, ldn, s_mch, L.mc.hid, wl + L.mc.w[1], wl + L.mc.b[1], L.mc.hid, L.mc.out, N);
                     __syncthreads();
                     cur = y; cur2 = y; ldc = ldy; ksp = mlp_out(L.mlp, i);
                 }
@@ -1555,16 +1568,18 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
         stamp(xa.dbg, 13);
         // ---- final MLP over every (i,j) on [graph channels | hodge channels]  (ScoreNetwork_A_CC.py:318-331)
         const MlpD& m = p.a_fin;
+        const float* wf = stage_w(m.w[0], m.b[2] + 1);
+        if (STAGE) __syncthreads();
         const int fc = p.pch, ldf = p.ldp;
         float* f0 = s_R;
         float* f1 = s_R + m.hid * ldf;
         for (int p0 = 0; p0 < NN; p0 += fc) {
             const int rows = (NN - p0) < fc ? (NN - p0) : fc;
-            block_linear<1>(f0, ldf, s_chan + p0, NN, s_chan + p0, m.in, w + m.w[0], w + m.b[0], m.in, m.hid, rows);
+            block_linear<1>(f0, ldf, s_chan + p0, NN, s_chan + p0, m.in, wf + m.w[0], wf + m.b[0], m.in, m.hid, rows);
             __syncthreads();
-            block_linear<1>(f1, ldf, f0, ldf, f0, m.hid, w + m.w[1], w + m.b[1], m.hid, m.hid, rows);
+            block_linear<1>(f1, ldf, f0, ldf, f0, m.hid, wf + m.w[1], wf + m.b[1], m.hid, m.hid, rows);
             __syncthreads();
-            block_linear<0>(f0, ldf, f1, ldf, f1, m.hid, w + m.w[2], w + m.b[2], m.hid, 1, rows);
+            block_linear<0>(f0, ldf, f1, ldf, f1, m.hid, wf + m.w[2], wf + m.b[2], m.hid, 1, rows);
             __syncthreads();
             for (int r = tid; r < rows; r += nth) {
                 const int ij = p0 + r;

@@ -25,6 +25,7 @@ struct AttnLayerD {
     int cin, cout, fin, adim, fout, dsplit, nchunk;
     int ci0, co0;             // first input / output channel inside the channel stack
     int attn_base, attn_stride;  // per-channel block: Wq[fin][ad] bq Wk bk Wv[fin][fo] bv
+    int w_lo, w_hi;              // blob range of this layer's weights (attention blocks, mlp, multi_channel)
     MlpD mlp, mc;
 };
 struct HodgeLayerD {
@@ -37,7 +38,7 @@ struct PlanD {
     int N, F, E, K, is_cc;
     float snr, seps;
     // ScoreNetworkX
-    int x_depth, x_nhid, x_fdim;
+    int x_depth, x_nhid, x_fdim, x_wlo, x_whi;
     int x_gw[CCSD_MAXL], x_gb[CCSD_MAXL];
     MlpD x_fin;
     // ScoreNetworkA(_CC)
@@ -57,10 +58,12 @@ struct PlanD {
     int o_flags, o_x, o_adj, o_an, o_xw, o_qkv, o_tmp, o_xcat, o_h1, o_h2, o_chan, o_att, o_xcur, o_xnext,
         o_vcat, o_c0, o_c1, o_acoef, o_hq, o_hatt, o_h1m, o_hd, o_red;
     int xa_lds_floats;
+    int o_wst, wst_floats;      // weight staging buffer (0 floats: weights are read in place)
 };
 
 #ifndef CCSD_DEVICE_ONLY
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -128,7 +131,9 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
         p->x_gw[l] = pb.take((int64_t)(l ? c->x_nhid : F) * c->x_nhid);
         p->x_gb[l] = pb.take(c->x_nhid);
     }
+    p->x_wlo = p->x_gw[0];
     p->x_fin = pb.mlp(3, p->x_fdim, 2 * p->x_fdim, F);
+    p->x_whi = pb.cur;
     // ---- ScoreNetworkA graph branch
     if (c->a_num_layers < 1 || c->a_num_layers > CCSD_MAXL) { pb.fail(CCSD_ERR_UNSUPPORTED, "a_num_layers out of range"); return 0; }
     if (c->a_num_heads < 1 || c->a_c_init < 1) { pb.fail(CCSD_ERR_INVALID, "bad heads/c_init"); return 0; }
@@ -148,9 +153,11 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
         a.ci0 = ch - a.cin; a.co0 = ch; ch += a.cout;
         a.attn_stride = 2 * (a.fin * a.adim + a.adim) + a.fin * a.fout + a.fout;
         a.attn_base = pb.take((int64_t)a.cin * a.attn_stride);
+        a.w_lo = a.attn_base;
         const int hid = 2 * (a.cin > a.cout ? a.cin : a.cout);
         a.mlp = pb.mlp(c->a_num_linears, 2 * a.cin, hid, a.cout);
         a.mc = pb.mlp(2, a.cin * a.fout, hid, a.fout);
+        a.w_hi = pb.cur;
     }
     p->a_nch_graph = ch;
     int fdim = c->a_c_hid * (p->a_L - 1) + c->a_c_final + c->a_c_init;
@@ -232,11 +239,21 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
         if (p->h_L > 1) h1m_floats = p->hl[0].cout * E * E;
         if (E > NN) { pb.fail(CCSD_ERR_UNSUPPORTED, "E > N*N"); return 0; }
     }
-    // Two passes: aim for <= 64 KB per workgroup (2-3 workgroups per CU); if the network does not fit, use
-    // up to 152 KB (one workgroup per CU).  Within a budget take the largest channel group / chunk sizes.
+    // weight staging: largest section (X-network, one AttentionLayer, final MLP); only when it is small
+    int wst = p->x_whi - p->x_wlo;
+    for (int l = 0; l < p->a_L; ++l) if (p->al[l].w_hi - p->al[l].w_lo > wst) wst = p->al[l].w_hi - p->al[l].w_lo;
+    if (p->a_fin.b[2] + 1 - p->a_fin.w[0] > wst) wst = p->a_fin.b[2] + 1 - p->a_fin.w[0];
+    if (wst > 8192 || getenv("CCSD_NO_STAGE")) wst = 0;
+    // Candidate LDS budgets, best first: 2 workgroups/CU with the weights staged in LDS; 3/CU reading weights from
+    // L2; then whatever fits in one CU.  Within a budget take the largest channel group / chunk sizes.
+    const int wst_full = wst;
+    const int budgets_kb[5] = {79, 53, 79, 152, 152};
+    const int stage_on[5] = {1, 0, 0, 1, 0};
     int best_total = -1;
-    for (int pass = 0; pass < 2 && best_total < 0; ++pass) {
-        const int budget = (pass == 0 ? 64 : 152) * 1024 / 4;
+    for (int pass = 0; pass < 5 && best_total < 0; ++pass) {
+        if (stage_on[pass] && wst_full == 0) continue;
+        wst = stage_on[pass] ? wst_full : 0;
+        const int budget = budgets_kb[pass] * 1024 / 4;
         for (int cg = cinmax; cg >= 1 && best_total < 0; --cg) {
             int o = 0;
             auto carve = [&](int n) { int r = o; o += (n + 3) / 4 * 4; return r; };
@@ -265,6 +282,8 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
                 p->o_hatt = carve(4);
             }
             if (xphase_end > o) o = xphase_end;
+            p->o_wst = carve(wst);
+            p->wst_floats = wst;
             // shared region R: GCN scratch of a channel group | hidden activations of the MLPs | dense hodge layer
             int rmin = 2 * cg * N * colmax;
             if (N * c->x_nhid > rmin) rmin = N * c->x_nhid;
