@@ -200,6 +200,41 @@ CCSD_DEV void small_mlp(const MlpD& m, const float* __restrict__ w, const float*
     for (int i = 0; i < W; ++i) out[i] = a[i];
 }
 
+// The hodge branch's channel-mixing MLPs (mlp_attention) evaluated from zero-padded 8x8 weight blocks staged in
+// LDS: block q of an MLP = [8][8] weights (row = output) + [8] biases (72 floats).  All lanes read the same
+// addresses (LDS broadcast); padded rows/columns contribute exact zeros.
+#define CCSD_HWBLK 72
+CCSD_DEV void stage_mlp_blocks(const MlpD& m, const float* __restrict__ w, float* blk) {
+    for (int t = threadIdx.x; t < m.n * CCSD_HWBLK; t += blockDim.x) {
+        const int q = t / CCSD_HWBLK, r = t % CCSD_HWBLK;
+        const int ni = mlp_in(m, q), no = mlp_out(m, q);
+        float v = 0.f;
+        if (r < 64) { const int o = r >> 3, i = r & 7; if (o < no && i < ni) v = w[m.w[q] + o * ni + i]; }
+        else { const int o = r - 64; if (o < no) v = w[m.b[q] + o]; }
+        blk[t] = v;
+    }
+}
+CCSD_DEV void small_mlp_lds(const float* blk, int nlin, const float* in, float* out) {
+    float a[CCSD_SMALLW], t[CCSD_SMALLW];
+#pragma unroll
+    for (int i = 0; i < CCSD_SMALLW; ++i) a[i] = in[i];
+    for (int l = 0; l < nlin; ++l) {
+        const float* wb = blk + l * CCSD_HWBLK;
+        const bool act = l < nlin - 1;
+#pragma unroll
+        for (int o = 0; o < CCSD_SMALLW; ++o) {
+            float acc = wb[64 + o];
+#pragma unroll
+            for (int i = 0; i < CCSD_SMALLW; ++i) acc = fmaf(a[i], wb[o * 8 + i], acc);
+            t[o] = act ? elu1(acc) : acc;
+        }
+#pragma unroll
+        for (int i = 0; i < CCSD_SMALLW; ++i) a[i] = t[i];
+    }
+#pragma unroll
+    for (int i = 0; i < CCSD_SMALLW; ++i) out[i] = a[i];
+}
+
 // ---------------------------------------------------------------------------------------------
 // block_linear: Y[o][m] = act( sum_k X[k][m] * W[o][k] + b[o] )  for m < rows, o < out.
 // X, Y: LDS, feature-major (row stride ldx / ldy; strides == 16 mod 32 give conflict-free fragment
@@ -1164,7 +1199,14 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
     // copy blob range [lo, hi) into LDS and return a pointer that is indexed with the ORIGINAL blob offsets
     auto stage_w = [&](int lo, int hi) -> const float* {
         if (!STAGE) return w;
-        for (int t = tid; t < hi - lo; t += nth) s_wst[t] = w[lo + t];
+        const int n = hi - lo;
+        for (int base = tid; base < n; base += 8 * nth) {     // eight independent (clamped, unpredicated) loads in flight
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int t = base + u * nth; v[u] = w[lo + (t < n ? t : n - 1)]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int t = base + u * nth; if (t < n) s_wst[t] = v[u]; }
+        }
         return s_wst - lo;
     };
 
@@ -1410,6 +1452,9 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
             float* s_hdiag = sm + p.o_hatt;     // [channel][E] attention diagonals
             float* s_h1m = s_R;                 // [cout0][E][E] dense output of the first hodge layer
             const float kscale = (float)sqrt((double)p.K);  // hodge_attention.py:118,122: / sqrt(out_dim), out_dim = K
+            float* s_hw = sm + p.o_hw;         // zero-padded mlp_attention weight blocks of both hodge layers
+            stage_mlp_blocks(p.hl[0].matt, w, s_hw);
+            if (p.h_L > 1) stage_mlp_blocks(p.hl[1].matt, w, s_hw + CCSD_MAXLIN * CCSD_HWBLK);
             for (int t = tid; t < p.a_cinit * E; t += nth) {
                 int c, e;
                 dE.divmod(t, c, e);
@@ -1451,7 +1496,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
                         }
                         in[c] = sacc;
                     }
-                    small_mlp<CCSD_SMALLW>(h0.matt, w, in, out);   // mlp_attention -> mask -> tanh -> + transpose
+                    small_mlp_lds(s_hw, h0.matt.n, in, out);   // mlp_attention -> mask -> tanh -> + transpose
                     const float fh = s_flags[edges[2 * e]] * s_flags[edges[2 * e + 1]];
 #pragma unroll
                     for (int o = 0; o < CCSD_SMALLW; ++o)
@@ -1486,7 +1531,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
                         }
                         in[c] = v;
                     }
-                    small_mlp<CCSD_SMALLW>(h0.matt, w, in, out);
+                    small_mlp_lds(s_hw, h0.matt.n, in, out);
                     const float fh = s_flags[edges[2 * e]] * s_flags[edges[2 * e + 1]];
                     const float fh2 = s_flags[edges[2 * e2]] * s_flags[edges[2 * e2 + 1]];
 #pragma unroll
@@ -1506,10 +1551,15 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
                 const float* P1b = xa.P1 + (size_t)b * E * h1.wc;
                 float* s_deg = s_tmp;                // [cin1][E]; cin1*E <= cg*NN is guarded on the host
                 for (int t = tid; t < h1.cin * E; t += nth) {
-                    const float* Hr = s_h1m + (size_t)t * E;      // row e of channel c: t = c*E + e
-                    float sacc = 0.f;
-                    for (int e2 = 0; e2 < E; ++e2) sacc += Hr[e2];
-                    s_deg[t] = 1.0f / sqrtf(fmaxf(sacc, 1.f));
+                    int c, e;
+                    dE.divmod(t, c, e);
+                    // degree = row sum; the matrix is symmetric, so walk the column: consecutive lanes hit consecutive banks
+                    const float* Hc = s_h1m + (size_t)c * E * E + e;
+                    float s0 = 0.f, s1 = 0.f;
+                    int e2 = 0;
+                    for (; e2 + 2 <= E; e2 += 2) { s0 += Hc[e2 * E]; s1 += Hc[(e2 + 1) * E]; }
+                    if (e2 < E) s0 += Hc[e2 * E];
+                    s_deg[t] = 1.0f / sqrtf(fmaxf(s0 + s1, 1.f));
                 }
                 __syncthreads();
                 for (int t = tid; t < h1.cin * E * qw1; t += nth) {
@@ -1520,8 +1570,8 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
                     const float* dg = s_deg + c * E;
                     const float* pc1 = P1b + c * qw1 + d;
                     float acc = 0.f;
-#pragma unroll 4
-                    for (int e2 = 0; e2 < E; ++e2) acc = fmaf(dg[e] * Hr[e2] * dg[e2], pc1[(size_t)e2 * h1.wc], acc);
+#pragma unroll 12
+                    for (int e2 = 0; e2 < E; ++e2) acc = fmaf(dg[e] * Hr[e2] * dg[e2], pc1[e2 * h1.wc], acc);
                     s_hq[t] = acc + w[h1.bcat + c * qw1 + d];
                 }
                 __syncthreads();
@@ -1542,7 +1592,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
                         }
                         in[c] = sacc;
                     }
-                    small_mlp<CCSD_SMALLW>(h1.matt, w, in, out);
+                    small_mlp_lds(s_hw + CCSD_MAXLIN * CCSD_HWBLK, h1.matt.n, in, out);
                     const float fh = s_flags[edges[2 * e]] * s_flags[edges[2 * e + 1]];
 #pragma unroll
                     for (int o = 0; o < CCSD_SMALLW; ++o)

@@ -59,6 +59,7 @@ struct PlanD {
         o_vcat, o_c0, o_c1, o_acoef, o_hq, o_hatt, o_h1m, o_hd, o_red;
     int xa_lds_floats;
     int o_wst, wst_floats;      // weight staging buffer (0 floats: weights are read in place)
+    int o_hw;                   // zero-padded hodge mlp_attention weight blocks
 };
 
 #ifndef CCSD_DEVICE_ONLY
@@ -280,6 +281,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
                 p->o_hq = carve(hq_floats);
                 p->o_hd = carve(p->a_nch_hodge * E);
                 p->o_hatt = carve(4);
+                p->o_hw = carve(2 * CCSD_MAXLIN * 72);
             }
             if (xphase_end > o) o = xphase_end;
             p->o_wst = carve(wst);

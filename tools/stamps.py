@@ -38,3 +38,6 @@ for k in sorted(lab):
     prev = k
 span = (d[:, 5].max() - d[:, 0].min())
 print("k_r2 first-start to last-end cycles:", span, " k_xa:", x[:, 14].max() - x[:, 0].min())
+print("hodge sub-phases (slots 6..15):", [int(np.median(d[:, i + 1] - d[:, i])) for i in range(6, 15)])
+print("last sub stamp -> final MLP loop start? slot values", [int(np.median(d[:, i] - x[:, 12])) for i in range(6, 16)], "finalMLPstart", int(np.median(x[:,13]-x[:,12])))
+print("hodge start -> first sub stamp:", int(np.median(d[:, 6] - x[:, 12])))
