@@ -1181,7 +1181,7 @@ CCSD_DEV void gcn_dinv(const float* a, float* dinv, int nc, int N) {
 // STAGE: every section's weights (X-network, each AttentionLayer, final MLP: contiguous blob ranges) are copied
 // into LDS once and read from there; otherwise they are read from L2 in place.
 template <bool STAGE>
-__global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, const float* __restrict__ w,
+__global__ __launch_bounds__(512, STAGE ? 4 : 8) void k_xa(const PlanD* __restrict__ plan, const float* __restrict__ w,
                                             const unsigned char* __restrict__ edges, XaArgs xa, NoiseArgs na) {
     CCSD_DYN_SMEM(sm);
     const PlanD& p = *plan;
@@ -1449,12 +1449,11 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
             float* s_hd = sm + p.o_hd;          // [hodge channel][E]: diagonals that reach the final MLP
             float* s_acoef = sm + p.o_acoef;
             float* s_hq = sm + p.o_hq;          // [channel][E][2*adim]
-            float* s_hdiag = sm + p.o_hatt;     // [channel][E] attention diagonals
             float* s_h1m = s_R;                 // [cout0][E][E] dense output of the first hodge layer
             const float kscale = (float)sqrt((double)p.K);  // hodge_attention.py:118,122: / sqrt(out_dim), out_dim = K
             float* s_hw = sm + p.o_hw;         // zero-padded mlp_attention weight blocks of both hodge layers
             stage_mlp_blocks(p.hl[0].matt, w, s_hw);
-            if (p.h_L > 1) stage_mlp_blocks(p.hl[1].matt, w, s_hw + CCSD_MAXLIN * CCSD_HWBLK);
+            if (p.h_L > 1) stage_mlp_blocks(p.hl[1].matt, w, s_hw + p.hw_stride);
             for (int t = tid; t < p.a_cinit * E; t += nth) {
                 int c, e;
                 dE.divmod(t, c, e);
@@ -1549,7 +1548,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
                 const int qw1 = 2 * h1.adim;
                 const FastDiv dqw1(qw1), dEqw1(E * qw1);
                 const float* P1b = xa.P1 + (size_t)b * E * h1.wc;
-                float* s_deg = s_tmp;                // [cin1][E]; cin1*E <= cg*NN is guarded on the host
+                float* s_deg = sm + p.o_deg;         // [cin1][E]
                 for (int t = tid; t < h1.cin * E; t += nth) {
                     int c, e;
                     dE.divmod(t, c, e);
@@ -1592,7 +1591,7 @@ __global__ __launch_bounds__(512) void k_xa(const PlanD* __restrict__ plan, cons
                         }
                         in[c] = sacc;
                     }
-                    small_mlp_lds(s_hw + CCSD_MAXLIN * CCSD_HWBLK, h1.matt.n, in, out);
+                    small_mlp_lds(s_hw + p.hw_stride, h1.matt.n, in, out);
                     const float fh = s_flags[edges[2 * e]] * s_flags[edges[2 * e + 1]];
 #pragma unroll
                     for (int o = 0; o < CCSD_SMALLW; ++o)

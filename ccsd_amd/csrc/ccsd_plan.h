@@ -59,11 +59,13 @@ struct PlanD {
         o_vcat, o_c0, o_c1, o_acoef, o_hq, o_hatt, o_h1m, o_hd, o_red;
     int xa_lds_floats;
     int o_wst, wst_floats;      // weight staging buffer (0 floats: weights are read in place)
-    int o_hw;                   // zero-padded hodge mlp_attention weight blocks
+    int o_hw, hw_stride;        // zero-padded hodge mlp_attention weight blocks (stride between the two layers)
+    int o_deg;                  // degree scratch of the dense hodge layer
 };
 
 #ifndef CCSD_DEVICE_ONLY
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <string>
@@ -245,16 +247,22 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     for (int l = 0; l < p->a_L; ++l) if (p->al[l].w_hi - p->al[l].w_lo > wst) wst = p->al[l].w_hi - p->al[l].w_lo;
     if (p->a_fin.b[2] + 1 - p->a_fin.w[0] > wst) wst = p->a_fin.b[2] + 1 - p->a_fin.w[0];
     if (wst > 8192 || getenv("CCSD_NO_STAGE")) wst = 0;
-    // Candidate LDS budgets, best first: 2 workgroups/CU with the weights staged in LDS; 3/CU reading weights from
-    // L2; then whatever fits in one CU.  Within a budget take the largest channel group / chunk sizes.
+    // Candidate LDS budgets, best first: 4 workgroups/CU reading weights from L2 (32 waves/CU hide the latency of the
+    // ~45 barrier-separated phases best); 2/CU with the weights staged in LDS; 3/CU; then whatever fits in one CU.
+    // Within a budget take the largest channel group / chunk sizes.  CCSD_XA_PASS=<n> skips the first n candidates.
     const int wst_full = wst;
-    const int budgets_kb[5] = {79, 53, 79, 152, 152};
-    const int stage_on[5] = {1, 0, 0, 1, 0};
+    const int NCAND = 6;
+    const int budgets_b[NCAND] = {40960, 79 * 1024, 53 * 1024, 79 * 1024, 152 * 1024, 152 * 1024};
+    const int stage_on[NCAND] = {0, 1, 0, 0, 1, 0};
+    int hw_n = 1;
+    for (int l = 0; l < p->h_L; ++l) if (p->hl[l].matt.n > hw_n) hw_n = p->hl[l].matt.n;
+    auto ld_of = [](int rows) { int r = (rows + 15) / 16 * 16; if (r % 32 == 0) r += 8; return r; };   // 2-way conflicts at worst
     int best_total = -1;
-    for (int pass = 0; pass < 5 && best_total < 0; ++pass) {
+    const char* skip = getenv("CCSD_XA_PASS");
+    for (int pass = skip ? atoi(skip) : 0; pass < NCAND && best_total < 0; ++pass) {
         if (stage_on[pass] && wst_full == 0) continue;
         wst = stage_on[pass] ? wst_full : 0;
-        const int budget = budgets_kb[pass] * 1024 / 4;
+        const int budget = budgets_b[pass] / 4;
         for (int cg = cinmax; cg >= 1 && best_total < 0; --cg) {
             int o = 0;
             auto carve = [&](int n) { int r = o; o += (n + 3) / 4 * 4; return r; };
@@ -262,9 +270,6 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             p->o_x = carve(N * F);
             p->o_adj = carve(NN);
             p->o_an = carve(cg * N > N ? cg * N : N);                       // D^-1/2 per channel of the group
-            int tmpf = cg * NN; if (p->h_L > 1 && p->hl[1].cin * E > tmpf) tmpf = p->hl[1].cin * E;
-            p->o_tmp = carve(tmpf);
-            p->o_red = carve(64);
             const int phase0 = o;
             p->o_xcat = carve(p->x_fdim * p->ldn);                          // X-network phase ...
             p->o_h1 = carve(2 * p->x_fdim * p->ldn);
@@ -272,16 +277,20 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             const int xphase_end = o;
             o = phase0;                                                     // ... aliased by the A-network phase
             p->o_chan = carve(p->a_fdim * NN);
-            p->o_att = carve(cinmax * NN);
+            p->o_tmp = carve(cg * NN);                                      // raw attention of a channel group
+            p->o_att = carve(cinmax * NN);                                  // contiguous with o_tmp (hodge scratch aliases both)
             p->o_xcur = carve(fmaxA * p->ldn);
             p->o_xnext = carve(fmaxA * p->ldn);
             p->o_vcat = carve(mchid * p->ldn);                              // hidden layer of multi_channel
+            p->o_deg = p->o_vcat;
             if (p->h_L) {
                 p->o_acoef = carve(c->a_c_init * E);
-                p->o_hq = carve(hq_floats);
+                // the hodge branch runs after the attention stack: its Q|K scratch reuses [raw attention | attention]
+                if (hq_floats <= (cg + cinmax) * NN) p->o_hq = p->o_tmp; else p->o_hq = carve(hq_floats);
+                if (p->h_L > 1 && p->hl[1].cin * E > mchid * p->ldn) p->o_deg = carve(p->hl[1].cin * E);
                 p->o_hd = carve(p->a_nch_hodge * E);
-                p->o_hatt = carve(4);
-                p->o_hw = carve(2 * CCSD_MAXLIN * 72);
+                p->o_hw = carve(2 * hw_n * 72);
+                p->hw_stride = hw_n * 72;
             }
             if (xphase_end > o) o = xphase_end;
             p->o_wst = carve(wst);
@@ -290,19 +299,22 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             int rmin = 2 * cg * N * colmax;
             if (N * c->x_nhid > rmin) rmin = N * c->x_nhid;
             if (h1m_floats > rmin) rmin = h1m_floats;
-            if (o + rmin + 2 * pw_fin * 16 > budget) continue;
+            if (o + rmin > budget || o + 2 * pw_fin * 16 > budget) continue;
             int pch = 16, pchp = 16;
-            while (pch + 16 <= NNpad && o + 2 * pw_fin * round_ld(pch + 16) <= budget) pch += 16;
-            while (pchp + 16 <= NNpad && o + 2 * pw_pair * round_ld(pchp + 16) <= budget) pchp += 16;
+            while (pch + 16 <= NNpad && o + 2 * pw_fin * ld_of(pch + 16) <= budget) pch += 16;
+            while (pchp + 16 <= NNpad && o + 2 * pw_pair * ld_of(pchp + 16) <= budget) pchp += 16;
             int r = rmin;
-            if (2 * pw_fin * round_ld(pch) > r) r = 2 * pw_fin * round_ld(pch);
-            if (2 * pw_pair * round_ld(pchp) > r) r = 2 * pw_pair * round_ld(pchp);
-            p->cg = cg; p->pch = pch; p->ldp = round_ld(pch); p->pchp = pchp; p->ldpp = round_ld(pchp);
-            p->o_c0 = carve(r); p->o_c1 = p->o_c0;
+            if (2 * pw_fin * ld_of(pch) > r) r = 2 * pw_fin * ld_of(pch);
+            if (2 * pw_pair * ld_of(pchp) > r) r = 2 * pw_pair * ld_of(pchp);
+            p->cg = cg; p->pch = pch; p->ldp = ld_of(pch); p->pchp = pchp; p->ldpp = ld_of(pchp);
+            p->o_c0 = carve(r > 64 ? r : 64); p->o_c1 = p->o_c0;
+            p->o_red = p->o_c0;                                              // block reductions run when R is idle
             p->xa_lds_floats = o;
             best_total = o;
         }
     }
+    if (getenv("CCSD_VERBOSE"))
+        fprintf(stderr, "[ccsd] k_xa LDS %d B (cg=%d pch=%d/%d pchp=%d/%d stage=%d floats)\n", best_total * 4, p->cg, p->pch, p->ldp, p->pchp, p->ldpp, p->wst_floats);
     if (best_total < 0 || (size_t)best_total * 4 > 160 * 1024)
         pb.fail(CCSD_ERR_UNSUPPORTED, "graph-network working set exceeds the 160 KB LDS of a CU");
     return nweights;
