@@ -327,8 +327,9 @@ static int launch_hf(const ccsd_plan* pl, int B, const float* rank2, RankEpi& ep
 }
 
 static int launch_r2(const ccsd_plan* pl, int B, const float* rank2, const float* adj, const float* flags, int want_p,
-                     RankEpi& ep, NoiseArgs& na, Workspace& w, void* stream) {
+                     RankEpi& ep, NoiseArgs& na, Workspace& w, void* stream, const CorrFuse* cf = nullptr) {
     R2Args ra{};
+    if (cf) ra.cf = *cf;
     ra.rank2 = rank2; ra.adj = adj; ra.flags = flags; ra.P0 = w.P0; ra.P1 = w.P1; ra.want_p = want_p;
     ra.ldk = pl->r2_ldk; ra.ldh = pl->r2_ldh; ra.dbg = pl->dbg;
     prof_mark(const_cast<ccsd_plan*>(pl), KID_R2, stream);
@@ -478,17 +479,26 @@ static int corrector_apply(ccsd_plan* pl, int B, int step, int it, const ccsd_st
     return CCSD_OK;
 }
 static int predictor(ccsd_plan* pl, int B, int step, const ccsd_state_t* in, const float* flags, const ccsd_noise_t* noise,
-                     uint64_t seed, int64_t off, ccsd_state_t* out, ccsd_state_t* mean, Workspace& w, void* stream) {
+                     uint64_t seed, int64_t off, ccsd_state_t* out, ccsd_state_t* mean, Workspace& w, void* stream,
+                     const float* fuse_sums = nullptr) {
     const PlanD& p = pl->h;
     int st;
     NoiseArgs na = make_noise(noise, seed, off, draw_base(pl, step, pl->cfg.n_corr_steps));
     const ccsd_step_coef_t* c = &pl->coef[(size_t)step * 3];
     const bool fused = pl->fused_r2 && p.is_cc;
+    CorrFuse cf{};
+    if (fuse_sums) {   // the Langevin corrector's apply pass runs in the prologues of this half-step's kernels
+        cf.on = 1; cf.net_x = w.net_x; cf.net_adj = w.net_adj; cf.net_r = w.net_r; cf.sums = fuse_sums;
+        for (int t = 0; t < 3; ++t) { cf.ss[t] = c[t].sscale; cf.alpha[t] = c[t].alpha; }
+        cf.snr = p.snr; cf.seps = p.seps;
+        const unsigned int cb = draw_base(pl, step, 0);
+        cf.draw_x = cb; cf.draw_adj = cb + 1; cf.draw_r = cb + 2;
+    }
     if (fused) {
         RankEpi ep{};
         ep.mode = MODE_PRED; ep.pa = c[2].pa; ep.pb = c[2].pb; ep.pc = c[2].pc;
         ep.out = out->rank2; ep.mean = mean ? mean->rank2 : nullptr;
-        if ((st = launch_r2(pl, B, in->rank2, in->adj, flags, 1, ep, na, w, stream))) return st;
+        if ((st = launch_r2(pl, B, in->rank2, in->adj, flags, 1, ep, na, w, stream, &cf))) return st;
     } else if ((st = launch_p(pl, B, in->adj, in->rank2, w, stream))) return st;
     XaArgs xa{};
     xa.xX = xa.xA = in->x; xa.adjX = xa.adjA = in->adj; xa.flags = flags;
@@ -497,6 +507,7 @@ static int predictor(ccsd_plan* pl, int B, int step, const ccsd_state_t* in, con
     xa.pa_a = c[1].pa; xa.pb_a = c[1].pb; xa.pc_a = c[1].pc;
     xa.out_x = out->x; xa.out_a = out->adj;
     xa.mean_x = mean ? mean->x : nullptr; xa.mean_a = mean ? mean->adj : nullptr;
+    xa.cf = cf;
     if ((st = launch_xa(pl, B, xa, na, w, stream))) return st;
     if (p.is_cc && !fused) {
         if ((st = launch_h(pl, B, in->rank2, w, stream))) return st;
@@ -564,7 +575,12 @@ extern "C" int ccsd_sampler_run(ccsd_plan_t* pl, int32_t B, const float* flags, 
     for (int step = first_step; step < last_step; ++step) {
         const bool lastone = step == last_step - 1;
         const bool want_mean = pl->cfg.denoise && (lastone || traj);
-        if (lang) {   // a -> (corrector) -> b -> (predictor) -> a
+        if (lang && pl->fused_r2 && getenv("CCSD_NO_FUSED_APPLY") == nullptr) {
+            // a -> [norms pass] ; [apply fused into the predictor kernels] -> b ; swap roles
+            if ((st = corrector_norms(pl, B, step, 0, &a, &a, flags, nullptr, seed, sample_offset, w.sums, w, stream))) return st;
+            if ((st = predictor(pl, B, step, &a, flags, nullptr, seed, sample_offset, &b, want_mean ? result : nullptr, w, stream, w.sums))) return st;
+            ccsd_state_t t = a; a = b; b = t;
+        } else if (lang) {   // a -> (corrector) -> b -> (predictor) -> a
             if ((st = corrector_norms(pl, B, step, 0, &a, &a, flags, nullptr, seed, sample_offset, w.sums, w, stream))) return st;
             if ((st = corrector_apply(pl, B, step, 0, &a, flags, nullptr, seed, sample_offset, w.sums, &b, w, stream))) return st;
             if ((st = predictor(pl, B, step, &b, flags, nullptr, seed, sample_offset, &a, want_mean ? result : nullptr, w, stream))) return st;
@@ -580,7 +596,7 @@ extern "C" int ccsd_sampler_run(ccsd_plan_t* pl, int32_t B, const float* flags, 
             if (nr) RT_CHECK(rt_d2d_async(slot + nx + na, src->rank2, nr * 4, stream));
         }
     }
-    if (a.x != state->x) {   // odd number of predictor-only steps: bring the live state home
+    if (a.x != state->x) {   // the live buffer ended up in `scratch`: bring the state home
         RT_CHECK(rt_d2d_async(state->x, a.x, (size_t)B * nx * 4, stream));
         RT_CHECK(rt_d2d_async(state->adj, a.adj, (size_t)B * na * 4, stream));
         if (nr) RT_CHECK(rt_d2d_async(state->rank2, a.rank2, (size_t)B * nr * 4, stream));

@@ -731,12 +731,31 @@ CCSD_DEV float raw_noise_r1(const NoiseArgs& na, int b, int e, int k, int E, int
     return s == 0 ? n[0] : s == 1 ? n[1] : s == 2 ? n[2] : n[3];
 }
 
+// Langevin corrector apply fused into the predictor kernels (ccsd_sampler_run): v <- v + step*score + sqrt(2 step)*z*scale_eps
+// with step from the batch norm sums (solver.py:767-769, 781-783, 797-801); same arithmetic as k_langevin_apply.
+struct CorrFuse {
+    int on;
+    const float* net_x; const float* net_adj; const float* net_r;   // raw network outputs kept by the NORMS pass
+    const float* sums;
+    float ss[3], alpha[3];
+    float snr, seps;
+    unsigned int draw_x, draw_adj, draw_r;                            // corrector draw indices (predictor ones are in NoiseArgs)
+};
+CCSD_DEV void corr_coef(const CorrFuse& cf, int t, float* c1, float* c2) {
+    const float gn = fabsf(cf.ss[t]) * cf.sums[t], zn = cf.sums[3 + t];
+    const float q = cf.snr * zn / gn;
+    const float step = q * q * 2.f * cf.alpha[t];
+    *c1 = step * cf.ss[t];
+    *c2 = sqrtf(step * 2.f) * cf.seps;
+}
+
 struct R2Args {
     const float* rank2; const float* adj; const float* flags;
     float* P0; float* P1;
     int want_p;            // write the hodge projections (the A-network will run on the same state)
     int ldk, ldh;
     long long* dbg;
+    CorrFuse cf;
 };
 
 // MT = ceil(E / 16) row tiles (1..4); AFFINE: ScoreNetworkF folds to alpha F + beta HF + gamma; GEN1: general
@@ -803,8 +822,21 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     }
     for (int t = tid; t < E * (Kp4 - K); t += nth) { const int e = t / (Kp4 - K), k = K + t % (Kp4 - K); sF[e * ldk + k] = 0.f; }
     const int hodge2 = (p.h_L > 1) && ra.want_p;
-    if (hodge2)
-        for (int i = tid; i < NN; i += nth) { const float v = ra.adj[(size_t)b * NN + i]; sAdj[i] = v; sAdj[NN + i] = v; }
+    if (hodge2) {
+        float c1a = 0.f, c2a = 0.f;
+        if (ra.cf.on) corr_coef(ra.cf, 1, &c1a, &c2a);
+        for (int i = tid; i < NN; i += nth) {
+            float v = ra.adj[(size_t)b * NN + i];
+            if (ra.cf.on) {   // the A-network of the predictor sees the corrected adjacency
+                NoiseArgs nc = na;
+                nc.zadj = nullptr; nc.draw_adj = ra.cf.draw_adj;
+                const int ii = i / N, jj = i % N;
+                const float z = raw_noise_adj(nc, b, ii, jj, N) * ra.flags[(size_t)b * N + ii] * ra.flags[(size_t)b * N + jj];
+                v = fmaf(c2a, z, fmaf(c1a, ra.cf.net_adj[(size_t)b * NN + i], v));
+            }
+            sAdj[i] = v; sAdj[NN + i] = v;
+        }
+    }
     __syncthreads();
     const unsigned long long off = s_off;
     for (int k = tid; k < Kp4; k += nth) sFrb[k] = (k < K && !(cells[k] & off)) ? 1 : 0;
@@ -828,6 +860,62 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
         }
     }
     __syncthreads();
+    if (ra.cf.on) {
+        // fused Langevin corrector apply on the LDS-resident block: F <- F + c1*net + c2*z (masked)
+        float c1, c2;
+        corr_coef(ra.cf, 2, &c1, &c2);
+        const float* Ng = ra.cf.net_r + (size_t)b * E * K;
+        if (((E * K) & 3) == 0) {
+            const float4* N4 = reinterpret_cast<const float4*>(Ng);
+            const int n4 = (E * K) >> 2;
+            for (int base = tid; base < n4; base += 4 * nth) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int i4 = base + u * nth; v[u] = N4[i4 < n4 ? i4 : n4 - 1]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i4 = base + u * nth;
+                    if (i4 < n4) {
+                        int e, k;
+                        dK.divmod(4 * i4, e, k);
+                        const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            sF[e * ldk + k] = fmaf(c1, vv[q], sF[e * ldk + k]);
+                            if (++k == K) { k = 0; ++e; }
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int t = tid; t < E * K; t += nth) {
+                int e, k;
+                dK.divmod(t, e, k);
+                sF[e * ldk + k] = fmaf(c1, Ng[t], sF[e * ldk + k]);
+            }
+        }
+        __syncthreads();
+        NoiseArgs nc = na;
+        nc.zr = nullptr; nc.draw_r = ra.cf.draw_r;
+        const int egn = (E + 3) >> 2;
+        for (int t = tid; t < egn * K; t += nth) {
+            int eg, k;
+            dK.divmod(t, eg, k);
+            float z[4];
+            raw_noise_r4(nc, b, eg, k, E, K, z);
+            const float fr = (float)sFrb[k];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = 4 * eg + r;
+                if (e < E) {
+                    // same expression as k_langevin_apply: fma(c2, z*fl*fr, fma(c1, net, v))
+                    const float zz = z[r] * sFl[e] * fr;
+                    sF[e * ldk + k] = fmaf(c2, zz, sF[e * ldk + k]);
+                }
+            }
+        }
+        __syncthreads();
+    }
     stamp(ra.dbg, 1);
     const HodgeLayerD& h0 = p.hl[0];
     const HodgeLayerD& h1 = p.hl[1];
@@ -1163,7 +1251,27 @@ struct XaArgs {
     float* mean_x; float* mean_a;         // PRED, nullable
     float* norm2;                         // NORMS: [B][4] = |net_x|^2, |net_adj|^2, |z_x|^2, |z_adj|^2
     long long* dbg;
+    CorrFuse cf;
 };
+
+// fused Langevin corrector apply for x and adj held in LDS (same expressions as k_langevin_apply)
+CCSD_DEV void corr_apply_xa(const CorrFuse& cf, const NoiseArgs& na, int b, int N, int F, float* s_x, float* s_adj,
+                            const float* s_flags) {
+    float c1x, c2x, c1a, c2a;
+    corr_coef(cf, 0, &c1x, &c2x);
+    corr_coef(cf, 1, &c1a, &c2a);
+    NoiseArgs nc = na;
+    nc.zx = nullptr; nc.zadj = nullptr; nc.draw_x = cf.draw_x; nc.draw_adj = cf.draw_adj;
+    for (int t = threadIdx.x; t < N * F; t += blockDim.x) {
+        const float z = raw_noise_x(nc, b, t, N * F) * s_flags[t / F];
+        s_x[t] = fmaf(c2x, z, fmaf(c1x, cf.net_x[(size_t)b * N * F + t], s_x[t]));
+    }
+    for (int t = threadIdx.x; t < N * N; t += blockDim.x) {
+        const int i = t / N, j = t % N;
+        const float z = raw_noise_adj(nc, b, i, j, N) * s_flags[i] * s_flags[j];
+        s_adj[t] = fmaf(c2a, z, fmaf(c1a, cf.net_adj[(size_t)b * N * N + t], s_adj[t]));
+    }
+}
 
 // clamp(rowsum(A with unit diagonal), 1)^-1/2 for `nc` channels   (DenseGCNConv, layers.py:139-145)
 CCSD_DEV void gcn_dinv(const float* a, float* dinv, int nc, int N) {
@@ -1223,6 +1331,7 @@ __global__ __launch_bounds__(512, STAGE ? 4 : 8) void k_xa(const PlanD* __restri
         const float* wx = stage_w(p.x_wlo, p.x_whi);   // visible after the barrier below
         for (int i = tid; i < N * F; i += nth) s_x[i] = xa.xX[(size_t)b * N * F + i];
         for (int i = tid; i < NN; i += nth) s_adj[i] = xa.adjX[(size_t)b * NN + i];
+        if (xa.cf.on) { __syncthreads(); corr_apply_xa(xa.cf, na, b, N, F, s_x, s_adj, s_flags); }
         __syncthreads();
         gcn_dinv(s_adj, s_dinv, 1, N);
         for (int t = tid; t < N * F; t += nth) { int i, f; dF.divmod(t, i, f); s_xcat[f * ldn + i] = s_x[t]; }
@@ -1292,13 +1401,25 @@ __global__ __launch_bounds__(512, STAGE ? 4 : 8) void k_xa(const PlanD* __restri
         float* s_xcur = sm + p.o_xcur;
         float* s_xnext = sm + p.o_xnext;
         float* s_mch = sm + p.o_vcat;
-        for (int t = tid; t < N * F; t += nth) {
-            const float v = xa.xA[(size_t)b * N * F + t];
-            int i, f;
-            dF.divmod(t, i, f);
-            s_xcur[f * ldn + i] = v;
+        if (xa.cf.on) {
+            // fused corrector: rebuild the corrected (x, adj) (identical values to the X-network phase), then fan out
+            __syncthreads();
+            for (int i = tid; i < N * F; i += nth) s_x[i] = xa.xA[(size_t)b * N * F + i];
+            for (int i = tid; i < NN; i += nth) s_adj[i] = xa.adjA[(size_t)b * NN + i];
+            __syncthreads();
+            corr_apply_xa(xa.cf, na, b, N, F, s_x, s_adj, s_flags);
+            __syncthreads();
+            for (int t = tid; t < N * F; t += nth) { int i, f; dF.divmod(t, i, f); s_xcur[f * ldn + i] = s_x[t]; }
+            for (int i = tid; i < NN; i += nth) s_chan[i] = s_adj[i];
+        } else {
+            for (int t = tid; t < N * F; t += nth) {
+                const float v = xa.xA[(size_t)b * N * F + t];
+                int i, f;
+                dF.divmod(t, i, f);
+                s_xcur[f * ldn + i] = v;
+            }
+            for (int i = tid; i < NN; i += nth) { const float v = xa.adjA[(size_t)b * NN + i]; s_adj[i] = v; s_chan[i] = v; }
         }
-        for (int i = tid; i < NN; i += nth) { const float v = xa.adjA[(size_t)b * NN + i]; s_adj[i] = v; s_chan[i] = v; }
         __syncthreads();
         // pow_tensor: channel c = channel(c-1) @ adj   (graph_utils.py:285-292)
         for (int c = 1; c < p.a_cinit; ++c) {
