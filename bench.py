@@ -31,9 +31,25 @@ FLOP_PER_UNIT = 2 * (FLOP_X + FLOP_A + FLOP_F)            # per complex per PC s
 BYTES_PER_UNIT = 4 * 16_893 * 4                           # 2 x (read + write) of x, adj, rank2
 PEAK_F32_MFMA_TFLOPS = 157.3                              # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_HBM_GBPS = 8000.0
-# The kernel that dominates the step (profiles/r01_*): algorithmic work of ONE launch for a batch of B complexes.
-# k_xa evaluates ScoreNetworkX + ScoreNetworkA_CC for every complex of the batch once per launch.
-DOMINANT = {"name": "k_xa", "bound": "mfma", "flops_per_complex": FLOP_X + FLOP_A}
+# Kernels of the step (profiles/README.md): algorithmic work of ONE launch for a batch of B complexes (SURVEY 8d figures).
+# k_xa evaluates ScoreNetworkX + ScoreNetworkA_CC once per launch (fp32 MFMA / issue bound): dominant kernel.
+# k_r2 is the rank-2 side: reads rank2 (E*K fp32) once and writes it once per launch (HBM bound), ScoreNetworkF in between.
+KERNELS = {
+    "k_xa": {"bound": "mfma", "flops_per_complex": FLOP_X + FLOP_A},
+    "k_r2": {"bound": "hbm", "bytes_per_complex": 2 * 36 * 466 * 4, "flops_per_complex": FLOP_F},
+}
+DOMINANT = "k_xa"
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+
+
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch from the committed PMC passes (FETCH_SIZE doubled: gfx950 reports half of a wide
+    coalesced read, MI355X_MICROARCH.md section HBM; WRITE_SIZE as is); None when the file is absent."""
+    try:
+        d = json.load(open(PMC_FILE))[kernel]
+        return {"bytes": d["hbm_bytes_per_launch"], "source": "profiles/r01_pmc_traffic.json"}
+    except Exception:
+        return None
 
 
 def qm9_flags(B: int, seed: int = 42) -> torch.Tensor:
@@ -95,6 +111,27 @@ def cpu_baseline(B: int, steps: int = 2, warm: int = 1):
     log(f"cpu_baseline: {dt:.2f} s / PC step")
     return {"value": B / (dt * 1000.0), "unit": "complexes/s at 1000 PC steps", "cores": threads, "kind": "port",
             "sample": f"oracle (torch CPU, {threads} threads), B={B}, {steps} PC steps after {warm} warm-up, scaled to 1000 steps"}
+
+
+def roofline_obj(kname, ktimes, B, dt):
+    if kname not in ktimes or not ktimes[kname][0]:
+        return None
+    launches, kms = ktimes[kname]
+    avg_s = kms / launches * 1e-3
+    k = KERNELS[kname]
+    tr = pmc_traffic(kname)
+    o = {"kernel": kname, "bound": k["bound"], "launches": launches, "avg_launch_us": avg_s * 1e6,
+         "share_of_step": kms / (dt * 1e3), "traffic": tr["bytes"] if tr else None}
+    if k["bound"] == "mfma":
+        a = k["flops_per_complex"] * B / avg_s / 1e12
+        o.update(achieved=a, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=a / PEAK_F32_MFMA_TFLOPS,
+                 note="achieved = dense-as-written GEMM FLOPs per launch (SURVEY 8d: ScoreNetworkX + ScoreNetworkA_CC) / "
+                      "mean launch time (HIP events on the launch stream); fp32 MFMA peak")
+    else:
+        a = k["bytes_per_complex"] * B / avg_s / 1e9
+        o.update(achieved=a, peak=PEAK_HBM_GBPS, unit="GB/s", frac=a / PEAK_HBM_GBPS,
+                 note="achieved = algorithmic bytes per launch (read + write of rank2) / mean launch time")
+    return o
 
 
 def main():
@@ -160,7 +197,8 @@ def main():
     run_steps(0, args.warmup)
     eng.init_state(flags, state, None, seed, off)          # the timed region starts from a fresh prior, inputs resident
     if not args.no_kernel_events:
-        eng.profile_kernel(DOMINANT["name"])               # HIP events around that kernel's launches, on its stream
+        for kname in KERNELS:                              # HIP events around those kernels' launches, on their stream
+            eng.profile_kernel(kname)
     sync()
     t0 = time.perf_counter()
     run_steps(0, args.steps)
@@ -174,7 +212,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
     log(f"timed region: {args.steps} steps in {dt:.3f} s")
-    launches, kms = eng.profile_read() if not args.no_kernel_events else (0, 0.0)
+    ktimes = {k: eng.profile_read(k) for k in KERNELS} if not args.no_kernel_events else {}
     eng.profile_kernel(None)
     ok = all(torch.isfinite(t).all().item() for t in result)
 
@@ -190,14 +228,8 @@ def main():
             "config": {"workload": "qm9_CC N=9 F=4 E=36 K=466, B=1024 per GPU, VE x3, Reverse+Langevin snr=0.2 scale_eps=0.7 n_steps=1, 1000 scales",
                        "global_batch": B * world, "parallelism": f"batch-sharded x{world}, per-shard Langevin norms, all-gather at end",
                        "finite": ok},
-            "roofline": None if not launches else {
-                "kernel": DOMINANT["name"], "bound": DOMINANT["bound"],
-                "achieved": DOMINANT["flops_per_complex"] * B / (kms / launches * 1e-3) / 1e12,
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": DOMINANT["flops_per_complex"] * B / (kms / launches * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                "traffic": None, "launches": launches, "avg_launch_us": kms / launches * 1e3,
-                "share_of_step": kms / (dt * 1e3),
-                "note": "achieved = dense-as-written GEMM FLOPs of ScoreNetworkX+ScoreNetworkA_CC per launch (SURVEY 8d) / mean launch time (HIP events on the launch stream)"},
+            "roofline": roofline_obj(DOMINANT, ktimes, B, dt),
+            "roofline_k_r2": roofline_obj("k_r2", ktimes, B, dt),
             "achieved_model_tflops": FLOP_PER_UNIT * units_per_s / 1e12,
             "achieved_state_gbps": BYTES_PER_UNIT * units_per_s / 1e9,
             "cpu_baseline": None,

@@ -109,7 +109,7 @@ class Library:
         L.ccsd_quantize.restype = C.c_int
         L.ccsd_profile_kernel.argtypes = [vp, i32]
         L.ccsd_profile_kernel.restype = C.c_int
-        L.ccsd_profile_read.argtypes = [vp, P(i64), P(C.c_double)]
+        L.ccsd_profile_read.argtypes = [vp, i32, P(i64), P(C.c_double)]
         L.ccsd_profile_read.restype = C.c_int
         L.ccsd_debug_stamps.argtypes = [vp, vp]
         L.ccsd_debug_stamps.restype = C.c_int

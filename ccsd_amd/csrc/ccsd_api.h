@@ -26,28 +26,28 @@ struct ccsd_plan {
     int fused_r2 = 0, r2_ldk = 0, r2_ldh = 0;
     size_t r2_lds = 0;
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
-    int prof_kernel = -1;
-    size_t prof_used = 0;
+    unsigned prof_mask = 0;
+    size_t prof_used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #ifndef CCSD_EMU
-    std::vector<hipEvent_t> prof_ev;
+    std::vector<hipEvent_t> prof_ev[8];
 #endif
 };
 
 enum { KID_XA = 0, KID_GEMM_P = 1, KID_HF = 2, KID_GEMM_H = 3, KID_LANGEVIN = 4, KID_R2 = 5 };
 static void prof_mark(ccsd_plan* pl, int kid, void* stream) {
 #ifndef CCSD_EMU
-    if (pl->prof_kernel != kid) return;
-    if (pl->prof_used == pl->prof_ev.size()) {
+    if (!(pl->prof_mask & (1u << kid))) return;
+    std::vector<hipEvent_t>& ev = pl->prof_ev[kid];
+    if (pl->prof_used[kid] == ev.size()) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return;
-        pl->prof_ev.push_back(e);
+        ev.push_back(e);
     }
-    (void)hipEventRecord(pl->prof_ev[pl->prof_used++], (hipStream_t)stream);
+    (void)hipEventRecord(ev[pl->prof_used[kid]++], (hipStream_t)stream);
 #else
     (void)pl; (void)kid; (void)stream;
 #endif
 }
-
 #define RT_CHECK(expr)                                                                    \
     do {                                                                                  \
         rtError_t _e = (expr);                                                            \
@@ -82,29 +82,30 @@ extern "C" int ccsd_debug_stamps(ccsd_plan_t* plan, void* dev_buffer) {
 }
 extern "C" int ccsd_profile_kernel(ccsd_plan_t* plan, int32_t kernel_id) {
     if (!plan) return set_err(CCSD_ERR_INVALID, "NULL plan");
-    plan->prof_kernel = kernel_id;
-    plan->prof_used = 0;
+    if (kernel_id < 0) plan->prof_mask = 0;
+    else if (kernel_id < 8) plan->prof_mask |= 1u << kernel_id;
+    for (int k = 0; k < 8; ++k) plan->prof_used[k] = 0;
     return CCSD_OK;
 }
-extern "C" int ccsd_profile_read(ccsd_plan_t* plan, int64_t* launches, double* total_ms) {
-    if (!plan || !launches || !total_ms) return set_err(CCSD_ERR_INVALID, "NULL argument");
+extern "C" int ccsd_profile_read(ccsd_plan_t* plan, int32_t kernel_id, int64_t* launches, double* total_ms) {
+    if (!plan || !launches || !total_ms || kernel_id < 0 || kernel_id >= 8) return set_err(CCSD_ERR_INVALID, "bad argument");
     *launches = 0; *total_ms = 0.0;
 #ifndef CCSD_EMU
-    for (size_t i = 0; i + 1 < plan->prof_used; i += 2) {
+    for (size_t i = 0; i + 1 < plan->prof_used[kernel_id]; i += 2) {
         float ms = 0.f;
-        RT_CHECK(hipEventSynchronize(plan->prof_ev[i + 1]));
-        RT_CHECK(hipEventElapsedTime(&ms, plan->prof_ev[i], plan->prof_ev[i + 1]));
+        RT_CHECK(hipEventSynchronize(plan->prof_ev[kernel_id][i + 1]));
+        RT_CHECK(hipEventElapsedTime(&ms, plan->prof_ev[kernel_id][i], plan->prof_ev[kernel_id][i + 1]));
         *total_ms += ms; *launches += 1;
     }
 #endif
-    plan->prof_used = 0;
+    plan->prof_used[kernel_id] = 0;
     return CCSD_OK;
 }
 
 extern "C" void ccsd_plan_destroy(ccsd_plan_t* plan) {
     if (!plan) return;
 #ifndef CCSD_EMU
-    for (hipEvent_t e : plan->prof_ev) (void)hipEventDestroy(e);
+    for (int k = 0; k < 8; ++k) for (hipEvent_t e : plan->prof_ev[k]) (void)hipEventDestroy(e);
 #endif
     if (plan->d) (void)rt_free(plan->d);
     if (plan->w) (void)rt_free(plan->w);

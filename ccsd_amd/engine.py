@@ -168,12 +168,12 @@ class PCEngine:
                                                  C.byref(s), C.byref(sc), C.byref(r), _ptr(traj), ws, n, self._stream()))
 
     def profile_kernel(self, name: Optional[str]):
-        """Time every launch of one kernel with HIP events on the launch stream (None disables)."""
+        """Add a kernel to the set timed with HIP events on the launch stream (None clears the set)."""
         self.lib.check(self.lib.ccsd_profile_kernel(self.handle, -1 if name is None else _lib.KERNEL_IDS[name]))
 
-    def profile_read(self) -> Tuple[int, float]:
+    def profile_read(self, name: str) -> Tuple[int, float]:
         n, ms = C.c_int64(0), C.c_double(0.0)
-        self.lib.check(self.lib.ccsd_profile_read(self.handle, C.byref(n), C.byref(ms)))
+        self.lib.check(self.lib.ccsd_profile_read(self.handle, _lib.KERNEL_IDS[name], C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
     def quantize(self, t: torch.Tensor, thr: float = 0.5) -> torch.Tensor:

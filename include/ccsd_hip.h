@@ -162,14 +162,14 @@ int ccsd_sampler_run(ccsd_plan_t* plan, int32_t B, const float* flags_dev, uint6
  * quantize(t, thr): t<thr ? 0 : 1. */
 int ccsd_quantize(const float* in_dev, int64_t n, float thr, int64_t* out_dev, void* stream);
 
-/* Measurement hooks (bench.py): time every launch of one kernel with HIP events on the launch stream.
- * kernel_id: 0 k_xa, 1 k_gemm_p, 2 k_hf_score, 3 k_gemm_h, 4 k_langevin_apply; -1 disables.
- * ccsd_profile_read synchronises on the recorded events and returns launches + summed milliseconds. */
+/* Measurement hooks (bench.py): time every launch of selected kernels with HIP events on the launch stream.
+ * kernel_id: 0 k_xa, 1 k_gemm_p, 2 k_hf_score, 3 k_gemm_h, 4 k_langevin_apply, 5 k_r2; each call adds one kernel to the
+ * selection, -1 clears it.  ccsd_profile_read synchronises on that kernel's events and returns launches + summed ms. */
 int ccsd_profile_kernel(ccsd_plan_t* plan, int32_t kernel_id);
+int ccsd_profile_read(ccsd_plan_t* plan, int32_t kernel_id, int64_t* launches, double* total_ms);
 /* Diagnostic: when dev_buffer (B x 32 int64, device) is non-NULL, thread 0 of every workgroup of k_r2 (slots 0-15)
- * and k_xa (slots 16-31, offset by 16) stores the shader clock at its phase boundaries.  NULL disables. */
+ * and k_xa (slots 16-31) stores the shader clock at its phase boundaries (tools/stamps.py).  NULL disables. */
 int ccsd_debug_stamps(ccsd_plan_t* plan, void* dev_buffer);
-int ccsd_profile_read(ccsd_plan_t* plan, int64_t* launches, double* total_ms);
 
 #ifdef __cplusplus
 }

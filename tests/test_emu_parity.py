@@ -57,3 +57,13 @@ def test_philox_prior_statistics(lib):
 
 def test_error_behaviour(lib):
     pc.case_error_behaviour(lib, DEV)
+
+
+@pytest.mark.parametrize("env", [{"CCSD_NO_FUSED_R2": "1"}, {"CCSD_XA_PASS": "1"}, {"CCSD_NO_FUSED_APPLY": "1"}])
+def test_alternative_kernel_paths_qm9(lib, env, monkeypatch):
+    """The general tiled rank-2 kernels / the LDS-staged-weights variant / the unfused apply pass on the qm9_CC cases."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    pc.case_forward_vs_reference_golden("ccsd_qm9_CC", lib, DEV)
+    pc.case_pc_sampler_identical_seed("ccsd_qm9_CC", "ccsd_qm9_CC", "k10", lib, DEV)
+    pc.case_philox_properties(lib, DEV)

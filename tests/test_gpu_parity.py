@@ -103,3 +103,14 @@ def test_full_size_qm9_philox_properties(lib):
     # the state after 5 of 1000 VE steps is still prior-dominated: unit-ish scale on the live entries
     live = rank2[flags.sum(1) == 9]
     assert 0.5 < live.std().item() < 2.0
+
+
+@pytest.mark.parametrize("env", [{"CCSD_NO_FUSED_R2": "1"}, {"CCSD_XA_PASS": "1"}, {"CCSD_XA_PASS": "2"}, {"CCSD_NO_FUSED_APPLY": "1"}])
+def test_alternative_kernel_paths_qm9(lib, env, monkeypatch):
+    """qm9_CC normally takes the fused LDS-resident rank-2 kernel and the 4-workgroups/CU graph-network layout; force the
+    general tiled rank-2 kernels, the LDS-staged-weights variant and the 3/CU layout through the same parity cases."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    pc.case_forward_vs_reference_golden("ccsd_qm9_CC", lib, DEV)
+    pc.case_pc_sampler_identical_seed("ccsd_qm9_CC", "ccsd_qm9_CC", "k10", lib, DEV)
+    pc.case_philox_properties(lib, DEV)
