@@ -185,7 +185,9 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     }
 #ifndef CCSD_EMU
     if ((size_t)pl->h.xa_lds_floats * 4 > 64 * 1024)
-        PC(rt_set_max_dyn_smem(pl->h.wst_floats > 0 ? (const void*)k_xa<true> : (const void*)k_xa<false>, (size_t)pl->h.xa_lds_floats * 4));
+        PC(rt_set_max_dyn_smem(pl->h.chan_global ? (const void*)k_xa<false, true>
+                               : pl->h.wst_floats > 0 ? (const void*)k_xa<true, false> : (const void*)k_xa<false, false>,
+                               (size_t)pl->h.xa_lds_floats * 4));
     if (pl->fused_r2 && pl->r2_lds > 64 * 1024) {
         const int MT = (E + 15) / 16;
         const bool aff = pl->h.f_affine != 0, gen1 = pl->h.h_L > 1 && pl->h.hl[0].mval.n > 1;
@@ -204,7 +206,7 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
 // ---------------- workspace ----------------
 struct Workspace {
     unsigned long long* offbits;
-    float *H, *P0, *P1, *acoef, *net_x, *net_adj, *net_r, *norm2, *part, *sums;
+    float *H, *P0, *P1, *acoef, *net_x, *net_adj, *net_r, *norm2, *part, *sums, *chan;
     int ntiles;
     size_t bytes;
 };
@@ -226,6 +228,7 @@ static Workspace carve_ws(const ccsd_plan* pl, int B, void* base) {
     w.ntiles = p.is_cc ? ((p.K + T_BN - 1) / T_BN) * ((p.E + T_BM - 1) / T_BM) : 0;
     w.part = (float*)take((size_t)B * (w.ntiles ? w.ntiles : 1) * 2 * 4);
     w.sums = (float*)take(64);
+    w.chan = (float*)take(p.chan_global ? (size_t)B * p.a_fdim * p.N * p.N * 4 : 0);
     w.bytes = o;
     return w;
 }
@@ -298,13 +301,16 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
     return CCSD_OK;
 }
 static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Workspace& w, void* stream) {
-    xa.P0 = w.P0; xa.P1 = w.P1; xa.dbg = pl->dbg ? pl->dbg + 16 : nullptr;
+    xa.P0 = w.P0; xa.P1 = w.P1; xa.chan_ws = w.chan; xa.dbg = pl->dbg ? pl->dbg + 16 : nullptr;
     prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
-    if (pl->h.wst_floats > 0)
-        CCSD_LAUNCH(k_xa<true>, dim3(B), dim3(CCSD_NTHREADS == 1 ? 1 : 512), (size_t)pl->h.xa_lds_floats * 4, stream,
+    if (pl->h.chan_global)
+        CCSD_LAUNCH((k_xa<false, true>), dim3(B), dim3(CCSD_NTHREADS == 1 ? 1 : 512), (size_t)pl->h.xa_lds_floats * 4, stream,
+                    (const PlanD*)pl->d, (const float*)pl->w, (const unsigned char*)pl->edges, xa, na);
+    else if (pl->h.wst_floats > 0)
+        CCSD_LAUNCH((k_xa<true, false>), dim3(B), dim3(CCSD_NTHREADS == 1 ? 1 : 512), (size_t)pl->h.xa_lds_floats * 4, stream,
                     (const PlanD*)pl->d, (const float*)pl->w, (const unsigned char*)pl->edges, xa, na);
     else
-        CCSD_LAUNCH(k_xa<false>, dim3(B), dim3(CCSD_NTHREADS == 1 ? 1 : 512), (size_t)pl->h.xa_lds_floats * 4, stream,
+        CCSD_LAUNCH((k_xa<false, false>), dim3(B), dim3(CCSD_NTHREADS == 1 ? 1 : 512), (size_t)pl->h.xa_lds_floats * 4, stream,
                     (const PlanD*)pl->d, (const float*)pl->w, (const unsigned char*)pl->edges, xa, na);
     prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
     LAUNCH_CHECK();

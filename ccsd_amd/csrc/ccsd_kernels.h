@@ -1250,6 +1250,7 @@ struct XaArgs {
     float* out_x; float* out_a;           // SCORE: scores; NORMS: raw nets; PRED: new state
     float* mean_x; float* mean_a;         // PRED, nullable
     float* norm2;                         // NORMS: [B][4] = |net_x|^2, |net_adj|^2, |z_x|^2, |z_adj|^2
+    float* chan_ws;                       // GCH: [B][a_fdim][N*N] channel stack in the workspace
     long long* dbg;
     CorrFuse cf;
 };
@@ -1288,8 +1289,11 @@ CCSD_DEV void gcn_dinv(const float* a, float* dinv, int nc, int N) {
 
 // STAGE: every section's weights (X-network, each AttentionLayer, final MLP: contiguous blob ranges) are copied
 // into LDS once and read from there; otherwise they are read from L2 in place.
-template <bool STAGE>
-__global__ __launch_bounds__(512, STAGE ? 4 : 8) void k_xa(const PlanD* __restrict__ plan, const float* __restrict__ w,
+// GCH: the channel stack (every AttentionLayer's adjacency channels, the final MLP's input) does not fit LDS
+// (zinc250k, N = 38: 266 KB) and lives in a per-graph slab of the workspace instead; a workgroup's waves share one
+// CU and its L1, so __syncthreads() orders those global accesses exactly like the LDS ones.
+template <bool STAGE, bool GCH>
+__global__ __launch_bounds__(512, GCH ? 2 : STAGE ? 4 : 8) void k_xa(const PlanD* __restrict__ plan, const float* __restrict__ w,
                                             const unsigned char* __restrict__ edges, XaArgs xa, NoiseArgs na) {
     CCSD_DYN_SMEM(sm);
     const PlanD& p = *plan;
@@ -1396,7 +1400,7 @@ __global__ __launch_bounds__(512, STAGE ? 4 : 8) void k_xa(const PlanD* __restri
     stamp(xa.dbg, 1);
     // ================= ScoreNetworkA / ScoreNetworkA_CC =================
     if (xa.do_a) {
-        float* s_chan = sm + p.o_chan;
+        float* s_chan = GCH ? xa.chan_ws + (size_t)b * p.a_fdim * NN : sm + p.o_chan;
         float* s_att = sm + p.o_att;
         float* s_xcur = sm + p.o_xcur;
         float* s_xnext = sm + p.o_xnext;

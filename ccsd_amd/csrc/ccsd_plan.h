@@ -61,6 +61,7 @@ struct PlanD {
     int o_wst, wst_floats;      // weight staging buffer (0 floats: weights are read in place)
     int o_hw, hw_stride;        // zero-padded hodge mlp_attention weight blocks (stride between the two layers)
     int o_deg;                  // degree scratch of the dense hodge layer
+    int chan_global;            // 1: the channel stack [a_fdim][N*N] lives in the HBM workspace (large graphs), not in LDS
 };
 
 #ifndef CCSD_DEVICE_ONLY
@@ -259,8 +260,13 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     auto ld_of = [](int rows) { int r = (rows + 15) / 16 * 16; if (r % 32 == 0) r += 8; return r; };   // 2-way conflicts at worst
     int best_total = -1;
     const char* skip = getenv("CCSD_XA_PASS");
-    for (int pass = skip ? atoi(skip) : 0; pass < NCAND && best_total < 0; ++pass) {
-        if (stage_on[pass] && wst_full == 0) continue;
+    // Large graphs (zinc250k: 46 channels x 38 x 38 = 266 KB): second round of candidates with the channel stack in the
+    // HBM workspace (L2-resident, one slab per graph) and only the per-layer working set in LDS.  CCSD_XA_GCH=1 forces it.
+    const int gch_first = getenv("CCSD_XA_GCH") ? 1 : 0;
+    for (int gch = gch_first; gch < 2 && best_total < 0; ++gch)
+    for (int pass = (skip && !gch) ? atoi(skip) : 0; pass < NCAND && best_total < 0; ++pass) {
+        if (stage_on[pass] && (wst_full == 0 || gch)) continue;
+        p->chan_global = gch;
         wst = stage_on[pass] ? wst_full : 0;
         const int budget = budgets_b[pass] / 4;
         for (int cg = cinmax; cg >= 1 && best_total < 0; --cg) {
@@ -276,7 +282,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             p->o_h2 = carve(2 * p->x_fdim * p->ldn);
             const int xphase_end = o;
             o = phase0;                                                     // ... aliased by the A-network phase
-            p->o_chan = carve(p->a_fdim * NN);
+            p->o_chan = gch ? 0 : carve(p->a_fdim * NN);
             p->o_tmp = carve(cg * NN);                                      // raw attention of a channel group
             p->o_att = carve(cinmax * NN);                                  // contiguous with o_tmp (hodge scratch aliases both)
             p->o_xcur = carve(fmaxA * p->ldn);
@@ -314,7 +320,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
         }
     }
     if (getenv("CCSD_VERBOSE"))
-        fprintf(stderr, "[ccsd] k_xa LDS %d B (cg=%d pch=%d/%d pchp=%d/%d stage=%d floats)\n", best_total * 4, p->cg, p->pch, p->ldp, p->pchp, p->ldpp, p->wst_floats);
+        fprintf(stderr, "[ccsd] k_xa LDS %d B (cg=%d pch=%d/%d pchp=%d/%d stage=%d floats, channel stack in %s)\n", best_total * 4, p->cg, p->pch, p->ldp, p->pchp, p->ldpp, p->wst_floats, p->chan_global ? "HBM" : "LDS");
     if (best_total < 0 || (size_t)best_total * 4 > 160 * 1024)
         pb.fail(CCSD_ERR_UNSUPPORTED, "graph-network working set exceeds the 160 KB LDS of a CU");
     return nweights;

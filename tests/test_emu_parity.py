@@ -26,6 +26,13 @@ def test_forward_community_small_cc(lib):
     pc.case_forward_vs_reference_golden("ccsd_community_small_CC", lib, DEV)
 
 
+@pytest.mark.parametrize("name", ["ccsd_enzymes_small_CC", "gdss_zinc250k"])
+def test_forward_large_nets(lib, name):
+    """ENZYMES_small_CC (E = 66 > 64: tiled rank-2 kernels, 2-linear hodge MLPs) and zinc250k (N = 38: channel stack in
+    the HBM workspace)."""
+    pc.case_forward_vs_reference_golden(name, lib, DEV)
+
+
 def test_model_objects(lib):
     pc.case_model_objects_forward(lib, DEV)
 
@@ -42,6 +49,7 @@ def test_kat_small_general_paths(lib):
     ("ccsd_qm9_CC_nsteps2_none", "ccsd_qm9_CC", "k6"),
     ("ccsd_qm9_CC_langevin2", "ccsd_qm9_CC", "k4"),
     ("ccsd_community_small_CC", "ccsd_community_small_CC", "n1000_first2"),
+    ("gdss_zinc250k", "gdss_zinc250k", "k5"),
 ])
 def test_pc_sampler_identical_seed(lib, gname, ckpt, case):
     pc.case_pc_sampler_identical_seed(gname, ckpt, case, lib, DEV)
@@ -59,9 +67,10 @@ def test_error_behaviour(lib):
     pc.case_error_behaviour(lib, DEV)
 
 
-@pytest.mark.parametrize("env", [{"CCSD_NO_FUSED_R2": "1"}, {"CCSD_XA_PASS": "1"}, {"CCSD_NO_FUSED_APPLY": "1"}])
+@pytest.mark.parametrize("env", [{"CCSD_NO_FUSED_R2": "1"}, {"CCSD_XA_PASS": "1"}, {"CCSD_NO_FUSED_APPLY": "1"}, {"CCSD_XA_GCH": "1"}])
 def test_alternative_kernel_paths_qm9(lib, env, monkeypatch):
-    """The general tiled rank-2 kernels / the LDS-staged-weights variant / the unfused apply pass on the qm9_CC cases."""
+    """The general tiled rank-2 kernels / the LDS-staged-weights variant / the unfused apply pass / the HBM channel
+    stack on the qm9_CC cases."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     pc.case_forward_vs_reference_golden("ccsd_qm9_CC", lib, DEV)

@@ -19,7 +19,8 @@ def lib():
     return L
 
 
-@pytest.mark.parametrize("name", ["ccsd_qm9_CC", "ccsd_community_small_CC", "gdss_community_small"])
+@pytest.mark.parametrize("name", ["ccsd_qm9_CC", "ccsd_community_small_CC", "gdss_community_small",
+                                  "ccsd_enzymes_small_CC", "gdss_zinc250k"])
 def test_forward_vs_reference_golden(lib, name):
     pc.case_forward_vs_reference_golden(name, lib, DEV)
 
@@ -42,6 +43,7 @@ def test_kat_small_general_paths(lib):
     ("gdss_community_small", "gdss_community_small", "n1000_first3"),
     ("ccsd_qm9_CC_nsteps2_none", "ccsd_qm9_CC", "k6"),
     ("ccsd_qm9_CC_langevin2", "ccsd_qm9_CC", "k4"),
+    ("gdss_zinc250k", "gdss_zinc250k", "k5"),
 ])
 def test_pc_sampler_identical_seed(lib, gname, ckpt, case):
     pc.case_pc_sampler_identical_seed(gname, ckpt, case, lib, DEV)
@@ -105,7 +107,8 @@ def test_full_size_qm9_philox_properties(lib):
     assert 0.5 < live.std().item() < 2.0
 
 
-@pytest.mark.parametrize("env", [{"CCSD_NO_FUSED_R2": "1"}, {"CCSD_XA_PASS": "1"}, {"CCSD_XA_PASS": "2"}, {"CCSD_NO_FUSED_APPLY": "1"}])
+@pytest.mark.parametrize("env", [{"CCSD_NO_FUSED_R2": "1"}, {"CCSD_XA_PASS": "1"}, {"CCSD_XA_PASS": "2"}, {"CCSD_NO_FUSED_APPLY": "1"},
+                                 {"CCSD_XA_GCH": "1"}])
 def test_alternative_kernel_paths_qm9(lib, env, monkeypatch):
     """qm9_CC normally takes the fused LDS-resident rank-2 kernel and the 4-workgroups/CU graph-network layout; force the
     general tiled rank-2 kernels, the LDS-staged-weights variant and the 3/CU layout through the same parity cases."""
