@@ -17,6 +17,8 @@ struct ccsd_plan {
     PlanD h;                    // host copy
     PlanD* d = nullptr;         // device copy
     float* w = nullptr;         // device weights
+    float* wp = nullptr;        // device: zero-padded copies of the chain MLPs' linears (mlp_chain_tile)
+    size_t npacked = 0;
     unsigned char* edges = nullptr;
     unsigned long long* cells = nullptr;
     std::vector<ccsd_step_coef_t> coef;  // [diff_steps][3]
@@ -109,6 +111,7 @@ extern "C" void ccsd_plan_destroy(ccsd_plan_t* plan) {
 #endif
     if (plan->d) (void)rt_free(plan->d);
     if (plan->w) (void)rt_free(plan->w);
+    if (plan->wp) (void)rt_free(plan->wp);
     if (plan->edges) (void)rt_free(plan->edges);
     if (plan->cells) (void)rt_free(plan->cells);
     delete plan;
@@ -123,6 +126,7 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     PlanBuilder pb;
     pl->nweights = ccsd_build_plan(cfg, &pl->h, pb);
     if (pb.status != CCSD_OK) { delete pl; return set_err(pb.status, pb.err); }
+    pl->npacked = (size_t)pb.pcur;
     if (pl->nweights != n_weights) {
         delete pl;
         return set_err(CCSD_ERR_WEIGHTS, "weight blob has " + std::to_string(n_weights) + " floats, config needs " +
@@ -167,6 +171,14 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     PC(rt_h2d(pl->d, &pl->h, sizeof(PlanD)));
     PC(rt_malloc((void**)&pl->w, n_weights * sizeof(float)));
     PC(rt_h2d(pl->w, weights, n_weights * sizeof(float)));
+    {
+        std::vector<float> packed(pl->npacked + 4, 0.f);
+        ccsd_pack_mlp(pl->h.x_fin, weights, packed.data());
+        for (int l = 0; l < pl->h.a_L; ++l) ccsd_pack_mlp(pl->h.al[l].mlp, weights, packed.data());
+        ccsd_pack_mlp(pl->h.a_fin, weights, packed.data());
+        PC(rt_malloc((void**)&pl->wp, packed.size() * sizeof(float)));
+        PC(rt_h2d(pl->wp, packed.data(), packed.size() * sizeof(float)));
+    }
     PC(rt_malloc((void**)&pl->edges, edges.size()));
     PC(rt_h2d(pl->edges, edges.data(), edges.size()));
     PC(rt_malloc((void**)&pl->cells, cells.size() * sizeof(unsigned long long)));
@@ -185,9 +197,7 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     }
 #ifndef CCSD_EMU
     if ((size_t)pl->h.xa_lds_floats * 4 > 64 * 1024)
-        PC(rt_set_max_dyn_smem(pl->h.chan_global ? (const void*)k_xa<false, true>
-                               : pl->h.wst_floats > 0 ? (const void*)k_xa<true, false> : (const void*)k_xa<false, false>,
-                               (size_t)pl->h.xa_lds_floats * 4));
+        PC(rt_set_max_dyn_smem(pl->h.chan_global ? (const void*)k_xa<true> : (const void*)k_xa<false>, (size_t)pl->h.xa_lds_floats * 4));
     if (pl->fused_r2 && pl->r2_lds > 64 * 1024) {
         const int MT = (E + 15) / 16;
         const bool aff = pl->h.f_affine != 0, gen1 = pl->h.h_L > 1 && pl->h.hl[0].mval.n > 1;
@@ -302,16 +312,15 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
 }
 static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Workspace& w, void* stream) {
     xa.P0 = w.P0; xa.P1 = w.P1; xa.chan_ws = w.chan; xa.dbg = pl->dbg ? pl->dbg + 16 : nullptr;
+    static const int xa_threads = getenv("CCSD_XA_THREADS") ? atoi(getenv("CCSD_XA_THREADS")) : 256;   // diagnostic: 64..512
     prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
-    if (pl->h.chan_global)
-        CCSD_LAUNCH((k_xa<false, true>), dim3(B), dim3(CCSD_NTHREADS == 1 ? 1 : 512), (size_t)pl->h.xa_lds_floats * 4, stream,
-                    (const PlanD*)pl->d, (const float*)pl->w, (const unsigned char*)pl->edges, xa, na);
-    else if (pl->h.wst_floats > 0)
-        CCSD_LAUNCH((k_xa<true, false>), dim3(B), dim3(CCSD_NTHREADS == 1 ? 1 : 512), (size_t)pl->h.xa_lds_floats * 4, stream,
-                    (const PlanD*)pl->d, (const float*)pl->w, (const unsigned char*)pl->edges, xa, na);
-    else
-        CCSD_LAUNCH((k_xa<false, false>), dim3(B), dim3(CCSD_NTHREADS == 1 ? 1 : 512), (size_t)pl->h.xa_lds_floats * 4, stream,
-                    (const PlanD*)pl->d, (const float*)pl->w, (const unsigned char*)pl->edges, xa, na);
+    xa.wp = pl->wp;
+    const dim3 xblk(CCSD_NTHREADS == 1 ? 1 : xa_threads);
+    const size_t xlds = (size_t)pl->h.xa_lds_floats * 4;
+#define XA_GO(G_) CCSD_LAUNCH((k_xa<G_>), dim3(B), xblk, xlds, stream, (const PlanD*)pl->d, (const float*)pl->w, \
+                              (const unsigned char*)pl->edges, xa, na)
+    if (pl->h.chan_global) XA_GO(true); else XA_GO(false);
+#undef XA_GO
     prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
     LAUNCH_CHECK();
     return CCSD_OK;

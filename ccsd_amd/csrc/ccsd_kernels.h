@@ -62,6 +62,13 @@ CCSD_DEV float elu1(float v) {
     if (v > -0.1f) return v * fmaf(v, fmaf(v, fmaf(v, fmaf(v, 0.00833333333f, 0.04166666667f), 0.16666666667f), 0.5f), 1.0f);
     return fast_exp(v) - 1.0f;
 }
+// same function without divergent branches (both arms evaluated, v_cndmask selects): used inside MFMA chains
+CCSD_DEV float elu1_sel(float v) {
+    const float ser = v * fmaf(v, fmaf(v, fmaf(v, fmaf(v, 0.00833333333f, 0.04166666667f), 0.16666666667f), 0.5f), 1.0f);
+    const float ex = fast_exp(v) - 1.0f;
+    const float neg = v > -0.1f ? ser : ex;
+    return v > 0.f ? v : neg;
+}
 // t / d and t % d for 0 <= t < 2^22 and small d without the ~40-instruction integer division:
 // (t + 0.5) * (1/d) is never within 0.5/d of an integer, far more than the fp32 rounding of the product.
 struct FastDiv {
@@ -293,6 +300,141 @@ CCSD_DEV void block_linear(float* Y, int ldy, const float* X, int ldx, const flo
         }
     }
 #endif
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// mlp_chain_tile: a whole MLP (layers.py:260-275; up to CCSD_MAXLIN linears, ELU between) for ONE tile of 16
+// rows, by ONE wave, with every activation held in registers -- no LDS round trip and no workgroup barrier
+// between the linears.  Transposed formulation Y^T = W . X^T on v_mfma_f32_16x16x4_f32:
+//   A operand = W (row = output feature 16*to + l15), B operand = X^T (column = row p0 + l15 of the tile),
+//   accumulator element r of lane (l15, kq) = feature 16*to + 4*kq + r of row p0 + l15.
+// The MFMA's k slot `kq` of step (t, j) is assigned to input feature 16*t + 4*kq + j: exactly the feature the lane
+// already holds in register j of the previous layer's accumulator tile t, so the next linear's B operands ARE
+// the previous accumulators; the matching A operands W[.][16t + 4kq .. +3] are one aligned float4 of the
+// zero-padded copy Wp[pad16(out)][pad16(in)] (ccsd_pack_mlp).  The first linear's input comes from LDS (or the
+// HBM channel stack), feature-major, optionally as two segments [X (k < ksplit) | X2].
+// epi(row, feature, value) is called for the valid outputs.  Tile counts are compile-time (CHAIN_SHAPES below).
+// ---------------------------------------------------------------------------------------------
+#ifndef CCSD_EMU
+typedef float chain_f32x4 __attribute__((ext_vector_type(4)));
+// one linear of the chain: TI input tiles (registers) -> TO output tiles, straight-line code
+template <int TI, int TO>
+CCSD_DEV void chain_layer(const float* __restrict__ W, const float* __restrict__ Bv, int ip, bool act,
+                          const chain_f32x4* in, chain_f32x4* out) {
+#pragma unroll
+    for (int to = 0; to < TO; ++to) {
+        const float* Wr = W + (size_t)(16 * to) * ip;
+        float4 wv[TI];
+#pragma unroll
+        for (int t = 0; t < TI; ++t) wv[t] = *reinterpret_cast<const float4*>(Wr + 16 * t);
+        const float4 bb = *reinterpret_cast<const float4*>(Bv + 16 * to);
+        chain_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < TI; ++t) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t].x, in[t][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t].y, in[t][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t].z, in[t][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t].w, in[t][3], acc, 0, 0, 0);
+        }
+        acc[0] += bb.x; acc[1] += bb.y; acc[2] += bb.z; acc[3] += bb.w;
+        if (act) { acc[0] = elu1_sel(acc[0]); acc[1] = elu1_sel(acc[1]); acc[2] = elu1_sel(acc[2]); acc[3] = elu1_sel(acc[3]); }
+        out[to] = acc;
+    }
+}
+#endif
+
+// NI / NH / NO: input / hidden / output width in 16-feature tiles (compile time: the code is branch-free)
+template <int NI, int NH, int NO, class ROWOFF, class EPI>
+CCSD_DEV void mlp_chain_tile(const MlpD& m, const float* __restrict__ wp, const float* X, int ldx, const float* X2,
+                             int ksplit, int p0, int rows, ROWOFF rowoff, EPI epi) {
+#ifdef CCSD_EMU
+    constexpr int MAXW = 16 * (NI > NH ? (NI > NO ? NI : NO) : (NH > NO ? NH : NO));
+    for (int rr = 0; rr < 16; ++rr) {
+        const int row = p0 + rr;
+        if (row >= rows) break;
+        float a[MAXW], t[MAXW];
+        for (int k = 0; k < MAXW; ++k) a[k] = 0.f;
+        const int roff = rowoff(row);
+        for (int k = 0; k < m.in; ++k) a[k] = k < ksplit ? X[k * ldx + roff] : X2[(k - ksplit) * ldx + roff];
+        for (int i = 0; i < m.n; ++i) {
+            const int ip = 16 * (i == 0 ? NI : NH), op = 16 * (i == m.n - 1 ? NO : NH);
+            const float* W = wp + m.pw[i];
+            const float* Bv = wp + m.pb[i];
+            for (int o = 0; o < op; ++o) {
+                float acc = 0.f;
+                for (int k = 0; k < ip; ++k) acc = fmaf(W[o * ip + k], a[k], acc);
+                acc += Bv[o];
+                t[o] = (i < m.n - 1) ? elu1(acc) : acc;
+            }
+            for (int o = 0; o < op; ++o) a[o] = t[o];
+        }
+        for (int f = 0; f < m.out; ++f) epi(row, f, a[f]);
+    }
+#else
+    const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+    const int prow = rowoff((p0 + l15 < rows) ? p0 + l15 : rows - 1);      // clamped: rows beyond `rows` are never stored
+    const int in = m.in;
+    chain_f32x4 xin[NI], h0[NH], h1[NH], yo[NO];
+#pragma unroll
+    for (int t = 0; t < NI; ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 16 * t + 4 * kq + j;
+            const int kc = k < in ? k : in - 1;                    // padded features meet zero weights: any finite value
+            const float* src = kc < ksplit ? X + kc * ldx : X2 + (kc - ksplit) * ldx;
+            xin[t][j] = src[prow];
+        }
+    }
+    const size_t lo = (size_t)l15;
+    if (m.n == 1) {
+        chain_layer<NI, NO>(wp + m.pw[0] + lo * (16 * NI) + 4 * kq, wp + m.pb[0] + 4 * kq, 16 * NI, false, xin, yo);
+    } else {
+        chain_layer<NI, NH>(wp + m.pw[0] + lo * (16 * NI) + 4 * kq, wp + m.pb[0] + 4 * kq, 16 * NI, true, xin, h0);
+        for (int i = 1; i < m.n - 1; ++i) {
+            chain_layer<NH, NH>(wp + m.pw[i] + lo * (16 * NH) + 4 * kq, wp + m.pb[i] + 4 * kq, 16 * NH, true, h0, h1);
+#pragma unroll
+            for (int t = 0; t < NH; ++t) h0[t] = h1[t];
+        }
+        const int il = m.n - 1;
+        if (NO == 1 && m.out == 1) {
+            // a single output feature: 16 of 16 MFMA rows would be padding -- dot product on the VALU instead; the lane
+            // holds features 16t + 4kq + r of its row, the four kq groups are summed with two cross-lane adds
+            const float* W3 = wp + m.pw[il] + 4 * kq;
+            float d = 0.f;
+#pragma unroll
+            for (int t = 0; t < NH; ++t) {
+                const float4 wv = *reinterpret_cast<const float4*>(W3 + 16 * t);
+                d = fmaf(wv.x, h0[t][0], d); d = fmaf(wv.y, h0[t][1], d); d = fmaf(wv.z, h0[t][2], d); d = fmaf(wv.w, h0[t][3], d);
+            }
+            d += __shfl_xor(d, 16, 64);
+            d += __shfl_xor(d, 32, 64);
+            d += wp[m.pb[il]];
+            if (kq == 0 && p0 + l15 < rows) epi(p0 + l15, 0, d);
+            return;
+        }
+        chain_layer<NH, NO>(wp + m.pw[il] + lo * (16 * NH) + 4 * kq, wp + m.pb[il] + 4 * kq, 16 * NH, false, h0, yo);
+    }
+    const bool rok = p0 + l15 < rows;
+#pragma unroll
+    for (int to = 0; to < NO; ++to)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = 16 * to + 4 * kq + r;
+            if (f < m.out && rok) epi(p0 + l15, f, yo[to][r]);
+        }
+#endif
+}
+// all 16-row tiles of `rows`, round-robin over the waves of the workgroup
+template <int NI, int NH, int NO, class ROWOFF, class EPI>
+CCSD_DEV void mlp_chain(const MlpD& m, const float* __restrict__ wp, const float* X, int ldx, const float* X2, int ksplit,
+                        int rows, ROWOFF rowoff, EPI epi) {
+#ifdef CCSD_EMU
+    const int wave = 0, nw = 1;
+#else
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#endif
+    for (int tile = wave; tile < (rows + 15) >> 4; tile += nw) mlp_chain_tile<NI, NH, NO>(m, wp, X, ldx, X2, ksplit, 16 * tile, rows, rowoff, epi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1251,6 +1393,7 @@ struct XaArgs {
     float* mean_x; float* mean_a;         // PRED, nullable
     float* norm2;                         // NORMS: [B][4] = |net_x|^2, |net_adj|^2, |z_x|^2, |z_adj|^2
     float* chan_ws;                       // GCH: [B][a_fdim][N*N] channel stack in the workspace
+    const float* wp;                      // packed (zero-padded) chain-MLP weights
     long long* dbg;
     CorrFuse cf;
 };
@@ -1287,13 +1430,12 @@ CCSD_DEV void gcn_dinv(const float* a, float* dinv, int nc, int N) {
     }
 }
 
-// STAGE: every section's weights (X-network, each AttentionLayer, final MLP: contiguous blob ranges) are copied
-// into LDS once and read from there; otherwise they are read from L2 in place.
 // GCH: the channel stack (every AttentionLayer's adjacency channels, the final MLP's input) does not fit LDS
 // (zinc250k, N = 38: 266 KB) and lives in a per-graph slab of the workspace instead; a workgroup's waves share one
 // CU and its L1, so __syncthreads() orders those global accesses exactly like the LDS ones.
-template <bool STAGE, bool GCH>
-__global__ __launch_bounds__(512, GCH ? 2 : STAGE ? 4 : 8) void k_xa(const PlanD* __restrict__ plan, const float* __restrict__ w,
+// Weights are read in place from L2.
+template <bool GCH>
+__global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict__ plan, const float* __restrict__ w,
                                             const unsigned char* __restrict__ edges, XaArgs xa, NoiseArgs na) {
     CCSD_DYN_SMEM(sm);
     const PlanD& p = *plan;
@@ -1307,20 +1449,7 @@ __global__ __launch_bounds__(512, GCH ? 2 : STAGE ? 4 : 8) void k_xa(const PlanD
     float* s_red = sm + p.o_red;
     float* s_R = sm + p.o_c0;            // shared region: GCN scratch | MLP hidden activations | dense hodge layer
     const FastDiv dN(N), dNN(NN), dF(F), dE(E > 0 ? E : 1);
-    float* s_wst = sm + p.o_wst;
-    // copy blob range [lo, hi) into LDS and return a pointer that is indexed with the ORIGINAL blob offsets
-    auto stage_w = [&](int lo, int hi) -> const float* {
-        if (!STAGE) return w;
-        const int n = hi - lo;
-        for (int base = tid; base < n; base += 8 * nth) {     // eight independent (clamped, unpredicated) loads in flight
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const int t = base + u * nth; v[u] = w[lo + (t < n ? t : n - 1)]; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const int t = base + u * nth; if (t < n) s_wst[t] = v[u]; }
-        }
-        return s_wst - lo;
-    };
+    const float* wp = xa.wp;
 
     stamp(xa.dbg, 0);
     for (int i = tid; i < N; i += nth) s_flags[i] = xa.flags[(size_t)b * N + i];
@@ -1332,7 +1461,7 @@ __global__ __launch_bounds__(512, GCH ? 2 : STAGE ? 4 : 8) void k_xa(const PlanD
         float* s_h1 = sm + p.o_h1;
         float* s_h2 = sm + p.o_h2;
         float* s_xw = s_R;
-        const float* wx = stage_w(p.x_wlo, p.x_whi);   // visible after the barrier below
+        const float* wx = w;
         for (int i = tid; i < N * F; i += nth) s_x[i] = xa.xX[(size_t)b * N * F + i];
         for (int i = tid; i < NN; i += nth) s_adj[i] = xa.adjX[(size_t)b * NN + i];
         if (xa.cf.on) { __syncthreads(); corr_apply_xa(xa.cf, na, b, N, F, s_x, s_adj, s_flags); }
@@ -1367,11 +1496,18 @@ __global__ __launch_bounds__(512, GCH ? 2 : STAGE ? 4 : 8) void k_xa(const PlanD
             __syncthreads();
         }
         const MlpD& m = p.x_fin;
-        block_linear<1>(s_h1, ldn, s_xcat, ldn, s_xcat, m.in, wx + m.w[0], wx + m.b[0], m.in, m.hid, N);
-        __syncthreads();
-        block_linear<1>(s_h2, ldn, s_h1, ldn, s_h1, m.hid, wx + m.w[1], wx + m.b[1], m.hid, m.hid, N);
-        __syncthreads();
-        block_linear<0>(s_h1, ldn, s_h2, ldn, s_h2, m.hid, wx + m.w[2], wx + m.b[2], m.hid, m.out, N);
+        if (m.chain) {
+            auto epx = [&](int row, int f, float v) { s_h1[f * ldn + row] = v; };
+            auto ident = [](int r) { return r; };
+            if (m.chain == 2) mlp_chain<2, 3, 1>(m, wp, s_xcat, ldn, s_xcat, m.in, N, ident, epx);
+            else mlp_chain<3, 6, 1>(m, wp, s_xcat, ldn, s_xcat, m.in, N, ident, epx);
+        } else {
+            block_linear<1>(s_h1, ldn, s_xcat, ldn, s_xcat, m.in, wx + m.w[0], wx + m.b[0], m.in, m.hid, N);
+            __syncthreads();
+            block_linear<1>(s_h2, ldn, s_h1, ldn, s_h1, m.hid, wx + m.w[1], wx + m.b[1], m.hid, m.hid, N);
+            __syncthreads();
+            block_linear<0>(s_h1, ldn, s_h2, ldn, s_h2, m.hid, wx + m.w[2], wx + m.b[2], m.hid, m.out, N);
+        }
         __syncthreads();
         for (int t = tid; t < N * F; t += nth) {
             int i, f;
@@ -1401,6 +1537,7 @@ __global__ __launch_bounds__(512, GCH ? 2 : STAGE ? 4 : 8) void k_xa(const PlanD
     // ================= ScoreNetworkA / ScoreNetworkA_CC =================
     if (xa.do_a) {
         float* s_chan = GCH ? xa.chan_ws + (size_t)b * p.a_fdim * NN : sm + p.o_chan;
+        auto pair_off = [&](int e) { return (int)edges[2 * e] * N + (int)edges[2 * e + 1]; };   // unordered pair e -> (i, j), i < j
         float* s_att = sm + p.o_att;
         float* s_xcur = sm + p.o_xcur;
         float* s_xnext = sm + p.o_xnext;
@@ -1443,8 +1580,7 @@ __global__ __launch_bounds__(512, GCH ? 2 : STAGE ? 4 : 8) void k_xa(const PlanD
             const int cols = 2 * L.adim + L.fout;
             const FastDiv dcols(cols), dNcols(N * cols);
             const float inv_scale = (float)sqrt((double)L.fout);  // attention.py:121: / math.sqrt(out_dim)
-            const float* wl = stage_w(L.w_lo, L.w_hi);
-            if (STAGE) __syncthreads();
+            const float* wl = w;
             // multi_channel MLP, first Linear: its input is cat_c V_c, accumulated group by group
             for (int t = tid; t < L.mc.hid * N; t += nth) { int hh, i; dN.divmod(t, hh, i); s_mch[hh * ldn + i] = wl[L.mc.b[0] + hh]; }
             for (int c0 = 0; c0 < L.cin; c0 += p.cg) {
@@ -1531,6 +1667,21 @@ __global__ __launch_bounds__(512, GCH ? 2 : STAGE ? 4 : 8) void k_xa(const PlanD
             const int pc = p.pchp, ldpp = p.ldpp;
             float* hb0 = s_R;
             float* hb1 = s_R + p.pw_pair * ldpp;
+            if (L.mlp.chain) {
+                // whole edge MLP per 16-pair tile in registers; the node MLP's second Linear shares the interval
+                // Every channel is a symmetric matrix and the diagonal never reaches an output (DenseGCNConv overwrites it,
+                // the final MLP masks it, the hodge branch takes triu(1)): evaluate the MLP on the E unordered pairs only and
+                // write  (_adj + _adj^T) * mask  (attention.py:301-302) to both halves from the epilogue.
+                mlp_chain<1, 1, 1>(L.mlp, wp, s_att, NN, adj_in, L.cin, E, pair_off,
+                                   [&](int e, int f, float v) {
+                                       const int i = edges[2 * e], j = edges[2 * e + 1];
+                                       const float sv = (v + v) * s_flags[i] * s_flags[j];
+                                       chan_out[f * NN + i * N + j] = sv;
+                                       chan_out[f * NN + j * N + i] = sv;
+                                   });
+                block_linear<0>(s_xnext, ldn, s_mch, ldn, s_mch, L.mc.hid, wl + L.mc.w[1], wl + L.mc.b[1], L.mc.hid, L.mc.out, N);
+                __syncthreads();
+            } else
             for (int p0 = 0; p0 < NN; p0 += pc) {
                 const int rows = (NN - p0) < pc ? (NN - p0) : pc;
                 const float* cur = s_att + p0; const float* cur2 = adj_in + p0; int ldc = NN, ksp = L.cin;
@@ -1549,6 +1700,7 @@ __global__ __launch_bounds__(512, GCH ? 2 : STAGE ? 4 : 8) void k_xa(const PlanD
             }
             if (l < 3) stamp(xa.dbg, 4 + 3 * l);
             // _adj + _adj^T, then mask_adjs (attention.py:301-302), in place per unordered pair; node tanh/mask
+            if (!L.mlp.chain)
             for (int t = tid; t < L.cout * NN; t += nth) {
                 int o, ij, i, j;
                 dNN.divmod(t, o, ij);
@@ -1742,19 +1894,29 @@ __global__ __launch_bounds__(512, GCH ? 2 : STAGE ? 4 : 8) void k_xa(const PlanD
         stamp(xa.dbg, 13);
         // ---- final MLP over every (i,j) on [graph channels | hodge channels]  (ScoreNetwork_A_CC.py:318-331)
         const MlpD& m = p.a_fin;
-        const float* wf = stage_w(m.w[0], m.b[2] + 1);
-        if (STAGE) __syncthreads();
-        const int fc = p.pch, ldf = p.ldp;
+        const float* wf = w;
+        const int fc = m.chain ? NN : p.pch, ldf = p.ldp;
         float* f0 = s_R;
         float* f1 = s_R + m.hid * ldf;
         for (int p0 = 0; p0 < NN; p0 += fc) {
             const int rows = (NN - p0) < fc ? (NN - p0) : fc;
-            block_linear<1>(f0, ldf, s_chan + p0, NN, s_chan + p0, m.in, wf + m.w[0], wf + m.b[0], m.in, m.hid, rows);
+            if (m.chain) {
+                // symmetric input channels, masked diagonal: the E unordered pairs suffice (see the edge MLP above)
+                auto epf = [&](int e, int f, float v) { (void)f; const int i = edges[2 * e], j = edges[2 * e + 1]; f0[i * N + j] = v; f0[j * N + i] = v; };
+                if (m.chain == 3) mlp_chain<2, 4, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
+                else if (m.chain == 4) mlp_chain<3, 5, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
+                else if (m.chain == 5) mlp_chain<3, 6, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
+                else mlp_chain<4, 7, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
+                stamp(xa.dbg, 11);
+            } else {
+                block_linear<1>(f0, ldf, s_chan + p0, NN, s_chan + p0, m.in, wf + m.w[0], wf + m.b[0], m.in, m.hid, rows);
+                __syncthreads();
+                block_linear<1>(f1, ldf, f0, ldf, f0, m.hid, wf + m.w[1], wf + m.b[1], m.hid, m.hid, rows);
+                __syncthreads();
+                block_linear<0>(f0, ldf, f1, ldf, f1, m.hid, wf + m.w[2], wf + m.b[2], m.hid, 1, rows);
+            }
             __syncthreads();
-            block_linear<1>(f1, ldf, f0, ldf, f0, m.hid, wf + m.w[1], wf + m.b[1], m.hid, m.hid, rows);
-            __syncthreads();
-            block_linear<0>(f0, ldf, f1, ldf, f1, m.hid, wf + m.w[2], wf + m.b[2], m.hid, 1, rows);
-            __syncthreads();
+            stamp(xa.dbg, 15);
             for (int r = tid; r < rows; r += nth) {
                 const int ij = p0 + r;
                 int i, j;

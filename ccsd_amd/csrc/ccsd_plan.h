@@ -16,7 +16,19 @@
 struct MlpD {
     int n, in, hid, out;
     int w[CCSD_MAXLIN], b[CCSD_MAXLIN];
+    // register-resident chain (mlp_chain_tile): chain = index into CCSD_CHAIN_SHAPES (0: not chained, block_linear
+    // path); offsets of the zero-padded copies Wp[16*to][16*ti], bp[16*to] of every linear in the packed weight buffer,
+    // padded to the chosen shape's tile counts
+    int chain;
+    int pw[CCSD_MAXLIN], pb[CCSD_MAXLIN];
 };
+// (input, hidden, output) widths in 16-feature tiles the chain is instantiated for (index 0 = none)
+#define CCSD_NSHAPES 7
+static const int CCSD_CHAIN_SHAPES[CCSD_NSHAPES][3] = {{0, 0, 0}, {1, 1, 1}, {2, 3, 1}, {2, 4, 1}, {3, 5, 1}, {3, 6, 1}, {4, 7, 1}};
+#define CCSD_CHAIN_EDGE 0x02u      /* shapes allowed per call site (bit = shape index) */
+#define CCSD_CHAIN_XFIN 0x24u
+#define CCSD_CHAIN_AFIN 0x78u
+static inline __host__ __device__ int pad16(int v) { return (v + 15) & ~15; }
 // dims of linear i of an MlpD
 static inline __host__ __device__ int mlp_in(const MlpD& m, int i) { return i == 0 ? m.in : m.hid; }
 static inline __host__ __device__ int mlp_out(const MlpD& m, int i) { return i == m.n - 1 ? m.out : m.hid; }
@@ -88,6 +100,9 @@ static inline void ccsd_dims(const ccsd_config_t* c, int* E, int64_t* K) {
 
 struct PlanBuilder {
     int cur = 0;
+    int pcur = 0;     // packed (chain) weight buffer
+    // reserve padded copies of an MLP's linears for mlp_chain_tile
+    void chainify(MlpD& m, unsigned allowed);
     std::string err;
     int status = CCSD_OK;
     int take(int64_t n) {
@@ -109,6 +124,35 @@ struct PlanBuilder {
         return m;
     }
 };
+
+inline void PlanBuilder::chainify(MlpD& m, unsigned allowed) {
+    m.chain = 0;
+    if (getenv("CCSD_NO_CHAIN")) return;
+    const int ni = pad16(m.in) / 16, nh = m.n > 1 ? pad16(m.hid) / 16 : 1, no = pad16(m.out) / 16;
+    for (int sidx = 1; sidx < CCSD_NSHAPES && !m.chain; ++sidx) {
+        const int* sh = CCSD_CHAIN_SHAPES[sidx];
+        if (((allowed >> sidx) & 1u) && sh[0] >= ni && sh[1] >= nh && sh[2] >= no) m.chain = sidx;
+    }
+    if (!m.chain) return;
+    const int* sh = CCSD_CHAIN_SHAPES[m.chain];
+    for (int i = 0; i < m.n; ++i) {
+        const int ip = 16 * (i == 0 ? sh[0] : sh[1]), op = 16 * (i == m.n - 1 ? sh[2] : sh[1]);
+        m.pw[i] = pcur; pcur += op * ip;
+        m.pb[i] = pcur; pcur += op;
+    }
+}
+// zero-padded copies of a chain MLP's linears (torch layout [out][in]) into the packed buffer
+static inline void ccsd_pack_mlp(const MlpD& m, const float* w, float* packed) {
+    if (!m.chain) return;
+    const int* sh = CCSD_CHAIN_SHAPES[m.chain];
+    for (int i = 0; i < m.n; ++i) {
+        const int in = i == 0 ? m.in : m.hid, out = i == m.n - 1 ? m.out : m.hid, ip = 16 * (i == 0 ? sh[0] : sh[1]);
+        for (int o = 0; o < out; ++o) {
+            for (int k = 0; k < in; ++k) packed[m.pw[i] + o * ip + k] = w[m.w[i] + o * in + k];
+            packed[m.pb[i] + o] = w[m.b[i] + o];
+        }
+    }
+}
 
 static inline int round_ld(int rows) {  // multiple of 16, and == 16 mod 32 (conflict-free MFMA A-fragment reads)
     int r = (rows + 15) / 16 * 16;
@@ -137,6 +181,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     }
     p->x_wlo = p->x_gw[0];
     p->x_fin = pb.mlp(3, p->x_fdim, 2 * p->x_fdim, F);
+    pb.chainify(p->x_fin, CCSD_CHAIN_XFIN);
     p->x_whi = pb.cur;
     // ---- ScoreNetworkA graph branch
     if (c->a_num_layers < 1 || c->a_num_layers > CCSD_MAXL) { pb.fail(CCSD_ERR_UNSUPPORTED, "a_num_layers out of range"); return 0; }
@@ -160,6 +205,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
         a.w_lo = a.attn_base;
         const int hid = 2 * (a.cin > a.cout ? a.cin : a.cout);
         a.mlp = pb.mlp(c->a_num_linears, 2 * a.cin, hid, a.cout);
+        pb.chainify(a.mlp, CCSD_CHAIN_EDGE);
         a.mc = pb.mlp(2, a.cin * a.fout, hid, a.fout);
         a.w_hi = pb.cur;
     }
@@ -199,6 +245,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     }
     p->a_fdim = p->a_nch_graph + p->a_nch_hodge;
     p->a_fin = pb.mlp(3, p->a_fdim, 2 * p->a_fdim, 1);
+    pb.chainify(p->a_fin, CCSD_CHAIN_AFIN);
     // ---- ScoreNetworkF
     if (c->is_cc) {
         if (c->f_num_layers < 1 || c->f_num_layers > CCSD_MAXFL) { pb.fail(CCSD_ERR_UNSUPPORTED, "f_num_layers out of range"); return 0; }
@@ -244,17 +291,14 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
         if (E > NN) { pb.fail(CCSD_ERR_UNSUPPORTED, "E > N*N"); return 0; }
     }
     // weight staging: largest section (X-network, one AttentionLayer, final MLP); only when it is small
-    int wst = p->x_whi - p->x_wlo;
-    for (int l = 0; l < p->a_L; ++l) if (p->al[l].w_hi - p->al[l].w_lo > wst) wst = p->al[l].w_hi - p->al[l].w_lo;
-    if (p->a_fin.b[2] + 1 - p->a_fin.w[0] > wst) wst = p->a_fin.b[2] + 1 - p->a_fin.w[0];
-    if (wst > 8192 || getenv("CCSD_NO_STAGE")) wst = 0;
+    int wst = 0;   // (weights are read in place from L2; the LDS-staged variant is gone)
     // Candidate LDS budgets, best first: 4 workgroups/CU reading weights from L2 (32 waves/CU hide the latency of the
     // ~45 barrier-separated phases best); 2/CU with the weights staged in LDS; 3/CU; then whatever fits in one CU.
     // Within a budget take the largest channel group / chunk sizes.  CCSD_XA_PASS=<n> skips the first n candidates.
     const int wst_full = wst;
-    const int NCAND = 6;
-    const int budgets_b[NCAND] = {40960, 79 * 1024, 53 * 1024, 79 * 1024, 152 * 1024, 152 * 1024};
-    const int stage_on[NCAND] = {0, 1, 0, 0, 1, 0};
+    const int NCAND = 4;
+    const int budgets_b[NCAND] = {40960, 53 * 1024, 79 * 1024, 152 * 1024};
+    const int stage_on[NCAND] = {0, 0, 0, 0};
     int hw_n = 1;
     for (int l = 0; l < p->h_L; ++l) if (p->hl[l].matt.n > hw_n) hw_n = p->hl[l].matt.n;
     auto ld_of = [](int rows) { int r = (rows + 15) / 16 * 16; if (r % 32 == 0) r += 8; return r; };   // 2-way conflicts at worst
@@ -305,6 +349,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             int rmin = 2 * cg * N * colmax;
             if (N * c->x_nhid > rmin) rmin = N * c->x_nhid;
             if (h1m_floats > rmin) rmin = h1m_floats;
+            if (NN > rmin) rmin = NN;                                       // raw output of the chained final MLP
             if (o + rmin > budget || o + 2 * pw_fin * 16 > budget) continue;
             int pch = 16, pchp = 16;
             while (pch + 16 <= NNpad && o + 2 * pw_fin * ld_of(pch + 16) <= budget) pch += 16;

@@ -37,7 +37,5 @@ for k in sorted(lab):
     print(f"  {lab[prev]:18s} -> {lab[k]:18s} {np.median(x[:, k] - x[:, prev]):10.0f}")
     prev = k
 span = (d[:, 5].max() - d[:, 0].min())
+print("final MLP: chain (wave 0)", int(np.median(x[:, 11] - x[:, 13])), " wait barrier", int(np.median(x[:, 15] - x[:, 11])), " epilogue", int(np.median(x[:, 14] - x[:, 15])))
 print("k_r2 first-start to last-end cycles:", span, " k_xa:", x[:, 14].max() - x[:, 0].min())
-print("hodge sub-phases (slots 6..15):", [int(np.median(d[:, i + 1] - d[:, i])) for i in range(6, 15)])
-print("last sub stamp -> final MLP loop start? slot values", [int(np.median(d[:, i] - x[:, 12])) for i in range(6, 16)], "finalMLPstart", int(np.median(x[:,13]-x[:,12])))
-print("hodge start -> first sub stamp:", int(np.median(d[:, 6] - x[:, 12])))
