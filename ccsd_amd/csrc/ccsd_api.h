@@ -18,6 +18,7 @@ struct ccsd_plan {
     PlanD* d = nullptr;         // device copy
     float* w = nullptr;         // device weights
     float* wp = nullptr;        // device: zero-padded copies of the chain MLPs' linears (mlp_chain_tile)
+    unsigned char* hpairs = nullptr;   // device: (e, e2), e <= e2, row-major: unordered pairs of the dense hodge layer
     size_t npacked = 0;
     unsigned char* edges = nullptr;
     unsigned long long* cells = nullptr;
@@ -112,6 +113,7 @@ extern "C" void ccsd_plan_destroy(ccsd_plan_t* plan) {
     if (plan->d) (void)rt_free(plan->d);
     if (plan->w) (void)rt_free(plan->w);
     if (plan->wp) (void)rt_free(plan->wp);
+    if (plan->hpairs) (void)rt_free(plan->hpairs);
     if (plan->edges) (void)rt_free(plan->edges);
     if (plan->cells) (void)rt_free(plan->cells);
     delete plan;
@@ -178,6 +180,14 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
         ccsd_pack_mlp(pl->h.a_fin, weights, packed.data());
         PC(rt_malloc((void**)&pl->wp, packed.size() * sizeof(float)));
         PC(rt_h2d(pl->wp, packed.data(), packed.size() * sizeof(float)));
+    }
+    if (pl->h.h_L > 1) {
+        if (E > 255) { ccsd_plan_destroy(pl); return set_err(CCSD_ERR_UNSUPPORTED, "dense hodge layer needs E <= 255"); }
+        std::vector<unsigned char> hp;
+        for (int e = 0; e < E; ++e)
+            for (int e2 = e; e2 < E; ++e2) { hp.push_back((unsigned char)e); hp.push_back((unsigned char)e2); }
+        PC(rt_malloc((void**)&pl->hpairs, hp.size()));
+        PC(rt_h2d(pl->hpairs, hp.data(), hp.size()));
     }
     PC(rt_malloc((void**)&pl->edges, edges.size()));
     PC(rt_h2d(pl->edges, edges.data(), edges.size()));
@@ -314,7 +324,7 @@ static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Work
     xa.P0 = w.P0; xa.P1 = w.P1; xa.chan_ws = w.chan; xa.dbg = pl->dbg ? pl->dbg + 16 : nullptr;
     static const int xa_threads = getenv("CCSD_XA_THREADS") ? atoi(getenv("CCSD_XA_THREADS")) : 256;   // diagnostic: 64..512
     prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
-    xa.wp = pl->wp;
+    xa.wp = pl->wp; xa.hpairs = pl->hpairs;
     const dim3 xblk(CCSD_NTHREADS == 1 ? 1 : xa_threads);
     const size_t xlds = (size_t)pl->h.xa_lds_floats * 4;
 #define XA_GO(G_) CCSD_LAUNCH((k_xa<G_>), dim3(B), xblk, xlds, stream, (const PlanD*)pl->d, (const float*)pl->w, \

@@ -221,25 +221,31 @@ CCSD_DEV void stage_mlp_blocks(const MlpD& m, const float* __restrict__ w, float
         blk[t] = v;
     }
 }
+template <int W>   // W = 4 when every width of the MLP is <= 4 (the shipped hodge branches), else CCSD_SMALLW
 CCSD_DEV void small_mlp_lds(const float* blk, int nlin, const float* in, float* out) {
-    float a[CCSD_SMALLW], t[CCSD_SMALLW];
+    float a[W], t[W];
 #pragma unroll
-    for (int i = 0; i < CCSD_SMALLW; ++i) a[i] = in[i];
+    for (int i = 0; i < W; ++i) a[i] = in[i];
     for (int l = 0; l < nlin; ++l) {
         const float* wb = blk + l * CCSD_HWBLK;
         const bool act = l < nlin - 1;
 #pragma unroll
-        for (int o = 0; o < CCSD_SMALLW; ++o) {
+        for (int o = 0; o < W; ++o) {
             float acc = wb[64 + o];
 #pragma unroll
-            for (int i = 0; i < CCSD_SMALLW; ++i) acc = fmaf(a[i], wb[o * 8 + i], acc);
+            for (int i = 0; i < W; ++i) acc = fmaf(a[i], wb[o * 8 + i], acc);
             t[o] = act ? elu1(acc) : acc;
         }
 #pragma unroll
-        for (int i = 0; i < CCSD_SMALLW; ++i) a[i] = t[i];
+        for (int i = 0; i < W; ++i) a[i] = t[i];
     }
 #pragma unroll
-    for (int i = 0; i < CCSD_SMALLW; ++i) out[i] = a[i];
+    for (int i = 0; i < W; ++i) out[i] = a[i];
+}
+CCSD_DEV int mlp_maxw(const MlpD& m) {
+    int wd = m.in > m.out ? m.in : m.out;
+    if (m.n > 1 && m.hid > wd) wd = m.hid;
+    return wd;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1394,6 +1400,7 @@ struct XaArgs {
     float* norm2;                         // NORMS: [B][4] = |net_x|^2, |net_adj|^2, |z_x|^2, |z_adj|^2
     float* chan_ws;                       // GCH: [B][a_fdim][N*N] channel stack in the workspace
     const float* wp;                      // packed (zero-padded) chain-MLP weights
+    const unsigned char* hpairs;          // (e, e2), e <= e2: unordered pairs of the dense hodge layer
     long long* dbg;
     CorrFuse cf;
 };
@@ -1724,34 +1731,33 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
         // ---- hodge branch of ScoreNetworkA_CC (ScoreNetwork_A_CC.py:295-316)
         if (p.h_L > 0) {
             float* s_hd = sm + p.o_hd;          // [hodge channel][E]: diagonals that reach the final MLP
-            float* s_acoef = sm + p.o_acoef;
             float* s_hq = sm + p.o_hq;          // [channel][E][2*adim]
             float* s_h1m = s_R;                 // [cout0][E][E] dense output of the first hodge layer
             const float kscale = (float)sqrt((double)p.K);  // hodge_attention.py:118,122: / sqrt(out_dim), out_dim = K
+            const float rks = 1.0f / kscale;
             float* s_hw = sm + p.o_hw;         // zero-padded mlp_attention weight blocks of both hodge layers
             stage_mlp_blocks(p.hl[0].matt, w, s_hw);
             if (p.h_L > 1) stage_mlp_blocks(p.hl[1].matt, w, s_hw + p.hw_stride);
-            for (int t = tid; t < p.a_cinit * E; t += nth) {
-                int c, e;
-                dE.divmod(t, c, e);
-                const float v = s_chan[c * NN + edges[2 * e] * N + edges[2 * e + 1]];
-                s_acoef[t] = v;
-                s_hd[t] = v;  // diagonal of adj_to_hodgedual(adjc): first c_init hodge channels
-            }
-            __syncthreads();
             const HodgeLayerD& h0 = p.hl[0];
             const int qw0 = 2 * h0.adim;
             const FastDiv dqw0(qw0), dEqw0(E * qw0);
             const float* P0b = xa.P0 + (size_t)b * E * h0.wc;
-            // DenseHCNConv on a diagonal hodge adjacency (hodge_layers.py:185-193): a row scaling
+            // adj_to_hodgedual (cc_utils.py:1525-1536): diagonal hodge adjacency = upper triangle of the adjacency powers;
+            // DenseHCNConv on a diagonal matrix (hodge_layers.py:185-193) is a row scaling
+            for (int t = tid; t < p.a_cinit * E; t += nth) {
+                int c, e;
+                dE.divmod(t, c, e);
+                s_hd[t] = s_chan[c * NN + pair_off(e)];
+            }
             for (int t = tid; t < h0.cin * E * qw0; t += nth) {
                 int c, r, e, d;
                 dEqw0.divmod(t, c, r);
                 dqw0.divmod(r, e, d);
-                const float a = s_acoef[c * E + e];
+                const float a = s_chan[c * NN + pair_off(e)];
                 const float g = 1.0f / sqrtf(fmaxf(a, 1.f));
                 s_hq[t] = fmaf(g * a * g, P0b[(size_t)e * h0.wc + c * qw0 + d], w[h0.bcat + c * qw0 + d]);
             }
+            const bool w4_0 = mlp_maxw(h0.matt) <= 4 && h0.cin <= 4;
             __syncthreads();
             if (p.h_L == 1) {
                 // only the diagonal is ever used (hodgedual_to_adj, cc_utils.py:1571)
@@ -1772,7 +1778,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                         }
                         in[c] = sacc;
                     }
-                    small_mlp_lds(s_hw, h0.matt.n, in, out);   // mlp_attention -> mask -> tanh -> + transpose
+                    small_mlp_lds<CCSD_SMALLW>(s_hw, h0.matt.n, in, out);   // mlp_attention -> mask -> tanh -> + transpose
                     const float fh = s_flags[edges[2 * e]] * s_flags[edges[2 * e + 1]];
 #pragma unroll
                     for (int o = 0; o < CCSD_SMALLW; ++o)
@@ -1780,11 +1786,15 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                 }
                 __syncthreads();
             } else {
-                // dense E x E attention of every channel, mlp_attention, mask, tanh, + transpose (hodge_attention.py:315-320)
-                for (int t = tid; t < E * E; t += nth) {
-                    int e, e2;
-                    dE.divmod(t, e, e2);
-                    if (e > e2) continue;                       // symmetric: compute the upper triangle, store both
+                // dense E x E attention of every channel, mlp_attention, mask, tanh, + transpose (hodge_attention.py:315-320):
+                // one thread per unordered pair (e <= e2) from the pair table, both halves stored
+                const HodgeLayerD& h1 = p.hl[1];
+                const int qw1 = 2 * h1.adim;
+                const float rnc0 = 1.0f / (float)h0.nchunk;
+                const int npair = E * (E + 1) / 2;
+                const float* P1b = xa.P1 + (size_t)b * E * h1.wc;   // [E][wc1] projections of the second layer (L2)
+                for (int t = tid; t < npair; t += nth) {
+                    const int e = xa.hpairs[2 * t], e2 = xa.hpairs[2 * t + 1];
                     float in[CCSD_SMALLW], out[CCSD_SMALLW];
 #pragma unroll
                     for (int c = 0; c < CCSD_SMALLW; ++c) {
@@ -1800,31 +1810,27 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                                     d1 = fmaf(q1[oq], q2[ok], d1);
                                     d2 = fmaf(q2[oq], q1[ok], d2);
                                 }
-                                s1 += tanh_f(d1 / kscale);
-                                s2 += tanh_f(d2 / kscale);
+                                s1 += tanh_f(d1 * rks);
+                                s2 += tanh_f(d2 * rks);
                             }
-                            v = (s1 / (float)h0.nchunk + s2 / (float)h0.nchunk) / 2.f;
+                            v = (s1 * rnc0 + s2 * rnc0) * 0.5f;
                         }
                         in[c] = v;
                     }
-                    small_mlp_lds(s_hw, h0.matt.n, in, out);
+                    if (w4_0) small_mlp_lds<4>(s_hw, h0.matt.n, in, out); else small_mlp_lds<CCSD_SMALLW>(s_hw, h0.matt.n, in, out);
                     const float fh = s_flags[edges[2 * e]] * s_flags[edges[2 * e + 1]];
                     const float fh2 = s_flags[edges[2 * e2]] * s_flags[edges[2 * e2 + 1]];
 #pragma unroll
                     for (int o = 0; o < CCSD_SMALLW; ++o)
                         if (o < h0.cout) {
                             const float tv = tanh_f(out[o] * fh * fh2);   // inputs are exactly symmetric -> h + h^T = 2h
-                            s_h1m[o * E * E + t] = tv + tv;
+                            s_h1m[o * E * E + e * E + e2] = tv + tv;
                             s_h1m[o * E * E + e2 * E + e] = tv + tv;
                             if (e == e2) s_hd[(p.a_cinit + o) * E + e] = tv + tv;
                         }
                 }
                 __syncthreads();
                 // second (last) HodgeAdjAttentionLayer: dense hodge adjacency, only the diagonal of its output
-                const HodgeLayerD& h1 = p.hl[1];
-                const int qw1 = 2 * h1.adim;
-                const FastDiv dqw1(qw1), dEqw1(E * qw1);
-                const float* P1b = xa.P1 + (size_t)b * E * h1.wc;
                 float* s_deg = sm + p.o_deg;         // [cin1][E]
                 for (int t = tid; t < h1.cin * E; t += nth) {
                     int c, e;
@@ -1838,19 +1844,33 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                     s_deg[t] = 1.0f / sqrtf(fmaxf(s0 + s1, 1.f));
                 }
                 __syncthreads();
-                for (int t = tid; t < h1.cin * E * qw1; t += nth) {
-                    int c, r, e, d;
-                    dEqw1.divmod(t, c, r);
-                    dqw1.divmod(r, e, d);
-                    const float* Hr = s_h1m + (size_t)(c * E + e) * E;
-                    const float* dg = s_deg + c * E;
-                    const float* pc1 = P1b + c * qw1 + d;
-                    float acc = 0.f;
-#pragma unroll 12
-                    for (int e2 = 0; e2 < E; ++e2) acc = fmaf(dg[e] * Hr[e2] * dg[e2], pc1[e2 * h1.wc], acc);
-                    s_hq[t] = acc + w[h1.bcat + c * qw1 + d];
+                // Q|K of the dense layer on MFMA: per channel  Y = D H D P1_c  (hodge_layers.py:185-193), tile tasks
+                // (channel, 16 rows of e) x 16 columns (2*adim <= 16 used) over the waves
+                {
+#ifdef CCSD_EMU
+                    const int wave = 0, nw = 1;
+#else
+                    const int wave = tid >> 6, nw = nth >> 6;
+#endif
+                    const int mtE = (E + 15) >> 4, ntq = (qw1 + 15) >> 4, ksE = (E + 3) >> 2;
+                    for (int task = wave; task < h1.cin * mtE * ntq; task += nw) {
+                        const int c = task / (mtE * ntq), rem = task % (mtE * ntq), rt = rem / ntq, ct = rem % ntq;
+                        const float* Hc = s_h1m + (size_t)c * E * E;
+                        const float* dg = s_deg + c * E;
+                        wave_tile(16 * rt, 16 * ct, ksE,
+                                  [&](int e, int k) { const float v = Hc[(e < E ? e : E - 1) * E + (k < E ? k : E - 1)]; return (e < E && k < E) ? v : 0.f; },
+                                  [&](int k, int d) {
+                                      const int kc = k < E ? k : E - 1, dc = d < qw1 ? d : qw1 - 1;
+                                      const float v = dg[kc] * P1b[kc * h1.wc + c * qw1 + dc];
+                                      return (k < E && d < qw1) ? v : 0.f;
+                                  },
+                                  [&](int e, int d, float acc) {
+                                      if (e < E && d < qw1) s_hq[(c * E + e) * qw1 + d] = fmaf(dg[e], acc, w[h1.bcat + c * qw1 + d]);
+                                  });
+                    }
                 }
                 __syncthreads();
+                const bool w4_1 = mlp_maxw(h1.matt) <= 4 && h1.cin <= 4;
                 for (int e = tid; e < E; e += nth) {
                     float in[CCSD_SMALLW], out[CCSD_SMALLW];
 #pragma unroll
@@ -1868,7 +1888,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                         }
                         in[c] = sacc;
                     }
-                    small_mlp_lds(s_hw + p.hw_stride, h1.matt.n, in, out);
+                    if (w4_1) small_mlp_lds<4>(s_hw + p.hw_stride, h1.matt.n, in, out); else small_mlp_lds<CCSD_SMALLW>(s_hw + p.hw_stride, h1.matt.n, in, out);
                     const float fh = s_flags[edges[2 * e]] * s_flags[edges[2 * e + 1]];
 #pragma unroll
                     for (int o = 0; o < CCSD_SMALLW; ++o)
@@ -1877,16 +1897,13 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                 __syncthreads();
             }
             // hodgedual_to_adj (cc_utils.py:1552-1588): scatter the diagonals behind the graph channels
-            for (int t = tid; t < p.a_nch_hodge * NN; t += nth) {
-                int c, ij, i, j;
-                dNN.divmod(t, c, ij);
-                dN.divmod(ij, i, j);
-                float v = 0.f;
-                if (i != j) {
-                    const int lo = i < j ? i : j, hi = i < j ? j : i;
-                    v = s_hd[c * E + lo * N - lo * (lo + 1) / 2 + (hi - lo - 1)];   // row-major triu index
-                }
-                s_chan[(p.a_nch_graph + c) * NN + ij] = v;
+            for (int t = tid; t < p.a_nch_hodge * E; t += nth) {
+                int c, e;
+                dE.divmod(t, c, e);
+                const int i = edges[2 * e], j = edges[2 * e + 1];
+                const float v = s_hd[t];
+                s_chan[(p.a_nch_graph + c) * NN + i * N + j] = v;
+                s_chan[(p.a_nch_graph + c) * NN + j * N + i] = v;
             }
             __syncthreads();
         }

@@ -334,7 +334,6 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             p->o_vcat = carve(mchid * p->ldn);                              // hidden layer of multi_channel
             p->o_deg = p->o_vcat;
             if (p->h_L) {
-                p->o_acoef = carve(c->a_c_init * E);
                 // the hodge branch runs after the attention stack: its Q|K scratch reuses [raw attention | attention]
                 if (hq_floats <= (cg + cinmax) * NN) p->o_hq = p->o_tmp; else p->o_hq = carve(hq_floats);
                 if (p->h_L > 1 && p->hl[1].cin * E > mchid * p->ldn) p->o_deg = carve(p->hl[1].cin * E);
@@ -350,13 +349,17 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             if (N * c->x_nhid > rmin) rmin = N * c->x_nhid;
             if (h1m_floats > rmin) rmin = h1m_floats;
             if (NN > rmin) rmin = NN;                                       // raw output of the chained final MLP
-            if (o + rmin > budget || o + 2 * pw_fin * 16 > budget) continue;
+            if (o + rmin > budget) continue;
+            bool pair_chained = true;
+            for (int l = 0; l < p->a_L; ++l) pair_chained = pair_chained && p->al[l].mlp.chain != 0;
+            const bool fin_chained = p->a_fin.chain != 0;
+            if (!fin_chained && o + 2 * pw_fin * 16 > budget) continue;
             int pch = 16, pchp = 16;
-            while (pch + 16 <= NNpad && o + 2 * pw_fin * ld_of(pch + 16) <= budget) pch += 16;
-            while (pchp + 16 <= NNpad && o + 2 * pw_pair * ld_of(pchp + 16) <= budget) pchp += 16;
+            while (!fin_chained && pch + 16 <= NNpad && o + 2 * pw_fin * ld_of(pch + 16) <= budget) pch += 16;
+            while (!pair_chained && pchp + 16 <= NNpad && o + 2 * pw_pair * ld_of(pchp + 16) <= budget) pchp += 16;
             int r = rmin;
-            if (2 * pw_fin * ld_of(pch) > r) r = 2 * pw_fin * ld_of(pch);
-            if (2 * pw_pair * ld_of(pchp) > r) r = 2 * pw_pair * ld_of(pchp);
+            if (!fin_chained && 2 * pw_fin * ld_of(pch) > r) r = 2 * pw_fin * ld_of(pch);
+            if (!pair_chained && 2 * pw_pair * ld_of(pchp) > r) r = 2 * pw_pair * ld_of(pchp);
             p->cg = cg; p->pch = pch; p->ldp = ld_of(pch); p->pchp = pchp; p->ldpp = ld_of(pchp);
             p->o_c0 = carve(r > 64 ? r : 64); p->o_c1 = p->o_c0;
             p->o_red = p->o_c0;                                              // block reductions run when R is idle
