@@ -444,6 +444,94 @@ CCSD_DEV void mlp_chain(const MlpD& m, const float* __restrict__ wp, const float
 }
 
 // ---------------------------------------------------------------------------------------------
+// gcn_tile: one 16-column tile of a DenseGCNConv (layers.py:139-158) for ALL nodes of one graph, by one wave:
+//   out[i][col] = dinv_i * sum_j A'_ij * ( dinv_j * sum_k x[j][k] W[k][col] ) + b[col],   A' = A with unit diagonal.
+// Both products run on v_mfma_f32_16x16x4_f32 and the intermediate x W never leaves registers: the first
+// product's accumulator element r of lane (l15, kq) is (node 16*tn + 4*kq + r, column l15) -- with the second
+// product's k slot kq of step (tn, j) assigned to node 16*tn + 4*kq + j it IS that product's B operand.
+// xT: LDS, feature-major [k][ldn].  A: [N][N] (LDS or the HBM channel stack).  wf(k, col) / bf(col): weight / bias.
+// NTN = ceil(N / 16) node tiles (compile time).
+// ---------------------------------------------------------------------------------------------
+template <int NTN, class WF, class BF, class OUT>
+CCSD_DEV void gcn_tile(const float* xT, int ldn, int fin, int N, const float* A, const float* dinv, int col0, int ncols,
+                       WF wf, BF bf, OUT out) {
+#ifdef CCSD_EMU
+    for (int cc = 0; cc < 16; ++cc) {
+        const int col = col0 + cc;
+        if (col >= ncols) break;
+        float xw[16 * NTN];
+        for (int j = 0; j < N; ++j) {
+            float acc = 0.f;
+            for (int k = 0; k < fin; ++k) acc = fmaf(xT[k * ldn + j], wf(k, col), acc);
+            xw[j] = acc * dinv[j];
+        }
+        for (int i = 0; i < N; ++i) {
+            float acc = 0.f;
+            for (int j = 0; j < N; ++j) acc = fmaf((i == j) ? 1.f : A[i * N + j], xw[j], acc);
+            out(i, col, fmaf(acc, dinv[i], bf(col)));
+        }
+    }
+#else
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+    const int col = col0 + l15;
+    const bool cok = col < ncols;
+    const int colc = cok ? col : ncols - 1;
+    f32x4 xw[NTN];
+#pragma unroll
+    for (int tn = 0; tn < NTN; ++tn) xw[tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int ks = (fin + 3) >> 2;
+    for (int s0 = 0; s0 < ks; ++s0) {
+        const int k = 4 * s0 + kq, kc = k < fin ? k : fin - 1;
+        const float bw = wf(kc, colc);
+        const float bv = (k < fin && cok) ? bw : 0.f;
+#pragma unroll
+        for (int tn = 0; tn < NTN; ++tn) {
+            const int j = 16 * tn + l15;
+            const float av = xT[kc * ldn + (j < N ? j : N - 1)];
+            xw[tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(j < N ? av : 0.f, bv, xw[tn], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int tn = 0; tn < NTN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * tn + 4 * kq + r;
+            const float dj = dinv[j < N ? j : N - 1];
+            xw[tn][r] = j < N ? xw[tn][r] * dj : 0.f;
+        }
+    const float bb = bf(colc);
+#pragma unroll
+    for (int ti = 0; ti < NTN; ++ti) {
+        const int i = 16 * ti + l15, ic = i < N ? i : N - 1;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tn = 0; tn < NTN; ++tn)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = 16 * tn + 4 * kq + jj, jc = j < N ? j : N - 1;
+                const float a0 = A[ic * N + jc];
+                const float av = (i < N && j < N) ? (i == j ? 1.f : a0) : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xw[tn][jj], acc, 0, 0, 0);
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int io = 16 * ti + 4 * kq + r;
+            if (io < N && cok) out(io, col, fmaf(acc[r], dinv[io], bb));
+        }
+    }
+#endif
+}
+template <class WF, class BF, class OUT>
+CCSD_DEV void gcn_tile_n(const float* xT, int ldn, int fin, int N, const float* A, const float* dinv, int col0, int ncols,
+                         WF wf, BF bf, OUT out) {
+    if (N <= 16) gcn_tile<1>(xT, ldn, fin, N, A, dinv, col0, ncols, wf, bf, out);
+    else if (N <= 32) gcn_tile<2>(xT, ldn, fin, N, A, dinv, col0, ncols, wf, bf, out);
+    else if (N <= 48) gcn_tile<3>(xT, ldn, fin, N, A, dinv, col0, ncols, wf, bf, out);
+    else gcn_tile<4>(xT, ldn, fin, N, A, dinv, col0, ncols, wf, bf, out);
+}
+
+// ---------------------------------------------------------------------------------------------
 // 64x64 output tile engine for the rank-2 contractions.  LDS slabs As[BK][TLD] (k-major, m fast)
 // and Bs[BK][TLD] (k-major, n fast); 4 waves as 2x2, each wave 32x32 = 2x2 MFMA 16x16x4 tiles.
 // ---------------------------------------------------------------------------------------------
@@ -1457,6 +1545,11 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
     float* s_R = sm + p.o_c0;            // shared region: GCN scratch | MLP hidden activations | dense hodge layer
     const FastDiv dN(N), dNN(NN), dF(F), dE(E > 0 ? E : 1);
     const float* wp = xa.wp;
+#ifdef CCSD_EMU
+    const int wave_id = 0, n_waves = 1;
+#else
+    const int wave_id = tid >> 6, n_waves = nth >> 6;
+#endif
 
     stamp(xa.dbg, 0);
     for (int i = tid; i < N; i += nth) s_flags[i] = xa.flags[(size_t)b * N + i];
@@ -1477,29 +1570,17 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
         for (int t = tid; t < N * F; t += nth) { int i, f; dF.divmod(t, i, f); s_xcat[f * ldn + i] = s_x[t]; }
         __syncthreads();
         const int H = p.x_nhid;
-        const FastDiv dH(H);
         for (int l = 0; l < p.x_depth; ++l) {
             const int fin = l ? H : F;
             const float* src = s_xcat + (l ? (F + (l - 1) * H) : 0) * ldn;
             const float* W = wx + p.x_gw[l];
             const float* B = wx + p.x_gb[l];
-            for (int t = tid; t < N * H; t += nth) {  // d_j * (x @ W)[j]
-                int j, o;
-                dH.divmod(t, j, o);
-                float acc = 0.f;
-#pragma unroll 4
-                for (int k = 0; k < fin; ++k) acc = fmaf(src[k * ldn + j], W[k * H + o], acc);
-                s_xw[t] = acc * s_dinv[j];
-            }
-            __syncthreads();
             float* dst = s_xcat + (F + l * H) * ldn;
-            for (int t = tid; t < N * H; t += nth) {  // tanh(d_i * sum_j A'_ij (.) + b)
-                int i, o;
-                dH.divmod(t, i, o);
-                float acc = 0.f;
-                for (int j = 0; j < N; ++j) acc = fmaf((i == j) ? 1.f : s_adj[i * N + j], s_xw[j * H + o], acc);
-                dst[o * ldn + i] = tanh_f(fmaf(acc, s_dinv[i], B[o]));
-            }
+            // tanh(DenseGCNConv(x, adj)) (ScoreNetwork_X.py:118-121): 16-column tiles over the waves
+            for (int ct = wave_id; ct < (H + 15) >> 4; ct += n_waves)
+                gcn_tile_n(src, ldn, fin, N, s_adj, s_dinv, 16 * ct, H,
+                           [&](int k, int col) { return W[k * H + col]; }, [&](int col) { return B[col]; },
+                           [&](int i, int col, float v) { dst[col * ldn + i] = tanh_f(v); });
             __syncthreads();
         }
         const MlpD& m = p.x_fin;
@@ -1590,58 +1671,57 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
             const float* wl = w;
             // multi_channel MLP, first Linear: its input is cat_c V_c, accumulated group by group
             for (int t = tid; t < L.mc.hid * N; t += nth) { int hh, i; dN.divmod(t, hh, i); s_mch[hh * ldn + i] = wl[L.mc.b[0] + hh]; }
+            const float rscale = 1.0f / inv_scale, ratt = 0.5f / (float)L.nchunk;
             for (int c0 = 0; c0 < L.cin; c0 += p.cg) {
                 const int gc = (L.cin - c0) < p.cg ? (L.cin - c0) : p.cg;
-                float* s_xw = s_R;
-                float* s_qkv = s_R + gc * N * cols;
+                float* s_qkv = s_R;                       // [channel of the group][node][Q | K | V]
                 const float* ac = s_chan + (L.ci0 + c0) * NN;
                 gcn_dinv(ac, s_dinv, gc, N);
                 __syncthreads();
-                for (int t = tid; t < gc * N * cols; t += nth) {  // d_j * (x @ [Wq | Wk | Wv]_c)[j]
-                    int c, r, j, col;
-                    dNcols.divmod(t, c, r);
-                    dcols.divmod(r, j, col);
+                // Q, K, V = DenseGCNConv(x, A_c) (attention.py:103-105) for every channel of the group: (channel, 16-column
+                // tile) tasks over the waves, both products of a task on MFMA (gcn_tile)
+                const int nct = (cols + 15) >> 4;
+                for (int task = wave_id; task < gc * nct; task += n_waves) {
+                    const int c = task / nct, ct = task % nct;
                     const float* wb = wl + L.attn_base + (c0 + c) * L.attn_stride;
-                    const float* W; int o, ow;
-                    if (col < L.adim) { W = wb; o = col; ow = L.adim; }
-                    else if (col < 2 * L.adim) { W = wb + L.fin * L.adim + L.adim; o = col - L.adim; ow = L.adim; }
-                    else { W = wb + 2 * (L.fin * L.adim + L.adim); o = col - 2 * L.adim; ow = L.fout; }
-                    float acc = 0.f;
-#pragma unroll 4
-                    for (int k = 0; k < L.fin; ++k) acc = fmaf(s_xcur[k * ldn + j], W[k * ow + o], acc);
-                    s_xw[t] = acc * s_dinv[c * N + j];
+                    float* qo = s_qkv + c * N * cols;
+                    const int ad = L.adim, fo = L.fout, fi = L.fin;
+                    gcn_tile_n(s_xcur, ldn, fi, N, ac + c * NN, s_dinv + c * N, 16 * ct, cols,
+                               [&](int k, int col) {
+                                   const int part = col < ad ? 0 : col < 2 * ad ? 1 : 2;
+                                   const int o = col - part * ad, ow = part == 2 ? fo : ad;
+                                   return wb[part * (fi * ad + ad) + k * ow + o];
+                               },
+                               [&](int col) {
+                                   const int part = col < ad ? 0 : col < 2 * ad ? 1 : 2;
+                                   const int o = col - part * ad;
+                                   return wb[part * (fi * ad + ad) + fi * (part == 2 ? fo : ad) + o];
+                               },
+                               [&](int i, int col, float v) { qo[i * cols + col] = v; });
                 }
                 __syncthreads();
-                for (int t = tid; t < gc * N * cols; t += nth) {  // d_i * sum_j A'_ij (.) + bias
-                    int c, r, i, col;
-                    dNcols.divmod(t, c, r);
-                    dcols.divmod(r, i, col);
-                    const float* wb = wl + L.attn_base + (c0 + c) * L.attn_stride;
-                    const float* arow = ac + c * NN + i * N;
-                    const float* xc = s_xw + c * N * cols + col;
-                    float acc = 0.f;
-#pragma unroll 4
-                    for (int j = 0; j < N; ++j) acc = fmaf((i == j) ? 1.f : arow[j], xc[j * cols], acc);
-                    const float bb = col < L.adim ? wb[L.fin * L.adim + col]
-                                   : col < 2 * L.adim ? wb[2 * L.fin * L.adim + L.adim + (col - L.adim)]
-                                                      : wb[2 * (L.fin * L.adim + L.adim) + L.fin * L.fout + (col - 2 * L.adim)];
-                    s_qkv[t] = fmaf(acc, s_dinv[c * N + i], bb);
-                }
-                __syncthreads();
-                // head chunks: tanh(Q_h K_h^T / sqrt(out_dim)), mean over chunks (attention.py:111-129)
-                for (int t = tid; t < gc * NN; t += nth) {
-                    int c, ij, i, j;
-                    dNN.divmod(t, c, ij);
-                    dN.divmod(ij, i, j);
-                    const float* q = s_qkv + c * N * cols;
-                    float sacc = 0.f;
+                // head chunks tanh(Q_h K_h^T / sqrt(out_dim)), mean over chunks, symmetrised (attention.py:111-130): one
+                // thread per (channel, unordered pair); the diagonal never reaches an output (see the edge MLP below)
+                for (int t = tid; t < gc * E; t += nth) {
+                    int c, e;
+                    dE.divmod(t, c, e);
+                    const int i = edges[2 * e], j = edges[2 * e + 1];
+                    const float* qi = s_qkv + c * N * cols + i * cols;
+                    const float* qj = s_qkv + c * N * cols + j * cols;
+                    float s1 = 0.f, s2 = 0.f;
                     for (int h = 0; h < L.nchunk; ++h) {
-                        float d = 0.f;
-                        for (int u = 0; u < L.dsplit; ++u)
-                            d = fmaf(q[i * cols + h * L.dsplit + u], q[j * cols + L.adim + h * L.dsplit + u], d);
-                        sacc += tanh_f(d / inv_scale);
+                        float d1 = 0.f, d2 = 0.f;
+                        for (int u = 0; u < L.dsplit; ++u) {
+                            const int oq = h * L.dsplit + u, ok = L.adim + oq;
+                            d1 = fmaf(qi[oq], qj[ok], d1);
+                            d2 = fmaf(qj[oq], qi[ok], d2);
+                        }
+                        s1 += tanh_f(d1 * rscale);
+                        s2 += tanh_f(d2 * rscale);
                     }
-                    s_tmp[t] = sacc / (float)L.nchunk;
+                    const float av = (s1 + s2) * ratt;
+                    s_att[(c0 + c) * NN + i * N + j] = av;
+                    s_att[(c0 + c) * NN + j * N + i] = av;
                 }
                 for (int t = tid; t < L.mc.hid * N; t += nth) {  // += W0[:, blocks of this group] . V_c
                     int hh, i;
@@ -1653,17 +1733,9 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
 #pragma unroll 4
                         for (int o = 0; o < L.fout; ++o) acc = fmaf(v[o], w0[o], acc);
                     }
+                    if (c0 + gc >= L.cin) acc = elu1(acc);   // last group: ELU of the multi_channel hidden layer
                     s_mch[hh * ldn + i] = acc;
                 }
-                __syncthreads();
-                for (int t = tid; t < gc * NN; t += nth) {  // symmetrise (attention.py:130)
-                    int c, ij, i, j;
-                    dNN.divmod(t, c, ij);
-                    dN.divmod(ij, i, j);
-                    s_att[(c0 + c) * NN + ij] = (s_tmp[t] + s_tmp[c * NN + j * N + i]) / 2.f;
-                }
-                if (c0 + gc >= L.cin)   // last group: ELU of the multi_channel hidden layer rides along
-                    for (int t = tid; t < L.mc.hid * N; t += nth) { int hh, i; dN.divmod(t, hh, i); float* q = s_mch + hh * ldn + i; *q = elu1(*q); }
                 __syncthreads();
             }
             // node update: tanh(mask_x(multi_channel(cat V_c)))  (attention.py:292-293); the first Linear of the
