@@ -178,6 +178,12 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
         ccsd_pack_mlp(pl->h.x_fin, weights, packed.data());
         for (int l = 0; l < pl->h.a_L; ++l) ccsd_pack_mlp(pl->h.al[l].mlp, weights, packed.data());
         ccsd_pack_mlp(pl->h.a_fin, weights, packed.data());
+        for (int l = 0; l < pl->h.h_L; ++l) {   // Wcat^T of the hodge projections for k_r2
+            const HodgeLayerD& h = pl->h.hl[l];
+            const int Kp = (K + 31) & ~31;
+            for (int k = 0; k < K; ++k)
+                for (int n = 0; n < h.wc; ++n) packed[(size_t)h.wcatT + (size_t)n * Kp + k] = weights[(size_t)h.wcat + (size_t)k * h.wc + n];
+        }
         PC(rt_malloc((void**)&pl->wp, packed.size() * sizeof(float)));
         PC(rt_h2d(pl->wp, packed.data(), packed.size() * sizeof(float)));
     }
@@ -197,7 +203,7 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     if (cfg->is_cc && E <= 64 && getenv("CCSD_NO_FUSED_R2") == nullptr) {
         const PlanD& p = pl->h;
         const int Kp4 = (K + 31) & ~31, Ep4 = (E + 3) & ~3;   // K zero-padded to whole 8-step MFMA batches
-        int ldk = Kp4; while ((ldk & 1) || ((ldk >> 1) & 1) == 0) ++ldk;   // ldk/2 odd: conflict-free 16x4 fragment reads
+        int ldk = Kp4; while ((ldk & 31) != 8 && (ldk & 31) != 24) ldk += 4;   // conflict-free ds_read_b128 fragment reads (16 rows x 4 k-quads)
         int ldh = Ep4 | 1;                                                 // odd stride; H fragments are read once per wave
         const size_t fl = (size_t)E * ldk + (size_t)E * ldh + 64 * 2 + (size_t)p.a_cinit * E + 3 * N * N + 64 + (Kp4 + 3) / 4 + 4;
         const bool wc_ok = true;
@@ -357,7 +363,7 @@ static int launch_r2(const ccsd_plan* pl, int B, const float* rank2, const float
     R2Args ra{};
     if (cf) ra.cf = *cf;
     ra.rank2 = rank2; ra.adj = adj; ra.flags = flags; ra.P0 = w.P0; ra.P1 = w.P1; ra.want_p = want_p;
-    ra.ldk = pl->r2_ldk; ra.ldh = pl->r2_ldh; ra.dbg = pl->dbg;
+    ra.ldk = pl->r2_ldk; ra.ldh = pl->r2_ldh; ra.dbg = pl->dbg; ra.wp = pl->wp;
     prof_mark(const_cast<ccsd_plan*>(pl), KID_R2, stream);
     const dim3 blk(CCSD_NTHREADS == 1 ? 1 : 512);
     const bool aff = pl->h.f_affine != 0, gen1 = pl->h.h_L > 1 && pl->h.hl[0].mval.n > 1;

@@ -78,6 +78,8 @@ struct FastDiv {
     CCSD_DEV void divmod(int t, int& q, int& r) const { q = div(t); r = t - q * d; }
 };
 
+template <bool V> struct BoolTag { static constexpr bool v = V; };
+
 struct NoiseArgs {
     const float* zx;
     const float* zadj;
@@ -991,6 +993,7 @@ struct R2Args {
     int want_p;            // write the hodge projections (the A-network will run on the same state)
     int ldk, ldh;
     long long* dbg;
+    const float* wp;       // packed buffer (Wcat^T of the hodge projections)
     CorrFuse cf;
 };
 
@@ -1210,127 +1213,144 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     }
 #else
     {
+        // Tile tasks over the full K, two tiles that share their A rows per wave.  The MFMA k slot kq of step j of a
+        // 16-wide k block is assigned to k = 16*blk + 4*kq + j, so a lane's A (and, for H, B) values of four steps are
+        // ONE aligned ds_read_b128 of F, and its weight values one float4 of the transposed copy Wcat^T[col][Kp].
+        // Rows / columns beyond E / wc read clamped (valid) addresses and are never stored; k >= K meets the zero
+        // padding of F.  Lists: per row tile i  [H(i, j >= i) ..., P_0(i, .)...]  and  [P_1(i, .)...] (A = F o fr).
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         const int wave = tid >> 6, nw = nth >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
-        // wave -> pairs of tasks.  H tasks first (both operands from LDS), then projection tasks (B from L2).
-        const int nP = MT * (nt0 + nt1);
-        const int pairsH = (nH + 1) >> 1, pairsP = (nP + 1) >> 1;
-        for (int pr = wave; pr < pairsH + pairsP; pr += nw) {
-            const bool isH = pr < pairsH;
-            int ti[2], tj[2], rowA[2], rowB[2], wcn[2];
-            float okA[2], okB[2], usefr[2];
-            const float* Wp[2];
-            bool live[2];
+        const int nblk = Kp4 >> 4;
+        const float* WT0 = ra.wp + h0.wcatT;
+        const float* WT1 = ra.wp + h1.wcatT;
+        int npairs = 0;
+        for (int i = 0; i < MT; ++i) npairs += (((p.f_cnum == 2 ? MT - i : 0) + nt0) + 1) / 2 + (nt1 + 1) / 2;
+        for (int pr = wave; pr < npairs; pr += nw) {
+            // decode pair -> (row tile, list, first entry)
+            int i = 0, kind = 0, first = 0, rem = pr;
+            for (;; ++i) {
+                const int na = ((p.f_cnum == 2 ? MT - i : 0) + nt0 + 1) / 2, nb = (nt1 + 1) / 2;
+                if (rem < na) { kind = 0; first = 2 * rem; break; }
+                rem -= na;
+                if (rem < nb) { kind = 1; first = 2 * rem; break; }
+                rem -= nb;
+            }
+            const int nh = p.f_cnum == 2 ? MT - i : 0;            // H tiles of this row tile
+            const int nlist = kind == 0 ? nh + nt0 : nt1;
+            const int ra_ = 16 * i + l15;
+            const float* pa = sF + (ra_ < E ? ra_ : E - 1) * ldk + 4 * kq;
+            int offB[2];                                          // H tiles: B rows of F in LDS
+            const float* wtp[2];                                  // P tiles: column of Wcat^T in global memory
+            int tcol[2], ttype[2];                                // 0 = H, 1 = P_0, 2 = P_1, -1 = none
+            bool blds[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                ti[q] = 0; tj[q] = 0; Wp[q] = w; wcn[q] = 1; usefr[q] = 0.f;
-                if (isH) {
-                    const int t = 2 * pr + q;
-                    live[q] = t < nH;
-                    int c = live[q] ? t : 0, i = 0;
-                    while (c >= MT - i) { c -= MT - i; ++i; }
-                    ti[q] = i; tj[q] = i + c;
+                const int idx = first + q;
+                const bool live = idx < nlist;
+                const int id = live ? idx : first;
+                offB[q] = 0; wtp[q] = WT0;
+                if (kind == 0 && id < nh) {
+                    tcol[q] = i + id; ttype[q] = live ? 0 : -1; blds[q] = true;
+                    const int rb_ = 16 * tcol[q] + l15;
+                    offB[q] = (rb_ < E ? rb_ : E - 1) * ldk + 4 * kq;
                 } else {
-                    const int t = 2 * (pr - pairsH) + q;
-                    live[q] = t < nP;
-                    const int tt = live[q] ? t : 0;
-                    if (tt < MT * nt0) { ti[q] = tt % MT; tj[q] = tt / MT; Wp[q] = w + h0.wcat; wcn[q] = wc0; }
-                    else { const int u = tt - MT * nt0; ti[q] = u % MT; tj[q] = u / MT; Wp[q] = w + h1.wcat; wcn[q] = wc1; usefr[q] = 1.f; }
+                    const int c = kind == 0 ? id - nh : id, wcn = kind == 0 ? wc0 : wc1;
+                    tcol[q] = c; ttype[q] = live ? (kind == 0 ? 1 : 2) : -1; blds[q] = false;
+                    const int n = 16 * c + l15;
+                    wtp[q] = (kind == 0 ? WT0 : WT1) + (size_t)(n < wcn ? n : wcn - 1) * Kp4 + 4 * kq;
                 }
-                const int ra_ = 16 * ti[q] + l15, rb_ = 16 * tj[q] + l15;
-                rowA[q] = (ra_ < E ? ra_ : E - 1) * ldk; okA[q] = (ra_ < E && live[q]) ? 1.f : 0.f;
-                rowB[q] = (rb_ < E ? rb_ : E - 1) * ldk; okB[q] = rb_ < E ? 1.f : 0.f;
             }
             f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
             float upart[2] = {0.f, 0.f};
-            if (isH) {
-                for (int s0 = 0; s0 < ks; s0 += 8) {
-                    float av[2][8], bv[2][8];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int kk = 4 * (s0 + u) + kq;            // < Kp4 <= ldk: zero padded, no predicate needed
-                            av[q][u] = sF[rowA[q] + kk] * okA[q];
-                            bv[q][u] = sF[rowB[q] + kk] * okB[q];
-                        }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u], bv[0][u], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][u], bv[1][u], acc[1], 0, 0, 0);
-                    }
-                }
-            } else {
-                // weight fragments: always-valid clamped addresses (rows >= K meet zero-padded F, columns >= wc are
-                // never stored), so the loads carry no predicate and no branch
-                float wnext[2][8];
-                int wcol[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) { const int n = 16 * tj[q] + l15; wcol[q] = n < wcn[q] ? n : wcn[q] - 1; }
-                auto load_w = [&](int q, int s0, float* dst) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        int kk = 4 * (s0 + u) + kq;
-                        kk = kk < K ? kk : K - 1;
-                        dst[u] = Wp[q][kk * wcn[q] + wcol[q]];
-                    }
+            // the k loop, specialised on where each tile's B operand lives (LDS / global) and on the masked-A kind
+            auto kloop = [&](auto L0, auto L1, auto K1) {
+                constexpr bool l0 = decltype(L0)::v, l1 = decltype(L1)::v, k1 = decltype(K1)::v;
+                auto ld0 = [&](int blk) -> float4 {
+                    if (l0) return *reinterpret_cast<const float4*>(sF + offB[0] + 16 * blk);
+                    return *reinterpret_cast<const float4*>(wtp[0] + 16 * blk);
                 };
-                load_w(0, 0, wnext[0]);
-                load_w(1, 0, wnext[1]);
-                for (int s0 = 0; s0 < ks; s0 += 8) {
-                    float av[2][8], wcur[2][8];
+                auto ld1 = [&](int blk) -> float4 {
+                    if (l1) return *reinterpret_cast<const float4*>(sF + offB[1] + 16 * blk);
+                    return *reinterpret_cast<const float4*>(wtp[1] + 16 * blk);
+                };
+                // operands of three 16-wide k blocks are kept in flight (the weights come from L2: ~500+ cycles)
+                constexpr int D = 3;
+                float4 ab[D], bb0[D], bb1[D];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q)
+                for (int u = 0; u < D; ++u) {
+                    const int bl = u < nblk ? u : nblk - 1;
+                    ab[u] = *reinterpret_cast<const float4*>(pa + 16 * bl);
+                    bb0[u] = ld0(bl); bb1[u] = ld1(bl);
+                }
+                for (int blk0 = 0; blk0 < nblk; blk0 += D) {
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) wcur[q][u] = wnext[q][u];
-                    if (s0 + 8 < ks) { load_w(0, s0 + 8, wnext[0]); load_w(1, s0 + 8, wnext[1]); }   // next batch: in flight during the MFMAs
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int kk = 4 * (s0 + u) + kq;
-                            const float f = sF[rowA[q] + kk] * okA[q];
-                            const float frk = (float)sFrb[kk];
+                    for (int u = 0; u < D; ++u) {
+                        const int blk = blk0 + u;
+                        if (blk >= nblk) break;
+                        float4 a4 = ab[u];
+                        const float4 b40 = bb0[u], b41 = bb1[u];
+                        {
+                            const int bl = blk + D < nblk ? blk + D : nblk - 1;   // clamped: a harmless reload at the tail
+                            ab[u] = *reinterpret_cast<const float4*>(pa + 16 * bl);
+                            bb0[u] = ld0(bl); bb1[u] = ld1(bl);
+                        }
+                        if (k1) {
+                            const unsigned int f4 = *reinterpret_cast<const unsigned int*>(sFrb + 16 * blk + 4 * kq);
+                            const float fr0 = (float)(f4 & 0xffu), fr1 = (float)((f4 >> 8) & 0xffu), fr2 = (float)((f4 >> 16) & 0xffu),
+                                        fr3 = (float)(f4 >> 24);
                             if (GEN1) {   // general mlp_value: rank2' element-wise on the fly (hodge_attention.py:322-323)
-                                if (usefr[q] != 0.f) {
-                                    const int r = 16 * ti[q] + l15, e = r < E ? r : E - 1;
+                                const int r = 16 * i + l15, e = r < E ? r : E - 1;
+                                float fv[4] = {a4.x, a4.y, a4.z, a4.w};
+                                const float frv[4] = {fr0, fr1, fr2, fr3};
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
                                     float iin[CCSD_SMALLW], out[CCSD_SMALLW];
 #pragma unroll
-                                    for (int c = 0; c < CCSD_SMALLW; ++c) iin[c] = c < h0.cin ? sAco[c * E + e] * f : 0.f;
+                                    for (int c = 0; c < CCSD_SMALLW; ++c) iin[c] = c < h0.cin ? sAco[c * E + e] * fv[j] : 0.f;
                                     small_mlp<CCSD_SMALLW>(h0.mval, w, iin, out);
-                                    av[q][u] = sFl[e] * out[0] * frk * okA[q];
-                                } else av[q][u] = f;
+                                    fv[j] = sFl[e] * out[0] * frv[j];
+                                }
+                                a4 = make_float4(fv[0], fv[1], fv[2], fv[3]);
                             } else {
-                                av[q][u] = f * fmaf(usefr[q], frk - 1.0f, 1.0f);     // f * frk for P_1, f for P_0
+                                a4.x *= fr0; a4.y *= fr1; a4.z *= fr2; a4.w *= fr3;
+                                upart[0] = fmaf(fr0, b40.x, fmaf(fr1, b40.y, fmaf(fr2, b40.z, fmaf(fr3, b40.w, upart[0]))));
+                                upart[1] = fmaf(fr0, b41.x, fmaf(fr1, b41.y, fmaf(fr2, b41.z, fmaf(fr3, b41.w, upart[1]))));
                             }
-                            upart[q] = fmaf(frk * usefr[q], wcur[q][u], upart[q]);
                         }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u], wcur[0][u], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][u], wcur[1][u], acc[1], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b40.x, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b41.x, acc[1], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b40.y, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b41.y, acc[1], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b40.z, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b41.z, acc[1], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b40.w, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b41.w, acc[1], 0, 0, 0);
                     }
                 }
-            }
+            };
+            if (kind == 1) kloop(BoolTag<false>{}, BoolTag<false>{}, BoolTag<true>{});
+            else if (blds[0] && blds[1]) kloop(BoolTag<true>{}, BoolTag<true>{}, BoolTag<false>{});
+            else if (blds[0]) kloop(BoolTag<true>{}, BoolTag<false>{}, BoolTag<false>{});
+            else kloop(BoolTag<false>{}, BoolTag<false>{}, BoolTag<false>{});
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 float un = upart[q];                       // fr . Wcat_1 column: reduce the four k residue classes
                 un += __shfl_xor(un, 16, 64);
                 un += __shfl_xor(un, 32, 64);
-                if (!live[q]) continue;
-                const int n = 16 * tj[q] + l15;
+                if (ttype[q] < 0) continue;
+                const int n = 16 * tcol[q] + l15;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = 16 * ti[q] + 4 * kq + r;
+                    const int m = 16 * i + 4 * kq + r;
                     const float v = acc[q][r];
                     if (m >= E) continue;
-                    if (isH) {
+                    if (ttype[q] == 0) {
                         if (n < E) {
                             const float hv = (p.f_hmask && m == n) ? 0.f : v;   // hodge_mask zeroes the diagonal (cc_utils.py:964-969)
                             sH[m * ldh + n] = hv;
                             sH[n * ldh + m] = hv;
                         }
-                    } else if (usefr[q] == 0.f) {
+                    } else if (ttype[q] == 1) {
                         if (n < wc0) ra.P0[((size_t)b * E + m) * wc0 + n] = v;
                     } else if (n < wc1) {
                         // rank2'[e,k] = fl[e] fr[k] (s[e] F[e,k] + b)  ->  P_1[e,:] = fl[e] (s[e] ((F.fr) W_1)[e,:] + b (fr W_1))

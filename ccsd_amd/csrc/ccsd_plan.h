@@ -43,6 +43,7 @@ struct AttnLayerD {
 struct HodgeLayerD {
     int cin, cout, adim, dsplit, nchunk, wc;   // wc = cin*2*adim columns of Wcat
     int wcat, bcat;                             // Wcat[K][wc], bcat[wc]
+    int wcatT;                                  // packed buffer: Wcat^T [pad16(wc)][Kp], zero padded (k_r2 float4 B operands)
     MlpD mval, matt;
 };
 
@@ -232,6 +233,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             h.wc = h.cin * 2 * h.adim;
             h.wcat = pb.take((int64_t)K * h.wc);
             h.bcat = pb.take(h.wc);
+            h.wcatT = pb.pcur; pb.pcur += pad16(h.wc) * ((K + 31) & ~31);
             const int hid = 2 * (h.cin > h.cout ? h.cin : h.cout);
             h.mval = pb.mlp(c->h_num_linears, h.cin, hid, 1);
             h.matt = pb.mlp(c->h_num_linears, h.cin, hid, h.cout);
