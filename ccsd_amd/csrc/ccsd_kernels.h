@@ -92,6 +92,11 @@ struct NoiseArgs {
 // Philox4x32-10 (Salmon et al. 2011), counter = (group, sample, draw, 0), key = seed
 CCSD_DEV void philox4(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3, unsigned int k0,
                       unsigned int k1, unsigned int* out) {
+#ifndef CCSD_EMU
+    // keep the key schedule on the scalar ALU of every call: hoisted out of the callers' loops its 20 round keys
+    // exhaust the SGPRs and come back as v_readlane spill traffic inside the hot loops
+    asm volatile("" : "+s"(k0), "+s"(k1));
+#endif
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
@@ -1223,6 +1228,8 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
         const int nblk = Kp4 >> 4;
         const float* WT0 = ra.wp + h0.wcatT;
         const float* WT1 = ra.wp + h1.wcatT;
+        const bool hmask = p.f_hmask != 0;
+        const float mval_b0 = lin1 ? w[h0.mval.b[0]] : 0.f;       // fetched before the k loops
         int npairs = 0;
         for (int i = 0; i < MT; ++i) npairs += (((p.f_cnum == 2 ? MT - i : 0) + nt0) + 1) / 2 + (nt1 + 1) / 2;
         for (int pr = wave; pr < npairs; pr += nw) {
@@ -1273,8 +1280,9 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                     if (l1) return *reinterpret_cast<const float4*>(sF + offB[1] + 16 * blk);
                     return *reinterpret_cast<const float4*>(wtp[1] + 16 * blk);
                 };
-                // operands of three 16-wide k blocks are kept in flight (the weights come from L2: ~500+ cycles)
-                constexpr int D = 3;
+                // operands of four 16-wide k blocks are kept in flight (the weights come from L2: ~500+ cycles); a slot is
+                // refilled only after the MFMAs that read it have been issued, so the load lands in the same registers
+                constexpr int D = 4;
                 float4 ab[D], bb0[D], bb1[D];
 #pragma unroll
                 for (int u = 0; u < D; ++u) {
@@ -1282,51 +1290,56 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                     ab[u] = *reinterpret_cast<const float4*>(pa + 16 * bl);
                     bb0[u] = ld0(bl); bb1[u] = ld1(bl);
                 }
-                for (int blk0 = 0; blk0 < nblk; blk0 += D) {
+                auto block = [&](int u, int blk, bool refill) {
+                    float4 a4 = ab[u];
+                    const float4 b40 = bb0[u], b41 = bb1[u];
+                    if (k1) {
+                        const unsigned int f4 = *reinterpret_cast<const unsigned int*>(sFrb + 16 * blk + 4 * kq);
+                        const float fr0 = (float)(f4 & 0xffu), fr1 = (float)((f4 >> 8) & 0xffu), fr2 = (float)((f4 >> 16) & 0xffu),
+                                    fr3 = (float)(f4 >> 24);
+                        if (GEN1) {   // general mlp_value: rank2' element-wise on the fly (hodge_attention.py:322-323)
+                            const int r = 16 * i + l15, e = r < E ? r : E - 1;
+                            float fv[4] = {a4.x, a4.y, a4.z, a4.w};
+                            const float frv[4] = {fr0, fr1, fr2, fr3};
 #pragma unroll
-                    for (int u = 0; u < D; ++u) {
-                        const int blk = blk0 + u;
-                        if (blk >= nblk) break;
-                        float4 a4 = ab[u];
-                        const float4 b40 = bb0[u], b41 = bb1[u];
-                        {
-                            const int bl = blk + D < nblk ? blk + D : nblk - 1;   // clamped: a harmless reload at the tail
-                            ab[u] = *reinterpret_cast<const float4*>(pa + 16 * bl);
-                            bb0[u] = ld0(bl); bb1[u] = ld1(bl);
-                        }
-                        if (k1) {
-                            const unsigned int f4 = *reinterpret_cast<const unsigned int*>(sFrb + 16 * blk + 4 * kq);
-                            const float fr0 = (float)(f4 & 0xffu), fr1 = (float)((f4 >> 8) & 0xffu), fr2 = (float)((f4 >> 16) & 0xffu),
-                                        fr3 = (float)(f4 >> 24);
-                            if (GEN1) {   // general mlp_value: rank2' element-wise on the fly (hodge_attention.py:322-323)
-                                const int r = 16 * i + l15, e = r < E ? r : E - 1;
-                                float fv[4] = {a4.x, a4.y, a4.z, a4.w};
-                                const float frv[4] = {fr0, fr1, fr2, fr3};
+                            for (int j = 0; j < 4; ++j) {
+                                float iin[CCSD_SMALLW], out[CCSD_SMALLW];
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    float iin[CCSD_SMALLW], out[CCSD_SMALLW];
-#pragma unroll
-                                    for (int c = 0; c < CCSD_SMALLW; ++c) iin[c] = c < h0.cin ? sAco[c * E + e] * fv[j] : 0.f;
-                                    small_mlp<CCSD_SMALLW>(h0.mval, w, iin, out);
-                                    fv[j] = sFl[e] * out[0] * frv[j];
-                                }
-                                a4 = make_float4(fv[0], fv[1], fv[2], fv[3]);
-                            } else {
-                                a4.x *= fr0; a4.y *= fr1; a4.z *= fr2; a4.w *= fr3;
-                                upart[0] = fmaf(fr0, b40.x, fmaf(fr1, b40.y, fmaf(fr2, b40.z, fmaf(fr3, b40.w, upart[0]))));
-                                upart[1] = fmaf(fr0, b41.x, fmaf(fr1, b41.y, fmaf(fr2, b41.z, fmaf(fr3, b41.w, upart[1]))));
+                                for (int c = 0; c < CCSD_SMALLW; ++c) iin[c] = c < h0.cin ? sAco[c * E + e] * fv[j] : 0.f;
+                                small_mlp<CCSD_SMALLW>(h0.mval, w, iin, out);
+                                fv[j] = sFl[e] * out[0] * frv[j];
                             }
+                            a4 = make_float4(fv[0], fv[1], fv[2], fv[3]);
+                        } else {
+                            a4.x *= fr0; a4.y *= fr1; a4.z *= fr2; a4.w *= fr3;
+                            upart[0] = fmaf(fr0, b40.x, fmaf(fr1, b40.y, fmaf(fr2, b40.z, fmaf(fr3, b40.w, upart[0]))));
+                            upart[1] = fmaf(fr0, b41.x, fmaf(fr1, b41.y, fmaf(fr2, b41.z, fmaf(fr3, b41.w, upart[1]))));
                         }
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b40.x, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b41.x, acc[1], 0, 0, 0);
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b40.y, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b41.y, acc[1], 0, 0, 0);
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b40.z, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b41.z, acc[1], 0, 0, 0);
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b40.w, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b41.w, acc[1], 0, 0, 0);
                     }
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b40.x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b41.x, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b40.y, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b41.y, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b40.z, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b41.z, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b40.w, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b41.w, acc[1], 0, 0, 0);
+                    if (refill) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int bl = blk + D < nblk ? blk + D : nblk - 1;   // clamped: a harmless reload at the tail
+                        ab[u] = *reinterpret_cast<const float4*>(pa + 16 * bl);
+                        bb0[u] = ld0(bl); bb1[u] = ld1(bl);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                int blk0 = 0;
+                for (; blk0 + D <= nblk; blk0 += D) {      // branch-free body: the waits at the loop head stay counted
+#pragma unroll
+                    for (int u = 0; u < D; ++u) block(u, blk0 + u, true);
                 }
+#pragma unroll
+                for (int u = 0; u < D - 1; ++u)
+                    if (blk0 + u < nblk) block(u, blk0 + u, false);
             };
             if (kind == 1) kloop(BoolTag<false>{}, BoolTag<false>{}, BoolTag<true>{});
             else if (blds[0] && blds[1]) kloop(BoolTag<true>{}, BoolTag<true>{}, BoolTag<false>{});
@@ -1334,33 +1347,50 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
             else kloop(BoolTag<false>{}, BoolTag<false>{}, BoolTag<false>{});
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                float un = upart[q];                       // fr . Wcat_1 column: reduce the four k residue classes
-                un += __shfl_xor(un, 16, 64);
-                un += __shfl_xor(un, 32, 64);
                 if (ttype[q] < 0) continue;
                 const int n = 16 * tcol[q] + l15;
+                const int mb = 16 * i + 4 * kq;
+                if (ttype[q] == 0) {
+                    if (n < E) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = 16 * i + 4 * kq + r;
-                    const float v = acc[q][r];
-                    if (m >= E) continue;
-                    if (ttype[q] == 0) {
-                        if (n < E) {
-                            const float hv = (p.f_hmask && m == n) ? 0.f : v;   // hodge_mask zeroes the diagonal (cc_utils.py:964-969)
-                            sH[m * ldh + n] = hv;
-                            sH[n * ldh + m] = hv;
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = mb + r;
+                            if (m < E) {
+                                const float hv = (hmask && m == n) ? 0.f : acc[q][r];   // hodge_mask zeroes the diagonal (cc_utils.py:964-969)
+                                sH[m * ldh + n] = hv;
+                                sH[n * ldh + m] = hv;
+                            }
                         }
-                    } else if (ttype[q] == 1) {
-                        if (n < wc0) ra.P0[((size_t)b * E + m) * wc0 + n] = v;
-                    } else if (n < wc1) {
+                    }
+                } else if (ttype[q] == 1) {
+                    if (n < wc0) {
+                        float* dst = ra.P0 + ((size_t)b * E + mb) * wc0 + n;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (mb + r < E) dst[(size_t)r * wc0] = acc[q][r];
+                    }
+                } else {
+                    float un = upart[q];                   // fr . Wcat_1 column: reduce the four k residue classes
+                    un += __shfl_xor(un, 16, 64);
+                    un += __shfl_xor(un, 32, 64);
+                    if (n < wc1) {
                         // rank2'[e,k] = fl[e] fr[k] (s[e] F[e,k] + b)  ->  P_1[e,:] = fl[e] (s[e] ((F.fr) W_1)[e,:] + b (fr W_1))
-                        ra.P1[((size_t)b * E + m) * wc1 + n] = GEN1 ? v : sFl[m] * fmaf(sRow[m], v, w[h0.mval.b[0]] * un);
+                        float* dst = ra.P1 + ((size_t)b * E + mb) * wc1 + n;
+                        const float bu = mval_b0 * un;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = mb + r, mc = m < E ? m : E - 1;
+                            const float v = GEN1 ? acc[q][r] : sFl[mc] * fmaf(sRow[mc], acc[q][r], bu);
+                            if (m < E) dst[(size_t)r * wc1] = v;
+                        }
                     }
                 }
             }
+            if (pr == 0) stamp(ra.dbg, 6);
         }
     }
 #endif
+    stamp(ra.dbg, 7);
     __syncthreads();
 
     // ---- phase 2: (H F) per 16-column tile, ScoreNetworkF element-wise, epilogue in place in LDS.

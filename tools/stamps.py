@@ -26,6 +26,7 @@ names_r2 = ["load", "prep(masks,acoef,u)", "->phase1", "gemm tiles (H,P)", "HF+e
 print("k_r2 per-phase cycles (median over workgroups), total", np.median(d[:, 5] - d[:, 0]))
 for i in range(5):
     print(f"  {names_r2[i]:24s} {np.median(d[:, i + 1] - d[:, i]):10.0f}")
+print("phase 1 (wave 0): k loop + epilogue", int(np.median(d[:, 6] - d[:, 2])), " loop exit", int(np.median(d[:, 7] - d[:, 6])), " barrier wait", int(np.median(d[:, 3] - d[:, 7])))
 x = d[:, 16:]
 lab = {0: "start", 1: "X-net done", 2: "L0 start", 3: "L0 gcn/att done", 4: "L0 edge MLP done", 5: "L1 start", 6: "L1 gcn/att done",
        7: "L1 edge MLP done", 8: "L2 start", 9: "L2 gcn/att done", 10: "L2 edge MLP done", 12: "hodge start", 13: "final MLP start", 14: "end"}
