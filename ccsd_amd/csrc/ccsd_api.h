@@ -327,7 +327,7 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
     return CCSD_OK;
 }
 static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Workspace& w, void* stream) {
-    xa.P0 = w.P0; xa.P1 = w.P1; xa.chan_ws = w.chan; xa.dbg = pl->dbg ? pl->dbg + 16 : nullptr;
+    xa.P0 = w.P0; xa.P1 = w.P1; xa.chan_ws = w.chan; xa.dbg = pl->dbg ? pl->dbg + 32 : nullptr;
     static const int xa_threads = getenv("CCSD_XA_THREADS") ? atoi(getenv("CCSD_XA_THREADS")) : 256;   // diagnostic: 64..512
     prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
     xa.wp = pl->wp; xa.hpairs = pl->hpairs;

@@ -22,10 +22,10 @@
 // small device helpers
 // ---------------------------------------------------------------------------------------------
 // Diagnostic cycle stamps (ccsd_debug_stamps): thread 0 of every workgroup writes the shader clock at phase
-// boundaries into a caller buffer [workgroup][32].  NULL (the default) compiles to a uniform branch not taken.
+// boundaries into a caller buffer [workgroup][64] (k_r2: slots 0.., k_xa: slots 32..).  NULL (the default) compiles to a uniform branch not taken.
 CCSD_DEV void stamp(long long* dbg, int slot) {
 #ifndef CCSD_EMU
-    if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 32 + slot] = (long long)__builtin_readcyclecounter();
+    if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 64 + slot] = (long long)__builtin_readcyclecounter();
 #else
     (void)dbg; (void)slot;
 #endif
@@ -45,30 +45,19 @@ CCSD_DEV float fast_rcp(float x) {
     return __builtin_amdgcn_rcpf(x);
 #endif
 }
-// tanh to ~2e-7 absolute / 3e-6 relative: odd polynomial near 0 (no cancellation), 1 - 2/(e^{2x}+1) elsewhere
+// tanh(x) = 1 - 2 / (e^{2x} + 1): branch-free, five instructions, ~1e-7 ABSOLUTE error (the cancellation near 0 costs
+// relative accuracy there, which nothing downstream needs: every consumer is compared at 1e-4 of the tensor's scale).
+// e^{2x} -> +inf gives 1, -> 0 gives -1.
 CCSD_DEV float tanh_f(float x) {
-    const float ax = fabsf(x);
-    if (ax < 0.1f) {
-        const float x2 = x * x;
-        return x * fmaf(x2, fmaf(x2, fmaf(x2, -0.05396825397f, 0.13333333333f), -0.33333333333f), 1.0f);
-    }
-    const float e = fast_exp(2.0f * ax);            // overflows to +inf for large |x| -> 1 - 0 = 1
-    const float t = 1.0f - 2.0f * fast_rcp(e + 1.0f);
-    return x < 0.f ? -t : t;
+    const float e = fast_exp(2.0f * x);
+    return fmaf(-2.0f, fast_rcp(e + 1.0f), 1.0f);
 }
-// F.elu, alpha = 1: x > 0 ? x : expm1(x); expm1 by series near 0, exp(x) - 1 elsewhere (rel. error ~1e-6)
+// F.elu, alpha = 1: x > 0 ? x : e^x - 1 (branch-free select; ~6e-8 absolute error on the negative side)
 CCSD_DEV float elu1(float v) {
-    if (v > 0.f) return v;
-    if (v > -0.1f) return v * fmaf(v, fmaf(v, fmaf(v, fmaf(v, 0.00833333333f, 0.04166666667f), 0.16666666667f), 0.5f), 1.0f);
-    return fast_exp(v) - 1.0f;
-}
-// same function without divergent branches (both arms evaluated, v_cndmask selects): used inside MFMA chains
-CCSD_DEV float elu1_sel(float v) {
-    const float ser = v * fmaf(v, fmaf(v, fmaf(v, fmaf(v, 0.00833333333f, 0.04166666667f), 0.16666666667f), 0.5f), 1.0f);
     const float ex = fast_exp(v) - 1.0f;
-    const float neg = v > -0.1f ? ser : ex;
-    return v > 0.f ? v : neg;
+    return v > 0.f ? v : ex;
 }
+CCSD_DEV float elu1_sel(float v) { return elu1(v); }
 // t / d and t % d for 0 <= t < 2^22 and small d without the ~40-instruction integer division:
 // (t + 0.5) * (1/d) is never within 0.5/d of an integer, far more than the fp32 rounding of the product.
 struct FastDiv {
@@ -1881,6 +1870,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
             }
             const bool w4_0 = mlp_maxw(h0.matt) <= 4 && h0.cin <= 4;
             __syncthreads();
+            stamp(xa.dbg, 16);
             if (p.h_L == 1) {
                 // only the diagonal is ever used (hodgedual_to_adj, cc_utils.py:1571)
                 for (int e = tid; e < E; e += nth) {
@@ -1893,10 +1883,9 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                             for (int hh = 0; hh < h0.nchunk; ++hh) {
                                 float d = 0.f;
                                 for (int u = 0; u < h0.dsplit; ++u) d = fmaf(q[hh * h0.dsplit + u], q[h0.adim + hh * h0.dsplit + u], d);
-                                sacc += tanh_f(d / kscale);
+                                sacc += tanh_f(d * rks);
                             }
-                            sacc /= (float)h0.nchunk;
-                            sacc = (sacc + sacc) / 2.f;
+                            sacc *= 1.0f / (float)h0.nchunk;
                         }
                         in[c] = sacc;
                     }
@@ -1915,6 +1904,23 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                 const float rnc0 = 1.0f / (float)h0.nchunk;
                 const int npair = E * (E + 1) / 2;
                 const float* P1b = xa.P1 + (size_t)b * E * h1.wc;   // [E][wc1] projections of the second layer (L2)
+                const int mtE = (E + 15) >> 4, ntq = (qw1 + 15) >> 4, ksE = (E + 3) >> 2;
+#ifndef CCSD_EMU
+                // The second layer's projection tasks are (channel, 16-column tile) x row tiles; with one (channel, column
+                // tile) per wave its B operands are the same for every row tile: fetch them now, so the L2 latency hides
+                // behind the dense attention below
+                const bool pf_ok = h1.cin * ntq <= n_waves && ksE <= 16;
+                float pfb[16];
+                const int pf_c = wave_id / ntq, pf_ct = wave_id % ntq;
+                const int pf_l15 = tid & 15, pf_kq = (tid & 63) >> 4;
+                if (pf_ok && wave_id < h1.cin * ntq) {
+#pragma unroll
+                    for (int s0 = 0; s0 < 16; ++s0) {
+                        const int k = 4 * s0 + pf_kq, d = 16 * pf_ct + pf_l15;
+                        pfb[s0] = P1b[(k < E ? k : E - 1) * h1.wc + pf_c * qw1 + (d < qw1 ? d : qw1 - 1)];
+                    }
+                }
+#endif
                 for (int t = tid; t < npair; t += nth) {
                     const int e = xa.hpairs[2 * t], e2 = xa.hpairs[2 * t + 1];
                     float in[CCSD_SMALLW], out[CCSD_SMALLW];
@@ -1952,6 +1958,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                         }
                 }
                 __syncthreads();
+                stamp(xa.dbg, 17);
                 // second (last) HodgeAdjAttentionLayer: dense hodge adjacency, only the diagonal of its output
                 float* s_deg = sm + p.o_deg;         // [cin1][E]
                 for (int t = tid; t < h1.cin * E; t += nth) {
@@ -1966,16 +1973,44 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                     s_deg[t] = 1.0f / sqrtf(fmaxf(s0 + s1, 1.f));
                 }
                 __syncthreads();
+                stamp(xa.dbg, 18);
                 // Q|K of the dense layer on MFMA: per channel  Y = D H D P1_c  (hodge_layers.py:185-193), tile tasks
                 // (channel, 16 rows of e) x 16 columns (2*adim <= 16 used) over the waves
                 {
-#ifdef CCSD_EMU
-                    const int wave = 0, nw = 1;
-#else
-                    const int wave = tid >> 6, nw = nth >> 6;
+#ifndef CCSD_EMU
+                    if (pf_ok) {
+                        if (wave_id < h1.cin * ntq) {
+                            typedef float f32x4 __attribute__((ext_vector_type(4)));
+                            const float* Hc = s_h1m + (size_t)pf_c * E * E;
+                            const float* dg = s_deg + pf_c * E;
+                            const int d = 16 * pf_ct + pf_l15;
+                            float bval[16];
+#pragma unroll
+                            for (int s0 = 0; s0 < 16; ++s0) {
+                                const int k = 4 * s0 + pf_kq;
+                                bval[s0] = (k < E && d < qw1) ? dg[k < E ? k : E - 1] * pfb[s0] : 0.f;
+                            }
+                            const float bias = w[h1.bcat + pf_c * qw1 + (d < qw1 ? d : qw1 - 1)];
+                            for (int rt = 0; rt < mtE; ++rt) {
+                                const int e = 16 * rt + pf_l15, ec = e < E ? e : E - 1;
+                                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                                for (int s0 = 0; s0 < 16; ++s0)
+                                    if (s0 < ksE) {
+                                        const int k = 4 * s0 + pf_kq;
+                                        const float hv = Hc[ec * E + (k < E ? k : E - 1)];
+                                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32((e < E && k < E) ? hv : 0.f, bval[s0], acc, 0, 0, 0);
+                                    }
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int eo = 16 * rt + 4 * pf_kq + r;
+                                    if (eo < E && d < qw1) s_hq[(pf_c * E + eo) * qw1 + d] = fmaf(dg[eo], acc[r], bias);
+                                }
+                            }
+                        }
+                    } else
 #endif
-                    const int mtE = (E + 15) >> 4, ntq = (qw1 + 15) >> 4, ksE = (E + 3) >> 2;
-                    for (int task = wave; task < h1.cin * mtE * ntq; task += nw) {
+                    for (int task = wave_id; task < h1.cin * mtE * ntq; task += n_waves) {
                         const int c = task / (mtE * ntq), rem = task % (mtE * ntq), rt = rem / ntq, ct = rem % ntq;
                         const float* Hc = s_h1m + (size_t)c * E * E;
                         const float* dg = s_deg + c * E;
@@ -1992,6 +2027,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                     }
                 }
                 __syncthreads();
+                stamp(xa.dbg, 19);
                 const bool w4_1 = mlp_maxw(h1.matt) <= 4 && h1.cin <= 4;
                 for (int e = tid; e < E; e += nth) {
                     float in[CCSD_SMALLW], out[CCSD_SMALLW];
@@ -2003,10 +2039,9 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                             for (int hh = 0; hh < h1.nchunk; ++hh) {
                                 float d = 0.f;
                                 for (int u = 0; u < h1.dsplit; ++u) d = fmaf(q[hh * h1.dsplit + u], q[h1.adim + hh * h1.dsplit + u], d);
-                                sacc += tanh_f(d / kscale);
+                                sacc += tanh_f(d * rks);
                             }
-                            sacc /= (float)h1.nchunk;
-                            sacc = (sacc + sacc) / 2.f;
+                            sacc *= 1.0f / (float)h1.nchunk;
                         }
                         in[c] = sacc;
                     }
@@ -2018,6 +2053,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                 }
                 __syncthreads();
             }
+            stamp(xa.dbg, 20);
             // hodgedual_to_adj (cc_utils.py:1552-1588): scatter the diagonals behind the graph channels
             for (int t = tid; t < p.a_nch_hodge * E; t += nth) {
                 int c, e;

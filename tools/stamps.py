@@ -17,7 +17,7 @@ flags = bench.qm9_flags(B).cuda()
 st, sc, rs = eng.alloc_state(B), eng.alloc_state(B), eng.alloc_state(B)
 eng.init_state(flags, st, None, 1, 0)
 eng.run(flags, st, sc, rs, 1, 0, 0, 3)
-dbg = torch.zeros(B, 32, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(B, 64, dtype=torch.int64, device="cuda")
 eng.lib.check(eng.lib.ccsd_debug_stamps(eng.handle, C.c_void_p(dbg.data_ptr())))
 eng.predictor(5, st, flags, None, 1, 0, sc, None)
 torch.cuda.synchronize()
@@ -27,7 +27,7 @@ print("k_r2 per-phase cycles (median over workgroups), total", np.median(d[:, 5]
 for i in range(5):
     print(f"  {names_r2[i]:24s} {np.median(d[:, i + 1] - d[:, i]):10.0f}")
 print("phase 1 (wave 0): k loop + epilogue", int(np.median(d[:, 6] - d[:, 2])), " loop exit", int(np.median(d[:, 7] - d[:, 6])), " barrier wait", int(np.median(d[:, 3] - d[:, 7])))
-x = d[:, 16:]
+x = d[:, 32:]
 lab = {0: "start", 1: "X-net done", 2: "L0 start", 3: "L0 gcn/att done", 4: "L0 edge MLP done", 5: "L1 start", 6: "L1 gcn/att done",
        7: "L1 edge MLP done", 8: "L2 start", 9: "L2 gcn/att done", 10: "L2 edge MLP done", 12: "hodge start", 13: "final MLP start", 14: "end"}
 print("k_xa total", np.median(x[:, 14] - x[:, 0]))
@@ -38,5 +38,7 @@ for k in sorted(lab):
     print(f"  {lab[prev]:18s} -> {lab[k]:18s} {np.median(x[:, k] - x[:, prev]):10.0f}")
     prev = k
 span = (d[:, 5].max() - d[:, 0].min())
+hs = [12, 16, 17, 18, 19, 20, 13]
+print("hodge: fill/hq0, dense pairs, deg, MFMA proj, diag att, scatter:", [int(np.median(x[:, hs[i + 1]] - x[:, hs[i]])) for i in range(6)])
 print("final MLP: chain (wave 0)", int(np.median(x[:, 11] - x[:, 13])), " wait barrier", int(np.median(x[:, 15] - x[:, 11])), " epilogue", int(np.median(x[:, 14] - x[:, 15])))
 print("k_r2 first-start to last-end cycles:", span, " k_xa:", x[:, 14].max() - x[:, 0].min())
