@@ -13,23 +13,23 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(HERE, "libccsd_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_WEIGHTS, ERR_RUNTIME, ERR_WORKSPACE = range(6)
 SDE_VP, SDE_VE, SDE_SUBVP = 0, 1, 2
-PRED_EULER, PRED_REVERSE = 0, 1
+PRED_EULER, PRED_REVERSE, PRED_S4 = 0, 1, 2
 CORR_NONE, CORR_LANGEVIN = 0, 1
 TARGET_X, TARGET_ADJ, TARGET_RANK2 = 0, 1, 2
 
 EXPORTS = [
     "ccsd_plan_create", "ccsd_plan_destroy", "ccsd_weight_count", "ccsd_rank2_dims", "ccsd_workspace_bytes",
     "ccsd_last_error", "ccsd_score", "ccsd_init_state", "ccsd_corrector_norms", "ccsd_corrector_apply",
-    "ccsd_predictor", "ccsd_sampler_run", "ccsd_quantize", "ccsd_profile_kernel", "ccsd_profile_read", "ccsd_debug_stamps",
+    "ccsd_predictor", "ccsd_s4_apply", "ccsd_sampler_run", "ccsd_quantize", "ccsd_profile_kernel", "ccsd_profile_read", "ccsd_debug_stamps",
 ]
 KERNEL_IDS = {"k_xa": 0, "k_gemm_p": 1, "k_hf_score": 2, "k_gemm_h": 3, "k_langevin_apply": 4, "k_r2": 5}
 
 
 class StepCoef(C.Structure):
-    _fields_ = [(n, C.c_float) for n in ("sscale", "alpha", "pa", "pb", "pc")]
+    _fields_ = [(n, C.c_float) for n in ("sscale", "alpha", "pa", "pb", "pc", "m1", "s1", "d", "m2", "s2")]
 
 
 class Config(C.Structure):
@@ -103,6 +103,8 @@ class Library:
         L.ccsd_corrector_apply.restype = C.c_int
         L.ccsd_predictor.argtypes = [vp, i32, i32, P(State), vp, P(Noise), u64, i64, P(State), P(State), vp, sz, vp]
         L.ccsd_predictor.restype = C.c_int
+        L.ccsd_s4_apply.argtypes = [vp, i32, i32, P(State), vp, P(Noise), P(Noise), P(Noise), u64, i64, vp, P(State), P(State), vp, sz, vp]
+        L.ccsd_s4_apply.restype = C.c_int
         L.ccsd_sampler_run.argtypes = [vp, i32, vp, u64, i64, i32, i32, P(State), P(State), P(State), vp, vp, sz, vp]
         L.ccsd_sampler_run.restype = C.c_int
         L.ccsd_quantize.argtypes = [vp, i64, f32, vp, vp]

@@ -134,7 +134,7 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
         return set_err(CCSD_ERR_WEIGHTS, "weight blob has " + std::to_string(n_weights) + " floats, config needs " +
                                              std::to_string(pl->nweights));
     }
-    if (cfg->predictor != CCSD_PRED_EULER && cfg->predictor != CCSD_PRED_REVERSE) { delete pl; return set_err(CCSD_ERR_UNSUPPORTED, "unknown predictor"); }
+    if (cfg->predictor != CCSD_PRED_EULER && cfg->predictor != CCSD_PRED_REVERSE && cfg->predictor != CCSD_PRED_S4) { delete pl; return set_err(CCSD_ERR_UNSUPPORTED, "unknown predictor"); }
     if (cfg->corrector != CCSD_CORR_NONE && cfg->corrector != CCSD_CORR_LANGEVIN) { delete pl; return set_err(CCSD_ERR_UNSUPPORTED, "unknown corrector"); }
     if (cfg->diff_steps < 1 || cfg->n_corr_steps < 0) { delete pl; return set_err(CCSD_ERR_INVALID, "bad step counts"); }
     ccsd_fold_fnet(&pl->h, weights);
@@ -389,7 +389,8 @@ static int launch_r2(const ccsd_plan* pl, int B, const float* rank2, const float
 }
 
 static unsigned int draw_base(const ccsd_plan* pl, int step, int phase) {
-    return 3u + (unsigned)((step * (pl->cfg.n_corr_steps + 1) + phase) * 3);
+    const int per_step = pl->cfg.predictor == CCSD_PRED_S4 ? 3 : pl->cfg.n_corr_steps + 1;   // S4: three draws per target per step
+    return 3u + (unsigned)((step * per_step + phase) * 3);
 }
 static NoiseArgs make_noise(const ccsd_noise_t* n, uint64_t seed, int64_t off, unsigned int base) {
     NoiseArgs na{};
@@ -551,6 +552,35 @@ static int predictor(ccsd_plan* pl, int B, int step, const ccsd_state_t* in, con
     return CCSD_OK;
 }
 
+// update half of one S4 step (k_s4_apply); the norms pass of the step is corrector_norms(step, 0, cur, cur)
+static int s4_apply(ccsd_plan* pl, int B, int step, const ccsd_state_t* cur, const float* flags, const ccsd_noise_t* n1,
+                    const ccsd_noise_t* n2, const ccsd_noise_t* n3, uint64_t seed, int64_t off, const float* sums,
+                    ccsd_state_t* out, ccsd_state_t* mean, Workspace& w, void* stream) {
+    const PlanD& p = pl->h;
+    S4Args q{};
+    LangArgs& a = q.a;
+    a.x = cur->x; a.adj = cur->adj; a.r = cur->rank2;
+    a.nx = w.net_x; a.nadj = w.net_adj; a.nr = w.net_r;
+    a.ox = out->x; a.oadj = out->adj; a.orr = out->rank2;
+    a.flags = flags; a.sums = sums;
+    for (int t = 0; t < 3; ++t) {
+        const ccsd_step_coef_t& c = pl->coef[(size_t)step * 3 + t];
+        a.ss[t] = c.sscale; a.alpha[t] = c.alpha;
+        q.m1[t] = c.m1; q.s1[t] = c.s1; q.d[t] = c.d; q.m2[t] = c.m2; q.s2[t] = c.s2;
+    }
+    a.snr = p.snr; a.seps = p.seps;
+    a.B = B; a.N = p.N; a.F = p.F; a.E = p.E; a.K = p.K; a.is_cc = p.is_cc;
+    q.mx = mean ? mean->x : nullptr; q.madj = mean ? mean->adj : nullptr; q.mr = mean ? mean->rank2 : nullptr;
+    NoiseArgs na1 = make_noise(n1, seed, off, draw_base(pl, step, 0));
+    NoiseArgs na2 = make_noise(n2, seed, off, draw_base(pl, step, 1));
+    NoiseArgs na3 = make_noise(n3, seed, off, draw_base(pl, step, 2));
+    const long long total = (long long)B * (p.N * p.F + p.N * p.N) + (p.is_cc ? (long long)B * ((p.E + 3) / 4) * p.K : 0);
+    CCSD_LAUNCH(k_s4_apply, dim3(grid_for(total, 256)), dim3(CCSD_NTHREADS), 0, stream, q, na1, na2, na3,
+                (const unsigned long long*)w.offbits, (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells);
+    LAUNCH_CHECK();
+    return CCSD_OK;
+}
+
 static int check_step(const ccsd_plan* pl, int step) {
     if (step < 0 || step >= pl->cfg.diff_steps) return set_err(CCSD_ERR_INVALID, "step out of range");
     return CCSD_OK;
@@ -580,6 +610,7 @@ extern "C" int ccsd_predictor(ccsd_plan_t* pl, int32_t B, int32_t step, const cc
                               const ccsd_noise_t* noise, uint64_t seed, int64_t sample_offset, ccsd_state_t* out,
                               ccsd_state_t* mean, void* workspace, size_t ws_bytes, void* stream) {
     int st = check_common(pl, B, flags, workspace, ws_bytes);
+    if (!st && pl->cfg.predictor == CCSD_PRED_S4) return set_err(CCSD_ERR_INVALID, "S4 plans step with ccsd_corrector_norms + ccsd_s4_apply");
     if (st || (st = check_step(pl, step)) || (st = check_state(pl, in, "in")) || (st = check_state(pl, out, "out"))) return st;
     if (mean && (st = check_state(pl, mean, "mean"))) return st;
     if (in->x == out->x || in->adj == out->adj || (pl->h.is_cc && in->rank2 == out->rank2))
@@ -589,6 +620,20 @@ extern "C" int ccsd_predictor(ccsd_plan_t* pl, int32_t B, int32_t step, const cc
     return predictor(pl, B, step, in, flags, noise, seed, sample_offset, out, mean, w, stream);
 }
 
+extern "C" int ccsd_s4_apply(ccsd_plan_t* pl, int32_t B, int32_t step, const ccsd_state_t* cur, const float* flags,
+                             const ccsd_noise_t* noise1, const ccsd_noise_t* noise2, const ccsd_noise_t* noise3, uint64_t seed,
+                             int64_t sample_offset, const float* norm_sums, ccsd_state_t* out, ccsd_state_t* mean,
+                             void* workspace, size_t ws_bytes, void* stream) {
+    int st = check_common(pl, B, flags, workspace, ws_bytes);
+    if (st || (st = check_step(pl, step)) || (st = check_state(pl, cur, "cur")) || (st = check_state(pl, out, "out"))) return st;
+    if (mean && (st = check_state(pl, mean, "mean"))) return st;
+    if (pl->cfg.predictor != CCSD_PRED_S4) return set_err(CCSD_ERR_INVALID, "ccsd_s4_apply needs a plan created with CCSD_PRED_S4");
+    if (!norm_sums) return set_err(CCSD_ERR_INVALID, "NULL norm_sums");
+    Workspace w = carve_ws(pl, B, workspace);
+    if ((st = launch_flagbits(pl, B, flags, w, stream))) return st;
+    return s4_apply(pl, B, step, cur, flags, noise1, noise2, noise3, seed, sample_offset, norm_sums, out, mean, w, stream);
+}
+
 extern "C" int ccsd_sampler_run(ccsd_plan_t* pl, int32_t B, const float* flags, uint64_t seed, int64_t sample_offset,
                                 int32_t first_step, int32_t last_step, ccsd_state_t* state, ccsd_state_t* scratch,
                                 ccsd_state_t* result, float* traj, void* workspace, size_t ws_bytes, void* stream) {
@@ -596,7 +641,8 @@ extern "C" int ccsd_sampler_run(ccsd_plan_t* pl, int32_t B, const float* flags, 
     if (st || (st = check_state(pl, state, "state")) || (st = check_state(pl, scratch, "scratch")) ||
         (st = check_state(pl, result, "result"))) return st;
     if (first_step < 0 || last_step > pl->cfg.diff_steps || first_step >= last_step) return set_err(CCSD_ERR_INVALID, "bad step range");
-    const bool lang = pl->cfg.corrector == CCSD_CORR_LANGEVIN;
+    const bool s4 = pl->cfg.predictor == CCSD_PRED_S4;
+    const bool lang = pl->cfg.corrector == CCSD_CORR_LANGEVIN && !s4;
     if (lang && pl->cfg.n_corr_steps != 1)
         return set_err(CCSD_ERR_UNSUPPORTED, "ccsd_sampler_run handles n_steps == 1; drive other values step by step");
     const PlanD& p = pl->h;
@@ -607,7 +653,12 @@ extern "C" int ccsd_sampler_run(ccsd_plan_t* pl, int32_t B, const float* flags, 
     for (int step = first_step; step < last_step; ++step) {
         const bool lastone = step == last_step - 1;
         const bool want_mean = pl->cfg.denoise && (lastone || traj);
-        if (lang && pl->fused_r2 && getenv("CCSD_NO_FUSED_APPLY") == nullptr) {
+        if (s4) {   // scores + first draw + norm sums at the state, then the element-wise S4 update: a -> b, swap
+            if ((st = corrector_norms(pl, B, step, 0, &a, &a, flags, nullptr, seed, sample_offset, w.sums, w, stream))) return st;
+            if ((st = s4_apply(pl, B, step, &a, flags, nullptr, nullptr, nullptr, seed, sample_offset, w.sums, &b,
+                               want_mean ? result : nullptr, w, stream))) return st;
+            ccsd_state_t t = a; a = b; b = t;
+        } else if (lang && pl->fused_r2 && getenv("CCSD_NO_FUSED_APPLY") == nullptr) {
             // a -> [norms pass] ; [apply fused into the predictor kernels] -> b ; swap roles
             if ((st = corrector_norms(pl, B, step, 0, &a, &a, flags, nullptr, seed, sample_offset, w.sums, w, stream))) return st;
             if ((st = predictor(pl, B, step, &a, flags, nullptr, seed, sample_offset, &b, want_mean ? result : nullptr, w, stream, w.sums))) return st;

@@ -2222,6 +2222,75 @@ __global__ void k_langevin_apply(LangArgs a, NoiseArgs na, const unsigned long l
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_s4_apply: the update half of one S4_solver step (solver.py:1296-1352 graph, 1446-1529 CC), element-wise:
+//   v1 = v + step*score + sqrt(2 step)*z1*scale_eps        Langevin-style correction with the step's score
+//   v2 = m1*v1 + s1*z2                                     sde.transition(v1, t, dt/2)
+//   v3 = v2 + d*net                                        + Sdrift*dt, Sdrift = -g(t)^2 * score
+//   mean = m2*v3 ;  v = mean + s2*z3                       sde.transition(v3, t + dt/2, dt/2)
+// Same indexing and masks as k_langevin_apply; three independent draws per element.
+// ---------------------------------------------------------------------------------------------
+struct S4Args {
+    LangArgs a;                       // state in/out, raw nets, flags, norm sums, Langevin scalars
+    float m1[3], s1[3], d[3], m2[3], s2[3];
+    float* mx; float* madj; float* mr;   // means (nullable)
+};
+CCSD_DEV float s4_chain(float v, float net, float z1, float z2, float z3, float c1, float c2, const S4Args& q, int t, float* mean) {
+    const float v1 = fmaf(c2, z1, fmaf(c1, net, v));
+    const float v2 = fmaf(q.s1[t], z2, q.m1[t] * v1);
+    const float v3 = fmaf(q.d[t], net, v2);
+    const float mu = q.m2[t] * v3;
+    *mean = mu;
+    return fmaf(q.s2[t], z3, mu);
+}
+__global__ void k_s4_apply(S4Args q, NoiseArgs n1, NoiseArgs n2, NoiseArgs n3, const unsigned long long* __restrict__ offbits,
+                           const unsigned char* __restrict__ edges, const unsigned long long* __restrict__ cells) {
+    const LangArgs& a = q.a;
+    const long long nxe = (long long)a.B * a.N * a.F, nae = (long long)a.B * a.N * a.N;
+    const long long nre = a.is_cc ? (long long)a.B * ((a.E + 3) / 4) * a.K : 0;
+    const long long total = nxe + nae + nre;
+    float c1x, c2x, c1a, c2a, c1r = 0.f, c2r = 0.f;
+    langevin_coef(a, 0, &c1x, &c2x);
+    langevin_coef(a, 1, &c1a, &c2a);
+    if (a.is_cc) langevin_coef(a, 2, &c1r, &c2r);
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        float mu;
+        if (t < nxe) {
+            const int per = a.N * a.F, b = (int)(t / per), idx = (int)(t % per), i = idx / a.F;
+            const float fl = a.flags[(size_t)b * a.N + i];
+            a.ox[t] = s4_chain(a.x[t], a.nx[t], raw_noise_x(n1, b, idx, per) * fl, raw_noise_x(n2, b, idx, per) * fl,
+                               raw_noise_x(n3, b, idx, per) * fl, c1x, c2x, q, 0, &mu);
+            if (q.mx) q.mx[t] = mu;
+        } else if (t < nxe + nae) {
+            const long long u = t - nxe;
+            const int per = a.N * a.N, b = (int)(u / per), ij = (int)(u % per), i = ij / a.N, j = ij % a.N;
+            const float fl = a.flags[(size_t)b * a.N + i] * a.flags[(size_t)b * a.N + j];
+            a.oadj[u] = s4_chain(a.adj[u], a.nadj[u], raw_noise_adj(n1, b, i, j, a.N) * fl, raw_noise_adj(n2, b, i, j, a.N) * fl,
+                                 raw_noise_adj(n3, b, i, j, a.N) * fl, c1a, c2a, q, 1, &mu);
+            if (q.madj) q.madj[u] = mu;
+        } else {
+            const long long u = t - nxe - nae;
+            const int eg_n = (a.E + 3) / 4;
+            const int k = (int)(u % a.K), eg = (int)((u / a.K) % eg_n), b = (int)(u / ((long long)a.K * eg_n));
+            float z1[4], z2[4], z3[4];
+            raw_noise_r4(n1, b, eg, k, a.E, a.K, z1);
+            raw_noise_r4(n2, b, eg, k, a.E, a.K, z2);
+            raw_noise_r4(n3, b, eg, k, a.E, a.K, z3);
+            const unsigned long long off = offbits[b];
+            const float fr = cell_on(off, cells, k);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int e = 4 * eg + s;
+                if (e >= a.E) continue;
+                const size_t gi = ((size_t)b * a.E + e) * a.K + k;
+                const float m = edge_on(off, edges, e) * fr;
+                a.orr[gi] = s4_chain(a.r[gi], a.nr[gi], z1[s] * m, z2[s] * m, z3[s] * m, c1r, c2r, q, 2, &mu);
+                if (q.mr) q.mr[gi] = mu;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_init_state: masked prior (solver.py:1111-1118; sde.py:436,448-449).  Same indexing as above.
 // ---------------------------------------------------------------------------------------------
 __global__ void k_init_state(float* x, float* adj, float* r, const float* __restrict__ flags, NoiseArgs na,

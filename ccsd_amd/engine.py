@@ -41,7 +41,7 @@ class PCEngine:
                 coef[:, 2] = coef[:, 1]
             self.diff_steps = sdes[1].N
         else:
-            coef = np.zeros((1, 3, 5), np.float32)
+            coef = np.zeros((1, 3, 10), np.float32)
             coef[:, :, 0] = 1.0
             self.diff_steps = 1
         self.coef = np.ascontiguousarray(coef, np.float32)
@@ -157,6 +157,16 @@ class PCEngine:
         ws, n = self._workspace(B)
         self.lib.check(self.lib.ccsd_predictor(self.handle, B, step, C.byref(si), _ptr(flags), self._noise(noise, B), seed,
                                                sample_offset, C.byref(so), sm, ws, n, self._stream()))
+
+    def s4_apply(self, step, cur, flags, noise1, noise2, noise3, seed, sample_offset, sums, out, mean=None):
+        """Update half of one S4_solver step; corrector_norms(step, 0, cur, cur, ...) must have filled `sums`."""
+        B = flags.shape[0]
+        sc, so = self._state(*cur, B, "cur"), self._state(*out, B, "out")
+        sm = C.byref(self._state(*mean, B, "mean")) if mean is not None else None
+        ws, n = self._workspace(B)
+        self.lib.check(self.lib.ccsd_s4_apply(self.handle, B, step, C.byref(sc), _ptr(flags), self._noise(noise1, B),
+                                              self._noise(noise2, B), self._noise(noise3, B), seed, sample_offset,
+                                              _ptr(sums), C.byref(so), sm, ws, n, self._stream()))
 
     def run(self, flags, state, scratch, result, seed: int = 0, sample_offset: int = 0, first_step: int = 0,
             last_step: Optional[int] = None, traj: Optional[torch.Tensor] = None):

@@ -19,7 +19,7 @@ import torch
 from .models import load_model  # noqa: F401  (re-exported, loader.py:71)
 from .plan import rank2_dim
 from .sde import SDE, VESDE, VPSDE, subVPSDE
-from .solver import get_pc_sampler
+from .solver import S4_solver, get_pc_sampler
 
 PKG_CKPT_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "checkpoints")
 
@@ -163,4 +163,4 @@ def load_sampling_fn(config_train, config_module, config_sample, device, is_cc: 
     if is_cc:
         kw.update(is_cc=True, sde_rank2=sde_rank2, shape_rank2=(bs, *rank2_dim(N, d_min, d_max)), d_min=d_min, d_max=d_max)
     kw.update(extra)
-    return get_pc_sampler(**kw)
+    return S4_solver(**kw) if use_s4 else get_pc_sampler(**kw)

@@ -175,12 +175,15 @@ def make_config(px: dict, pa: dict, pf: Optional[dict], *, predictor="Euler", co
         c.f_num_layers, c.f_num_linears, c.f_nhid = pf["num_layers"], pf["num_linears"], pf["nhid"]
         c.f_c_hid, c.f_c_final, c.f_cnum = pf["c_hid"], pf["c_final"], pf["cnum"]
         c.f_num_layers_mlp, c.f_use_hodge_mask = pf["num_layers_mlp"], int(pf.get("use_hodge_mask", True))
-    preds = {"Euler": _lib.PRED_EULER, "Reverse": _lib.PRED_REVERSE}
+    preds = {"Euler": _lib.PRED_EULER, "Reverse": _lib.PRED_REVERSE, "S4": _lib.PRED_S4}
     corrs = {"None": _lib.CORR_NONE, "Langevin": _lib.CORR_LANGEVIN}
     if predictor not in preds:
         raise NotImplementedError(f"Predictor {predictor} not yet supported. Select from [Reverse, Euler].")
-    if corrector not in corrs:
+    if corrector not in corrs and predictor != "S4":
         raise NotImplementedError(f"Corrector {corrector} not yet supported. Select from [Langevin, None].")
+    if predictor == "S4":
+        corrector = "None"      # S4_solver ignores the corrector / n_steps / probability_flow knobs (solver.py:1221-1226)
+        n_steps, probability_flow = 1, False
     c.predictor, c.corrector = preds[predictor], corrs[corrector]
     c.n_corr_steps, c.probability_flow, c.denoise = int(n_steps), int(probability_flow), int(denoise)
     c.snr, c.scale_eps, c.diff_steps = float(snr), float(scale_eps), int(diff_steps)

@@ -132,21 +132,23 @@ class VESDE(SDE):
 
 
 def step_coefficients(sdes, predictor: str, probability_flow: bool, eps: float):
-    """[diff_steps][len(sdes)][5] float32 table of (sscale, alpha, pa, pb, pc) -- include/ccsd_hip.h.
+    """[diff_steps][len(sdes)][10] float32 table of (sscale, alpha, pa, pb, pc, m1, s1, d, m2, s2) -- include/ccsd_hip.h.
 
     Restates, per step and per target, the scalar part of
       get_score_fn(_cc)                      losses.py:157-163, 189-193
       LangevinCorrector alpha                solver.py:752-756
       ReverseDiffusionPredictor + RSDE.discretize   solver.py:430-457, sde.py:329-340
       EulerMaruyamaPredictor + RSDE.sde             solver.py:275-307, sde.py:290-302
-    with v_mean = pa * v + pb * net and v = v_mean + pc * z.
+    with v_mean = pa * v + pb * net and v = v_mean + pc * z.  predictor == "S4" (S4_solver, solver.py:1266-1352) fills
+    m1, s1 = transition(1, t, dt/2); d = -g(t)^2 * sscale * dt (Sdrift * dt); m2, s2 = transition(1, t + dt/2, dt/2),
+    with the Langevin alpha taken at sde_x's timestep index for every target (solver.py:1296).
     """
-    if predictor not in ("Reverse", "Euler"):
+    if predictor not in ("Reverse", "Euler", "S4"):
         raise NotImplementedError(f"Predictor {predictor} not yet supported. Select from [Reverse, Euler].")
     sde_adj = sdes[1]
     steps = sde_adj.N
     timesteps = torch.linspace(sde_adj.T, eps, steps)
-    out = np.zeros((steps, 3, 5), dtype=np.float32)
+    out = np.zeros((steps, 3, 10), dtype=np.float32)
     one = torch.ones(1, 1, 1)
     half = 0.5 if probability_flow else 1.0
     for i in range(steps):
@@ -158,6 +160,18 @@ def step_coefficients(sdes, predictor: str, probability_flow: bool, eps: float):
             else:
                 sscale = -1.0 / s.marginal_prob(torch.zeros(1, 1, 1), t)[1]
                 alpha = s.alphas[s.timestep_index(t)]
+            if predictor == "S4":
+                dt = -1.0 / steps                                    # diff_steps = sde_adj.N (solver.py:1281)
+                vec_dt = torch.ones(1) * (dt / 2)
+                if not isinstance(s, VESDE):                         # alpha index from sde_x for all targets (solver.py:1296)
+                    alpha = s.alphas[(t * (sdes[0].N - 1) / sdes[0].T).long()]
+                g = s.sde(one, t)[1]
+                m1, s1 = s.transition(one, t, vec_dt)
+                m2, s2 = s.transition(one, t + vec_dt, vec_dt)
+                d = -(g**2) * sscale * dt
+                out[i, k] = [float(sscale), float(alpha), 0.0, 0.0, 0.0, float(m1.reshape(-1)[0]), float(s1), float(d),
+                             float(m2.reshape(-1)[0]), float(s2)]
+                continue
             if predictor == "Reverse":
                 f, G = s.discretize(one, t)            # f evaluated at v = 1: v_mean = v - f(v) + G^2 * score
                 pa = 1.0 - f.reshape(1)
@@ -173,5 +187,5 @@ def step_coefficients(sdes, predictor: str, probability_flow: bool, eps: float):
                 pa = 1.0 + drift.reshape(1) * dt
                 pb = -(g**2) * half * dt * sscale
                 pc = g * np.sqrt(-dt)
-            out[i, k] = [float(sscale), float(alpha), float(pa), float(pb), float(pc)]
+            out[i, k, :5] = [float(sscale), float(alpha), float(pa), float(pb), float(pc)]
     return out

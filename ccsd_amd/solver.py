@@ -43,6 +43,20 @@ def _unwrap(model):
     return getattr(model, "module", model)
 
 
+def S4_solver(sde_x: SDE, sde_adj: SDE, shape_x: Sequence[int], shape_adj: Sequence[int], predictor: str = "None",
+              corrector: str = "None", snr: float = 0.1, scale_eps: float = 1.0, n_steps: int = 1,
+              probability_flow: bool = False, continuous: bool = False, denoise: bool = True, eps: float = 1e-3,
+              device: str = "cuda", is_cc: bool = False, sde_rank2: Optional[SDE] = None,
+              shape_rank2: Optional[Sequence[int]] = None, d_min: Optional[int] = None, d_max: Optional[int] = None,
+              **extra) -> Callable:
+    """The reference's S4 sampler factory (ccsd/src/solver.py:1179-1563): same signature, closure signature and return
+    tuple (nfe is 0 there); predictor / corrector / n_steps / probability_flow are accepted and unused, as in the
+    reference.  One step = one joint score evaluation, a Langevin-style correction with it, and two half-step transition
+    kernels around the score drift.  `extra`: the keyword-only knobs of get_pc_sampler (rng, seed, keep_traj, ...)."""
+    return get_pc_sampler(sde_x, sde_adj, shape_x, shape_adj, "S4", "None", snr, scale_eps, 1, False, continuous, denoise, eps,
+                          device, is_cc, sde_rank2, shape_rank2, d_min, d_max, **extra)
+
+
 def get_pc_sampler(sde_x: SDE, sde_adj: SDE, shape_x: Sequence[int], shape_adj: Sequence[int], predictor: str = "Euler",
                    corrector: str = "None", snr: float = 0.1, scale_eps: float = 1.0, n_steps: int = 1,
                    probability_flow: bool = False, continuous: bool = False, denoise: bool = True, eps: float = 1e-3,
@@ -50,8 +64,10 @@ def get_pc_sampler(sde_x: SDE, sde_adj: SDE, shape_x: Sequence[int], shape_adj: 
                    shape_rank2: Optional[Sequence[int]] = None, d_min: Optional[int] = None, d_max: Optional[int] = None,
                    *, rng: str = "philox", keep_traj: bool = False, seed: Optional[int] = None, group=None,
                    sample_offset: int = 0, max_steps: Optional[int] = None, lib: Optional[_lib.Library] = None) -> Callable:
-    get_predictor(predictor)
-    get_corrector(corrector)
+    s4 = predictor == "S4"          # reached through S4_solver only (get_predictor rejects the name, as the reference does)
+    if not s4:
+        get_predictor(predictor)
+        get_corrector(corrector)
     if rng not in ("philox", "torch", "torch_cpu"):
         raise ValueError(f"rng {rng} unknown. Select from [philox, torch, torch_cpu].")
     B, N, F = shape_x
@@ -133,7 +149,7 @@ def get_pc_sampler(sde_x: SDE, sde_adj: SDE, shape_x: Sequence[int], shape_adj: 
         else:
             out = result
         print(" ")
-        return (*out[:nt], diff_steps * (n_steps + 1), diff_traj)
+        return (*out[:nt], 0 if s4 else diff_steps * (n_steps + 1), diff_traj)
 
     def _stepwise(eng, flags, state, scratch, result, noise_fn, the_seed, off, last, diff_traj, keep, grp):
         """Python-driven loop: used for host-supplied noise and for the exact multi-GPU mode."""
@@ -146,7 +162,16 @@ def get_pc_sampler(sde_x: SDE, sde_adj: SDE, shape_x: Sequence[int], shape_adj: 
         a, b = state, scratch   # a = live
         for step in range(last):
             lastone = step == last - 1
-            if corrector == "Langevin":
+            if s4:
+                # draw order of one S4 step (solver.py:1299-1350): correction x, adj(, rank2); first transition; second transition
+                z1, z2, z3 = ([noise_fn(k) for k in range(nt)] for _ in range(3)) if noise_fn else (None, None, None)
+                eng.corrector_norms(step, 0, a, a, flags, z1, the_seed, off, sums)
+                if grp is not None and dist.is_available() and dist.is_initialized():
+                    dist.all_reduce(sums, group=grp)
+                want_mean = denoise and (lastone or keep)
+                eng.s4_apply(step, a, flags, z1, z2, z3, the_seed, off, sums, b, result if want_mean else None)
+                a, b = b, a
+            elif corrector == "Langevin":
                 base, cur = a, a
                 bufs = [b, third]
                 # the reference finishes all inner steps of one target before the next target draws

@@ -23,7 +23,8 @@
  * ccsd_corrector_apply         second half: step_size, x_mean, x (solver.py:767-769, 781-783, 797-801)
  * ccsd_predictor               ReverseDiffusionPredictor / EulerMaruyamaPredictor.update_fn_*
  *                              (solver.py:210-313, 367-463) + RSDE.sde/discretize (sde.py:180-340)
- * ccsd_sampler_run             the whole pc_sampler loop (solver.py:1109-1174)
+ * ccsd_s4_apply                the update half of one S4_solver step (solver.py:1296-1352, 1446-1529)
+ * ccsd_sampler_run             the whole pc_sampler / s4_solver loop (solver.py:1109-1174, 1266-1352)
  * ccsd_quantize_mol            quantize_mol / quantize (graph_utils.py:181-213)
  */
 #ifndef CCSD_HIP_H
@@ -36,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CCSD_ABI_VERSION 1
+#define CCSD_ABI_VERSION 2
 
 /* status codes; the Python shim re-raises the reference's exception types */
 enum {
@@ -49,7 +50,7 @@ enum {
 };
 
 enum { CCSD_SDE_VP = 0, CCSD_SDE_VE = 1, CCSD_SDE_SUBVP = 2 };
-enum { CCSD_PRED_EULER = 0, CCSD_PRED_REVERSE = 1 };
+enum { CCSD_PRED_EULER = 0, CCSD_PRED_REVERSE = 1, CCSD_PRED_S4 = 2 };
 enum { CCSD_CORR_NONE = 0, CCSD_CORR_LANGEVIN = 1 };
 enum { CCSD_TARGET_X = 0, CCSD_TARGET_ADJ = 1, CCSD_TARGET_RANK2 = 2 };
 
@@ -59,9 +60,13 @@ enum { CCSD_TARGET_X = 0, CCSD_TARGET_ADJ = 1, CCSD_TARGET_RANK2 = 2 };
  *   sscale : score = sscale * net(...)      (1 for VE, -1/std(t) for VP/subVP; losses.py:157-163)
  *   alpha  : Langevin alpha                 (alphas[timestep] for VP/subVP, 1 for VE; solver.py:752-756)
  *   pa,pb,pc : predictor  v_mean = pa*v + pb*net ; v = v_mean + pc*z   (pb already includes sscale)
+ *   m1,s1,d,m2,s2 : S4_solver (solver.py:1179-1563), after its Langevin-style correction v1:
+ *              v2 = m1*v1 + s1*z2   (sde.transition(v, t, dt/2));   v3 = v2 + d*net   (Sdrift*dt, d = -g(t)^2*sscale*dt);
+ *              v_mean = m2*v3 ; v = v_mean + s2*z3   (sde.transition(v, t + dt/2, dt/2)).  Zero for the PC predictors.
  */
 typedef struct {
     float sscale, alpha, pa, pb, pc;
+    float m1, s1, d, m2, s2;
 } ccsd_step_coef_t;
 
 typedef struct {
@@ -147,6 +152,17 @@ int ccsd_corrector_apply(ccsd_plan_t* plan, int32_t B, int32_t step, int32_t cor
 int ccsd_predictor(ccsd_plan_t* plan, int32_t B, int32_t step, const ccsd_state_t* in, const float* flags_dev,
                    const ccsd_noise_t* noise, uint64_t seed, int64_t sample_offset,
                    ccsd_state_t* out, ccsd_state_t* mean, void* workspace, size_t workspace_bytes, void* stream);
+
+/* S4_solver (plans created with predictor = CCSD_PRED_S4): one step = ccsd_corrector_norms(step, corr_iter 0, base = cur =
+ * state) -- the three scores at the current state, the first noise draw and the six norm sums -- followed by
+ * ccsd_s4_apply: Langevin-style correction with that score and noise (solver.py:1296-1334), transition kernel over dt/2
+ * with a second draw, the score drift over dt, transition kernel over dt/2 with a third draw (solver.py:1337-1352).
+ * noise1 must be the draws given to ccsd_corrector_norms; NULL noise pointers select in-kernel Philox.  `mean`
+ * (nullable) receives the last transition's mean. */
+int ccsd_s4_apply(ccsd_plan_t* plan, int32_t B, int32_t step, const ccsd_state_t* cur, const float* flags_dev,
+                  const ccsd_noise_t* noise1, const ccsd_noise_t* noise2, const ccsd_noise_t* noise3, uint64_t seed,
+                  int64_t sample_offset, const float* norm_sums_dev, ccsd_state_t* out, ccsd_state_t* mean,
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* The whole loop with in-kernel Philox noise and per-shard Langevin norms (the reference's own
  * divide_batch semantics, sampler.py:1199-1211).  `state` holds the prior on entry (see

@@ -692,3 +692,72 @@ def get_pc_sampler(sde_x: SDE, sde_adj: SDE, shape_x, shape_adj, predictor="Eule
             return (*out, diff_steps * (n_steps + 1), traj)
 
     return pc_sampler
+
+
+# --------------------------------------------------------------------------------------
+# L5: the S4 sampler                                         (solver.py:1179-1563)
+# --------------------------------------------------------------------------------------
+def S4_solver(sde_x: SDE, sde_adj: SDE, shape_x, shape_adj, predictor="None", corrector="None", snr=0.1, scale_eps=1.0,
+              n_steps=1, probability_flow=False, continuous=False, denoise=True, eps=1e-3, is_cc=False,
+              sde_rank2: Optional[SDE] = None, shape_rank2=None, d_min=None, d_max=None,
+              noise: Optional[NoiseSource] = None, keep_traj=True, n_diff_steps: Optional[int] = None):
+    """Functional restatement of S4_solver: per step one joint score evaluation, Sdrift = -g(t)^2 score
+    (solver.py:1290-1294, 1436-1444), a Langevin-style correction per target with the alpha index taken from sde_x
+    (:1296-1334, :1446-1510), transition(v, t, dt/2) + noise, v += Sdrift*dt, transition(v, t + dt/2, dt/2) + noise
+    (:1337-1352, :1512-1529).  predictor / corrector / n_steps / probability_flow are unused, as in the reference."""
+    if not continuous:
+        raise NotImplementedError("Discrete not supported")
+    src = noise or NoiseSource()
+    N = shape_adj[1]
+    sdes = [sde_x, sde_adj] + ([sde_rank2] if is_cc else [])
+    targets = [_Target("x"), _Target("adj")] + ([_Target("rank2", N, d_min, d_max)] if is_cc else [])
+
+    def s4_solver(*args):
+        nets, init_flags = args[:-1], args[-1]
+        assert len(nets) == len(sdes)
+        fns = [make_score_fn(s, n) for s, n in zip(sdes, nets)]
+        with torch.no_grad():
+            state = [sde_x.prior(shape_x), sde_adj.prior_sym(shape_adj)]
+            if is_cc:
+                state.append(sde_rank2.prior(shape_rank2))
+            flags = init_flags
+            state[0] = mask_x(state[0], flags)
+            state[1] = mask_adjs(state[1], flags)
+            if is_cc:
+                state[2] = mask_rank2(state[2], N, d_min, d_max, flags)
+            diff_steps = sde_adj.N
+            timesteps = torch.linspace(sde_adj.T, eps, diff_steps)
+            dt = -1.0 / diff_steps
+            traj = []
+            means = list(state)
+            for i in range(diff_steps if n_diff_steps is None else n_diff_steps):
+                t = timesteps[i]
+                vec_t = torch.ones(shape_adj[0]) * t
+                vec_dt = torch.ones(shape_adj[0]) * (dt / 2)
+                scores = [fn(*state, flags, vec_t) for fn in fns]
+                sdrift = [-sd.sde(v, vec_t)[1][:, None, None] ** 2 * sc for sd, v, sc in zip(sdes, state, scores)]
+                timestep = (vec_t * (sde_x.N - 1) / sde_x.T).long()
+                for k, (tg, sd) in enumerate(zip(targets, sdes)):           # correction step
+                    z = tg.noise(state[k], flags, src)
+                    grad_norm = torch.norm(scores[k].reshape(scores[k].shape[0], -1), dim=-1).mean()
+                    noise_norm = torch.norm(z.reshape(z.shape[0], -1), dim=-1).mean()
+                    alpha = sd.alphas[timestep] if sd.kind == "VP" else torch.ones_like(vec_t)
+                    step = (snr * noise_norm / grad_norm) ** 2 * 2 * alpha
+                    v_mean = state[k] + step[:, None, None] * scores[k]
+                    state[k] = v_mean + torch.sqrt(step * 2)[:, None, None] * z * scale_eps
+                trans = [sd.transition(v, vec_t, vec_dt) for sd, v in zip(sdes, state)]      # prediction step
+                for k, tg in enumerate(targets):
+                    state[k] = trans[k][0] + trans[k][1][:, None, None] * tg.noise(state[k], flags, src)
+                for k in range(len(state)):
+                    state[k] = state[k] + sdrift[k] * dt
+                trans = [sd.transition(v, vec_t + vec_dt, vec_dt) for sd, v in zip(sdes, state)]
+                for k, tg in enumerate(targets):
+                    state[k] = trans[k][0] + trans[k][1][:, None, None] * tg.noise(state[k], flags, src)
+                    means[k] = trans[k][0]
+                if keep_traj:
+                    traj.append([(m if denoise else v)[0].detach().clone() for m, v in zip(means, state)])
+            out = means if denoise else state
+            return (*out, 0, traj)
+
+    return s4_solver
+

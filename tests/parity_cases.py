@@ -126,21 +126,30 @@ def sampler_from_golden(g, ckpt, case, lib, device, rng="torch_cpu", shape_overr
         d_min, d_max = cfg["data"]["d_min"], cfg["data"]["d_max"]
         kw.update(is_cc=True, sde_rank2=sdes[2], shape_rank2=(B, *rank2_dim(N, d_min, d_max)), d_min=d_min, d_max=d_max)
     kw.update(extra)
-    return solver.get_pc_sampler(**kw), models, flags, names
+    return (solver.S4_solver if sm["predictor"] == "S4" else solver.get_pc_sampler)(**kw), models, flags, names
+
+
+# Trajectory cases whose tolerance is wider than RTOL, with the reason.  ENZYMES_small_CC under S4 with few, large steps:
+# every single score evaluation agrees with the reference to 1.3e-5 (g1 goldens), but ScoreNetworkF is cubic in rank2
+# (H = F F^T, then H F over K = 715) and the first, large-sigma S4 steps amplify fp32 summation-order differences: measured
+# growth 6e-6 -> 3e-5 -> 6e-5 -> 1.1e-4 over steps 1, 2, 3, 5, then flat (x and adj stay at 1e-6).  The CPU emulation of the
+# kernels shows the same figures, and the 1000-scale case of the same checkpoint agrees to 7e-7.
+TRAJ_RTOL = {("s4_ccsd_enzymes_small_CC", "k20"): 5e-4, ("s4_ccsd_enzymes_small_CC", "k4"): 5e-4}
 
 
 def case_pc_sampler_identical_seed(gname, ckpt, case, lib, device):
     """G5: get_pc_sampler closure, every draw from torch's CPU generator -> the reference's CPU outputs."""
+    rtol = TRAJ_RTOL.get((gname, case), RTOL)
     g = load_golden(f"g5_{gname}.npz")
     assert rng_matches(g)
     fn, models, flags, names = sampler_from_golden(g, ckpt, case, lib, device, keep_traj=True)
     torch.manual_seed(int(g["seed"]))
     res = fn(*models, flags.to(device))
     for p, v in zip(names, res):
-        assert_close(v, g[f"{case}/{p}"], f"{gname} {case} {p}")
+        assert_close(v, g[f"{case}/{p}"], f"{gname} {case} {p}", rtol)
     assert int(res[len(names)]) == int(g[f"{case}/nfe"])
     assert len(res[-1]) == int(g[f"{case}/traj_len"])
-    assert_close(res[-1][-1][1], g[f"{case}/traj_last_adj"], "diff_traj[-1] adj")
+    assert_close(res[-1][-1][1], g[f"{case}/traj_last_adj"], "diff_traj[-1] adj", rtol)
     # integer outputs: bit-exact (thresholds are >= 7e-4 away, g[*/min_thr_dist])
     adj = res[1].cpu()
     assert np.array_equal(O.quantize_mol(adj), g[f"{case}/quantize_mol_adj"])

@@ -44,6 +44,10 @@ def test_kat_small_general_paths(lib):
     ("ccsd_qm9_CC_nsteps2_none", "ccsd_qm9_CC", "k6"),
     ("ccsd_qm9_CC_langevin2", "ccsd_qm9_CC", "k4"),
     ("gdss_zinc250k", "gdss_zinc250k", "k5"),
+    ("s4_ccsd_qm9_CC", "ccsd_qm9_CC", "k6"),
+    ("s4_gdss_community_small", "gdss_community_small", "k5"),
+    ("s4_ccsd_enzymes_small_CC", "ccsd_enzymes_small_CC", "k20"),
+    ("s4_ccsd_enzymes_small_CC", "ccsd_enzymes_small_CC", "n1000_first2"),
 ])
 def test_pc_sampler_identical_seed(lib, gname, ckpt, case):
     pc.case_pc_sampler_identical_seed(gname, ckpt, case, lib, DEV)

@@ -153,6 +153,10 @@ G5 = [
     ("gdss_zinc250k", "gdss_zinc250k", ["k5"]),
     ("ccsd_qm9_CC_nsteps2_none", "ccsd_qm9_CC", ["k6"]),
     ("ccsd_qm9_CC_langevin2", "ccsd_qm9_CC", ["k4"]),
+    # S4_solver (solver.py:1179-1563)
+    ("s4_ccsd_enzymes_small_CC", "ccsd_enzymes_small_CC", ["k4", "k20", "n1000_first2"]),
+    ("s4_ccsd_qm9_CC", "ccsd_qm9_CC", ["k6"]),
+    ("s4_gdss_community_small", "gdss_community_small", ["k5"]),
 ]
 
 
@@ -181,7 +185,7 @@ def oracle_sampler_from_golden(g, ckpt, case, noise=None):
     if is_cc:
         d_min, d_max = cfg["data"]["d_min"], cfg["data"]["d_max"]
         kw.update(is_cc=True, sde_rank2=sdes[2], shape_rank2=(B, *O.get_rank2_dim(N, d_min, d_max)), d_min=d_min, d_max=d_max)
-    return O.get_pc_sampler(**kw), nets, flags, parts
+    return (O.S4_solver if sm["predictor"] == "S4" else O.get_pc_sampler)(**kw), nets, flags, parts
 
 
 @pytest.mark.parametrize("gname,ckpt,cases", G5)

@@ -228,7 +228,7 @@ def g5_pc_runs(name, ck, is_cc, B, counts, sampler_cfg, cases, seed):
         if is_cc:
             E, K = ref_cc.get_rank2_dim(N, d_min, d_max)
             kw.update(is_cc=True, sde_rank2=sdes[2], shape_rank2=(B, E, K), d_min=d_min, d_max=d_max)
-        fn = ref_solver.get_pc_sampler(**kw)
+        fn = ref_solver.S4_solver(**kw) if sampler_cfg["predictor"] == "S4" else ref_solver.get_pc_sampler(**kw)
         orig = ref_solver.trange
         if max_steps is not None:
             ref_solver.trange = lambda a, b, **k: range(a, min(b, max_steps))
@@ -358,6 +358,14 @@ def main():
         g5_pc_runs("ccsd_qm9_CC_langevin2", cks["ccsd_qm9_CC"], True, 2, [9, 6],
                    dict(predictor="Reverse", corrector="Langevin", snr=0.2, scale_eps=0.7, n_steps=2),
                    {"k4": (4, None)}, seed=6)
+    if not only or "s4" in only:
+        # S4_solver (solver.py:1179-1563): the sampler the shipped ENZYMES_small_CC config selects
+        s4 = dict(predictor="S4", corrector="None", snr=0.15, scale_eps=0.7, n_steps=1)
+        g5_pc_runs("s4_ccsd_enzymes_small_CC", cks["ccsd_enzymes_small_CC"], True, 2, [12, 9], s4,
+                   {"k4": (4, None), "k20": (20, None), "n1000_first2": (None, 2)}, seed=42)
+        g5_pc_runs("s4_ccsd_qm9_CC", cks["ccsd_qm9_CC"], True, 4, [9, 8, 7, 5], s4, {"k6": (6, None)}, seed=7)
+        g5_pc_runs("s4_gdss_community_small", cks["gdss_community_small"], False, 4, [20, 18, 14, 12], s4,
+                   {"k5": (5, None)}, seed=9)
     if not only or "refkat" in only:
         reference_kat_status()
 
