@@ -119,6 +119,9 @@ def load_ckpt(config, device, ts: Optional[str] = None, return_ckpt: bool = Fals
             for part in ["x", "adj"] + (["rank2"] if is_cc else []):
                 out[f"params_{part}"] = meta[f"params_{part}"]
                 out[f"{part}_state_dict"] = {k.split("/", 1)[1]: torch.from_numpy(z[k]) for k in z.files if k.startswith(part + "/")}
+                ema = {k.split("/", 1)[1]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"ema_{part}/")}
+                if ema:
+                    out[f"ema_{part}"] = ema          # EMA shadow parameters by name (applied when sample.use_ema)
             print(f"{c}.npz loaded")
             break
     else:
@@ -131,7 +134,8 @@ def load_ckpt(config, device, ts: Optional[str] = None, return_ckpt: bool = Fals
             out[f"{part}_state_dict"] = ckpt[f"{part}_state_dict"]
         if _get(_get(config, "sample"), "use_ema", False):
             for part in ["x", "adj"] + (["rank2"] if is_cc else []):
-                out[f"ema_{part}"] = ckpt[f"ema_{part}"]
+                names = [n for n, _ in load_model(out[f"params_{part}"]).named_parameters()]
+                out[f"ema_{part}"] = dict(zip(names, ckpt[f"ema_{part}"]["shadow_params"]))
         if return_ckpt:
             out["ckpt"] = ckpt
     out["config"]["folder"] = folder
@@ -146,8 +150,7 @@ def load_sampling_fn(config_train, config_module, config_sample, device, is_cc: 
     sde_rank2 = load_sde(_get(sde_cfg, "rank2")) if is_cc else None
     data = _get(config_train, "data")
     N, F = _get(data, "max_node_num"), _get(data, "max_feat_num")
-    if _get(config_module, "predictor") == "S4":
-        raise NotImplementedError("S4_solver is not built in this round (SURVEY.md section 8f row 4)")
+    use_s4 = _get(config_module, "predictor") == "S4"          # loader.py:381-384
     if _get(data, "data") in ["QM9", "ZINC250k"]:
         bs = _get(config_sample, "n_samples")
     else:

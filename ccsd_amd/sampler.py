@@ -1,0 +1,207 @@
+"""Sampler harness: the reference's Sampler_{Graph,CC,mol_Graph,mol_CC}.sample() up to quantisation.
+
+Mirrors ccsd/src/sampler.py:92-1235 for the part that is on, or directly around, the reverse-SDE path:
+
+  load_ckpt -> load_seed(config.seed) -> load_model_from_ckpt x3 (EMA weights if sample.use_ema)
+  -> load_sampling_fn(configt, config.sampler, config.sample, device, is_cc, d_min, d_max, divide_batch)
+  -> load_seed(config.sample.seed) -> [init_flags -> sampling_fn] x divide_batch (x sampling rounds for the generic
+  datasets) -> torch.cat -> quantize / quantize_mol (+ the molecule relabelling and one-hot of sampler.py:1216-1225)
+
+What follows in the reference -- rdkit molecule construction, toponetx complexes, MMD / NSPDK / FCD metrics, pickles,
+plots, wandb -- is out of scope; `sample()` returns the tensors those steps consume and, when
+`save=True`, writes them to <folder>/samples/<log name>.npz.
+
+init_flags (cc_utils.py:883-914): the reference draws `np.random.randint(0, len(train_list), batch)` and takes the node
+flags of those training objects.  Only the node COUNT of each training object matters, so this build ships the counts
+(ccsd_amd/data/node_counts.json: per-graph node counts of the pickled datasets in file order -> the same indices pick
+the same flags for the same numpy seed).  QM9 / ZINC250k need the csv blobs the reference repository does not ship:
+there the flags are drawn from the test-set node-count histogram instead (documented deviation).
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import time
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import loader
+from .engine import PCEngine
+from .loader import AttrDict, _get
+
+_COUNTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "node_counts.json")
+
+
+def _dataset_key(name: str) -> str:
+    return name[:-3] if name.endswith("_CC") else name
+
+
+def train_node_counts(configt, with_test_size: bool = False):
+    """Node counts of the training split, in the order the reference's load_data(get_list=True) returns it
+    (and, on request, the size of the test split, which sets the number of sampling rounds)."""
+    with open(_COUNTS) as f:
+        table = json.load(f)
+    data = _get(configt, "data")
+    entry = table.get(_dataset_key(_get(data, "data")))
+    if entry is None or "node_counts" not in entry:
+        return (None, 0) if with_test_size else None
+    counts = np.asarray(entry["node_counts"], dtype=np.int64)
+    test_size = int(_get(data, "test_split", 0.2) * len(counts))          # data_loader.py:80-81, 109-110
+    return (counts[test_size:], test_size) if with_test_size else counts[test_size:]
+
+
+def init_flags(obj_counts, config, batch_size: Optional[int] = None, is_cc: bool = False) -> torch.Tensor:
+    """cc_utils.py:883-914 on node counts: flags[b, :n_b] = 1 with n_b the node count of a uniformly drawn training
+    object (np.random.randint on the global numpy stream, like the reference).  `obj_counts` may also be a
+    {node count: frequency} histogram (QM9 / ZINC250k, see the module docstring)."""
+    data = _get(config, "data")
+    if batch_size is None:
+        batch_size = _get(data, "batch_size")
+    N = _get(data, "max_node_num")
+    if isinstance(obj_counts, dict):
+        ks = np.array([int(k) for k in obj_counts], dtype=np.int64)
+        p = np.array([float(v) for v in obj_counts.values()], dtype=np.float64)
+        counts = np.random.choice(ks, size=batch_size, p=p / p.sum())
+    else:
+        counts = np.asarray(obj_counts, dtype=np.int64)
+        counts = counts[np.random.randint(0, len(counts), batch_size)]
+    flags = torch.zeros(batch_size, N)
+    for b, c in enumerate(counts):
+        flags[b, : int(min(c, N))] = 1.0
+    return flags
+
+
+class Sampler:
+    """One class for the four reference samplers: `is_cc` and the dataset name select the behaviour."""
+
+    def __init__(self, config) -> None:
+        self.config = config if isinstance(config, AttrDict) else AttrDict(config)
+        self.is_cc = bool(_get(self.config, "is_cc", False))
+        self.is_mol = _get(_get(self.config, "data"), "data") in ("QM9", "ZINC250k")
+        self.device = loader.load_device()
+        self.device0 = loader._device_id(self.device)
+        sample = _get(self.config, "sample")
+        self.n_samples = _get(sample, "n_samples", None) if self.is_mol else None
+        self.divide_batch = _get(sample, "divide_batch", 1) or 1
+        self.extra = {}          # forwarded to get_pc_sampler / S4_solver (rng, seed, keep_traj, group, lib, ...)
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}(is_cc={self.is_cc}, data={_get(_get(self.config, 'data'), 'data')})"
+
+    # -- pieces of sample(), reusable on their own
+    def load(self):
+        cfg = self.config
+        self.ckpt_dict = loader.load_ckpt(cfg, self.device, is_cc=self.is_cc)
+        self.configt = self.ckpt_dict["config"]
+        loader.load_seed(_get(cfg, "seed", 42))
+        parts = ["x", "adj"] + (["rank2"] if self.is_cc else [])
+        use_ema = bool(_get(_get(cfg, "sample"), "use_ema", False))
+        self.models = []
+        for p in parts:
+            sd = dict(self.ckpt_dict[f"{p}_state_dict"])
+            if use_ema:
+                ema = self.ckpt_dict.get(f"ema_{p}")
+                if ema is None:
+                    raise KeyError(f"sample.use_ema is set but the checkpoint holds no EMA weights for {p}")
+                sd.update(ema)                                            # ema.copy_to(model.parameters()), sampler.py:469-471
+            self.models.append(loader.load_model_from_ckpt(self.ckpt_dict[f"params_{p}"], sd, self.device))
+        data = _get(cfg, "data")
+        self.sampling_fn = loader.load_sampling_fn(self.configt, _get(cfg, "sampler"), _get(cfg, "sample"), self.device,
+                                                   is_cc=self.is_cc, d_min=_get(data, "d_min"), d_max=_get(data, "d_max"),
+                                                   divide_batch=self.divide_batch, **self.extra)
+        counts, self.n_test = train_node_counts(self.configt, with_test_size=True)
+        if counts is None:
+            with open(_COUNTS) as f:
+                entry = json.load(f).get(_dataset_key(_get(_get(self.configt, "data"), "data")), {})
+            counts = entry.get("test_histogram")
+            if counts is None:
+                raise FileNotFoundError(f"no node counts for dataset {_get(_get(self.configt, 'data'), 'data')}: pass "
+                                        "`node_counts=` to sample()")
+        self.node_counts = counts
+
+    def sample(self, save: bool = False, node_counts=None, rounds: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        cfg = self.config
+        self.load()
+        if node_counts is not None:
+            self.node_counts = node_counts
+        loader.load_seed(_get(_get(cfg, "sample"), "seed", 42))
+        datat = _get(self.configt, "data")
+        if self.is_mol:
+            qty = self.n_samples // self.divide_batch                        # sampler.py:1185-1187
+            n_rounds = 1
+        else:
+            qty = None
+            bs = _get(datat, "batch_size")
+            n_rounds = rounds if rounds is not None else max(1, math.ceil(self.n_test / bs))   # sampler.py:488-490
+            if self.divide_batch > 1:
+                qty = bs // self.divide_batch
+        t0 = time.perf_counter()
+        outs: List[List[torch.Tensor]] = []
+        flags_all = []
+        for _ in range(n_rounds):
+            parts = None
+            for _d in range(self.divide_batch):
+                fl = init_flags(self.node_counts, self.configt, qty, is_cc=self.is_cc).to(self.device0)
+                res = self.sampling_fn(*self.models, fl)
+                nt = 3 if self.is_cc else 2
+                parts = list(res[:nt]) if parts is None else [torch.cat((a, b), dim=0) for a, b in zip(parts, res[:nt])]
+                flags_all.append(fl)
+            outs.append(parts)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        sampling_time = time.perf_counter() - t0
+        x, adj = (torch.cat([o[k] for o in outs], dim=0) for k in (0, 1))
+        rank2 = torch.cat([o[2] for o in outs], dim=0) if self.is_cc else None
+        out: Dict[str, torch.Tensor] = {"x": x, "adj": adj, "flags": torch.cat(flags_all, dim=0)}
+        quant = PCEngine(None, None, None, None, None, None, N=adj.shape[-1], F=1, is_cc=False, device=self.device0,
+                         lib=self.extra.get("lib"))
+        if self.is_mol:
+            samples_int = quant.quantize(adj, -1.0)                          # quantize_mol, graph_utils.py:195-213
+            samples_int = samples_int - 1
+            samples_int[samples_int == -1] = 3                               # 0,1,2,3 (no,S,D,T) -> 3,0,1,2 (sampler.py:1219-1220)
+            out["adj_int"] = samples_int
+            out["adj_onehot"] = torch.nn.functional.one_hot(samples_int, num_classes=4).permute(0, 3, 1, 2)
+            xi = torch.where(x > 0.5, 1, 0)
+            out["x_onehot"] = torch.concat([xi, 1 - xi.sum(dim=-1, keepdim=True)], dim=-1)
+        else:
+            out["adj_int"] = quant.quantize(adj, 0.5)                        # quantize, graph_utils.py:181-192
+        if self.is_cc:
+            out["rank2"] = rank2
+            out["rank2_int"] = quant.quantize(rank2, 0.5).to(torch.uint8)
+        out["sampling_time"] = torch.tensor(sampling_time)
+        self.result = out
+        if save:
+            folder = os.path.join(_get(cfg, "folder", "./"), "samples")
+            os.makedirs(folder, exist_ok=True)
+            name = f"{_get(cfg, 'config_name', 'sample')}_{_get(cfg, 'ckpt')}-sample_{_get(cfg, 'current_time', 'now')}"
+            np.savez_compressed(os.path.join(folder, name + ".npz"), **{k: v.detach().cpu().numpy() for k, v in out.items()})
+        print("Sampling done.")
+        return out
+
+
+# the reference's four class names (sampler.py:92, 369, 684, 1061) and its factory (sampler.py:1438-1468)
+class Sampler_Graph(Sampler):
+    pass
+
+
+class Sampler_CC(Sampler):
+    pass
+
+
+class Sampler_mol_Graph(Sampler):
+    pass
+
+
+class Sampler_mol_CC(Sampler):
+    pass
+
+
+def get_sampler_from_config(config) -> Sampler:
+    config = config if isinstance(config, AttrDict) else AttrDict(config)
+    is_cc = bool(_get(config, "is_cc", False))
+    is_mol = _get(_get(config, "data"), "data") in ("QM9", "ZINC250k")
+    cls = (Sampler_mol_CC if is_cc else Sampler_mol_Graph) if is_mol else (Sampler_CC if is_cc else Sampler_Graph)
+    return cls(config)

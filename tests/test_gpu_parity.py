@@ -121,3 +121,18 @@ def test_alternative_kernel_paths_qm9(lib, env, monkeypatch):
     pc.case_forward_vs_reference_golden("ccsd_qm9_CC", lib, DEV)
     pc.case_pc_sampler_identical_seed("ccsd_qm9_CC", "ccsd_qm9_CC", "k10", lib, DEV)
     pc.case_philox_properties(lib, DEV)
+
+
+def test_ccsd_api_yaml_surface_on_gpu(lib, tmp_path):
+    """CCSD(type="sample", config=<yaml>).run()-equivalent flow on the HIP path: qm9_CC (Reverse+Langevin, divide_batch) and
+    the shipped ENZYMES_small_CC config (S4 solver, EMA weights)."""
+    from tests import test_harness as H
+
+    out, c = H.run_harness(tmp_path, lib, None, "sample_qm9_CC", dict(H.QM9_CC_YAML, sample=dict(H.QM9_CC_YAML["sample"], n_samples=64)),
+                           max_steps=20)
+    assert out["adj"].is_cuda and out["adj"].shape == (64, 9, 9) and out["rank2"].shape == (64, 36, 466)
+    assert torch.isfinite(out["rank2"]).all() and set(out["adj_int"].unique().tolist()) <= {0, 1, 2, 3}
+    fl = out["flags"]
+    assert torch.equal(out["adj"], out["adj"] * fl[:, :, None] * fl[:, None, :])
+    out, c = H.run_harness(tmp_path, lib, None, "sample_enzymes_small_CC", H.ENZYMES_YAML, max_steps=10, rounds=1)
+    assert out["adj"].shape[1:] == (12, 12) and torch.isfinite(out["rank2"]).all()

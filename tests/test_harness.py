@@ -1,0 +1,100 @@
+"""Sampler harness / CCSD API / YAML surface (ccsd_amd.sampler, ccsd_amd.diffusion): the reference's
+Sampler_*.sample() flow up to quantisation (sampler.py:1104-1235, 415-545; diffusion.py:27-200).  CPU: the product code
+runs over the host emulation of the kernel source (explicit lib=); the GPU twin lives in test_gpu_parity.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from ccsd_amd import sampler as S
+from ccsd_amd.diffusion import CCSD, get_config
+from ccsd_amd.loader import AttrDict
+
+QM9_CC_YAML = {
+    "is_cc": True,
+    "data": {"data": "QM9", "dir": "./data", "max_node_num": 9, "min_node_val": 6, "max_node_val": 9, "node_label": "symbol",
+             "min_edge_val": 1, "max_edge_val": 3, "edge_label": "bond_type", "d_min": 3, "d_max": 9},
+    "ckpt": "ccsd_qm9_CC",
+    "sampler": {"predictor": "Reverse", "corrector": "Langevin", "snr": 0.2, "scale_eps": 0.7, "n_steps": 1},
+    "sample": {"divide_batch": 2, "n_samples": 8, "cc_nb_eval": 1000, "use_ema": False, "noise_removal": True,
+               "probability_flow": False, "eps": 1.0e-4, "seed": 42},
+}
+ENZYMES_YAML = {
+    "is_cc": True,
+    "data": {"data": "ENZYMES_small_CC", "dir": "./data", "d_min": 3, "d_max": 4},
+    "ckpt": "ccsd_enzymes_small_CC",
+    "sampler": {"predictor": "S4", "corrector": "None", "snr": 0.15, "scale_eps": 0.7, "n_steps": 1},
+    "sample": {"use_ema": True, "noise_removal": True, "probability_flow": False, "eps": 1.0e-4, "seed": 42},
+}
+
+
+def write_cfg(tmp_path, name, cfg):
+    os.makedirs(tmp_path / "config", exist_ok=True)
+    with open(tmp_path / "config" / f"{name}.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+
+
+def test_init_flags_follows_the_numpy_stream():
+    """Same indices as the reference's np.random.randint over the train split (cc_utils.py:906-907)."""
+    cfgt = AttrDict({"data": {"data": "community_small_CC", "max_node_num": 20, "batch_size": 16, "test_split": 0.2}})
+    counts = S.train_node_counts(cfgt)
+    table = json.load(open(S._COUNTS))["community_small"]["node_counts"]
+    assert len(counts) == 80 and list(counts) == table[20:]
+    np.random.seed(12)
+    fl = S.init_flags(counts, cfgt)
+    np.random.seed(12)
+    idx = np.random.randint(0, 80, 16)
+    want = torch.zeros(16, 20)
+    for b, i in enumerate(idx):
+        want[b, : counts[i]] = 1
+    assert torch.equal(fl, want)
+    assert S.init_flags(counts, cfgt, 5).shape == (5, 20)
+
+
+def run_harness(tmp_path, lib, device_patch, name, cfg, max_steps, **kw):
+    write_cfg(tmp_path, name, cfg)
+    c = CCSD("sample", name + ".yaml", folder=str(tmp_path), seed=42)
+    assert get_config(name, 42, str(tmp_path)).ckpt == cfg["ckpt"]
+    with pytest.raises(NotImplementedError):
+        CCSD("train", name, folder=str(tmp_path)).run()
+    c.sampler = S.get_sampler_from_config(c.cfg)
+    c.sampler.extra = dict(lib=lib, max_steps=max_steps)
+    return c.sampler.sample(save=True, **kw), c
+
+
+def test_ccsd_sample_qm9_cc_yaml(tmp_path):
+    from tests.emu_util import emu_library
+
+    out, c = run_harness(tmp_path, emu_library(), None, "sample_qm9_CC", QM9_CC_YAML, max_steps=2)
+    assert type(c.sampler).__name__ == "Sampler_mol_CC"
+    assert out["x"].shape == (8, 9, 4) and out["adj"].shape == (8, 9, 9) and out["rank2"].shape == (8, 36, 466)
+    assert out["flags"].shape == (8, 9) and set(out["flags"].unique().tolist()) <= {0.0, 1.0}
+    assert out["adj_int"].dtype == torch.int64 and set(out["adj_int"].unique().tolist()) <= {0, 1, 2, 3}
+    assert out["adj_onehot"].shape == (8, 4, 9, 9) and out["x_onehot"].shape == (8, 9, 5)
+    assert out["rank2_int"].dtype == torch.uint8
+    # relabelling of sampler.py:1219-1220: "no bond" (quantize_mol 0) -> 3
+    from oracle import ccsd_oracle as O
+    q = torch.as_tensor(O.quantize_mol(out["adj"].clone()))
+    assert torch.equal(out["adj_int"], torch.where(q == 0, torch.full_like(q, 3), q - 1))
+    assert len(os.listdir(tmp_path / "samples")) == 1
+    # masked entries stay masked through the whole flow
+    fl = out["flags"]
+    assert torch.equal(out["adj"], out["adj"] * fl[:, :, None] * fl[:, None, :])
+
+
+def test_ccsd_sample_enzymes_s4_ema_yaml(tmp_path):
+    """The shipped ENZYMES_small_CC sampling config: S4 solver + EMA weights; one round of the generic-dataset loop."""
+    from tests.emu_util import emu_library
+
+    out, c = run_harness(tmp_path, emu_library(), None, "sample_enzymes_small_CC", ENZYMES_YAML, max_steps=1, rounds=1)
+    assert type(c.sampler).__name__ == "Sampler_CC"
+    B = c.sampler.configt.data.batch_size
+    assert out["adj"].shape == (B, 12, 12) and out["rank2"].shape[0] == B
+    assert set(out["adj_int"].unique().tolist()) <= {0, 1}
+    ema = c.sampler.ckpt_dict["ema_adj"]
+    sd = c.sampler.models[1].state_dict()
+    k = next(iter(ema))
+    assert torch.equal(sd[k].cpu(), ema[k]) and not torch.equal(ema[k], c.sampler.ckpt_dict["adj_state_dict"][k])

@@ -73,6 +73,14 @@ def export_checkpoint(name):
         for k, v in sd.items():
             k = k[7:] if k.startswith("module.") else k
             arrays[f"{part}/{k}"] = v.detach().cpu().numpy().astype(np.float32)
+        if f"ema_{part}" in ck:
+            # torch_ema state: shadow_params in model.parameters() order (loader.py:169-184, sampler.py:469-471)
+            m = ref_loader.load_model_from_ckpt(ck[f"params_{part}"], sd, "cpu")
+            names = [n[7:] if n.startswith("module.") else n for n, _ in m.named_parameters()]
+            shadow = ck[f"ema_{part}"]["shadow_params"]
+            assert len(names) == len(shadow)
+            for n, v in zip(names, shadow):
+                arrays[f"ema_{part}/{n}"] = v.detach().cpu().numpy().astype(np.float32)
     np.savez_compressed(os.path.join(CKPT, name + ".npz"), **arrays)
     with open(os.path.join(CKPT, name + ".json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
