@@ -25,7 +25,7 @@ EXPORTS = [
     "ccsd_last_error", "ccsd_score", "ccsd_init_state", "ccsd_corrector_norms", "ccsd_corrector_apply",
     "ccsd_predictor", "ccsd_s4_apply", "ccsd_sampler_run", "ccsd_quantize", "ccsd_profile_kernel", "ccsd_profile_read", "ccsd_debug_stamps",
 ]
-KERNEL_IDS = {"k_xa": 0, "k_gemm_p": 1, "k_hf_score": 2, "k_gemm_h": 3, "k_langevin_apply": 4, "k_r2": 5}
+KERNEL_IDS = {"k_xa": 0, "k_gemm_p": 1, "k_hf_score": 2, "k_gemm_h": 3, "k_langevin_apply": 4, "k_r2": 5, "k_s4_apply": 6}
 
 
 class StepCoef(C.Structure):

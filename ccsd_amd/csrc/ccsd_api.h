@@ -36,7 +36,7 @@ struct ccsd_plan {
 #endif
 };
 
-enum { KID_XA = 0, KID_GEMM_P = 1, KID_HF = 2, KID_GEMM_H = 3, KID_LANGEVIN = 4, KID_R2 = 5 };
+enum { KID_XA = 0, KID_GEMM_P = 1, KID_HF = 2, KID_GEMM_H = 3, KID_LANGEVIN = 4, KID_R2 = 5, KID_S4 = 6 };
 static void prof_mark(ccsd_plan* pl, int kid, void* stream) {
 #ifndef CCSD_EMU
     if (!(pl->prof_mask & (1u << kid))) return;
@@ -506,8 +506,10 @@ static int corrector_apply(ccsd_plan* pl, int B, int step, int it, const ccsd_st
     a.snr = p.snr; a.seps = p.seps;
     a.B = B; a.N = p.N; a.F = p.F; a.E = p.E; a.K = p.K; a.is_cc = p.is_cc;
     const long long total = (long long)B * (p.N * p.F + p.N * p.N) + (p.is_cc ? (long long)B * ((p.E + 3) / 4) * p.K : 0);
+    prof_mark(pl, KID_LANGEVIN, stream);
     CCSD_LAUNCH(k_langevin_apply, dim3(grid_for(total, 256)), dim3(CCSD_NTHREADS), 0, stream, a, na,
                 (const unsigned long long*)w.offbits, (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells);
+    prof_mark(pl, KID_LANGEVIN, stream);
     LAUNCH_CHECK();
     return CCSD_OK;
 }
@@ -575,8 +577,10 @@ static int s4_apply(ccsd_plan* pl, int B, int step, const ccsd_state_t* cur, con
     NoiseArgs na2 = make_noise(n2, seed, off, draw_base(pl, step, 1));
     NoiseArgs na3 = make_noise(n3, seed, off, draw_base(pl, step, 2));
     const long long total = (long long)B * (p.N * p.F + p.N * p.N) + (p.is_cc ? (long long)B * ((p.E + 3) / 4) * p.K : 0);
+    prof_mark(pl, KID_S4, stream);
     CCSD_LAUNCH(k_s4_apply, dim3(grid_for(total, 256)), dim3(CCSD_NTHREADS), 0, stream, q, na1, na2, na3,
                 (const unsigned long long*)w.offbits, (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells);
+    prof_mark(pl, KID_S4, stream);
     LAUNCH_CHECK();
     return CCSD_OK;
 }
