@@ -1664,7 +1664,13 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
     // ================= ScoreNetworkA / ScoreNetworkA_CC =================
     if (xa.do_a) {
         float* s_chan = GCH ? xa.chan_ws + (size_t)b * p.a_fdim * NN : sm + p.o_chan;
-        auto pair_off = [&](int e) { return (int)edges[2 * e] * N + (int)edges[2 * e + 1]; };   // unordered pair e -> (i, j), i < j
+        // unordered pair e -> (i, j), i < j: the edge table, copied to LDS once (the global copy costs an L2 round trip
+        // at the head of every per-pair phase)
+        int* s_edge = reinterpret_cast<int*>(sm + p.o_edge);
+        for (int e = tid; e < E; e += nth) s_edge[e] = ((int)edges[2 * e] << 8) | (int)edges[2 * e + 1];
+        auto edge_i = [&](int e) { return s_edge[e] >> 8; };
+        auto edge_j = [&](int e) { return s_edge[e] & 255; };
+        auto pair_off = [&](int e) { const int v = s_edge[e]; return (v >> 8) * N + (v & 255); };
         float* s_att = sm + p.o_att;
         float* s_xcur = sm + p.o_xcur;
         float* s_xnext = sm + p.o_xnext;
@@ -1744,7 +1750,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                 for (int t = tid; t < gc * E; t += nth) {
                     int c, e;
                     dE.divmod(t, c, e);
-                    const int i = edges[2 * e], j = edges[2 * e + 1];
+                    const int i = edge_i(e), j = edge_j(e);
                     const float* qi = s_qkv + c * N * cols + i * cols;
                     const float* qj = s_qkv + c * N * cols + j * cols;
                     float s1 = 0.f, s2 = 0.f;
@@ -1792,7 +1798,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                 // write  (_adj + _adj^T) * mask  (attention.py:301-302) to both halves from the epilogue.
                 mlp_chain<1, 1, 1>(L.mlp, wp, s_att, NN, adj_in, L.cin, E, pair_off,
                                    [&](int e, int f, float v) {
-                                       const int i = edges[2 * e], j = edges[2 * e + 1];
+                                       const int i = edge_i(e), j = edge_j(e);
                                        const float sv = (v + v) * s_flags[i] * s_flags[j];
                                        chan_out[f * NN + i * N + j] = sv;
                                        chan_out[f * NN + j * N + i] = sv;
@@ -1890,7 +1896,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                         in[c] = sacc;
                     }
                     small_mlp_lds<CCSD_SMALLW>(s_hw, h0.matt.n, in, out);   // mlp_attention -> mask -> tanh -> + transpose
-                    const float fh = s_flags[edges[2 * e]] * s_flags[edges[2 * e + 1]];
+                    const float fh = s_flags[edge_i(e)] * s_flags[edge_j(e)];
 #pragma unroll
                     for (int o = 0; o < CCSD_SMALLW; ++o)
                         if (o < h0.cout) { const float tv = tanh_f(out[o] * fh * fh); s_hd[(p.a_cinit + o) * E + e] = tv + tv; }
@@ -1921,8 +1927,11 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                     }
                 }
 #endif
+                int pe_n = 0, pe2_n = 0;
+                if (tid < npair) { pe_n = xa.hpairs[2 * tid]; pe2_n = xa.hpairs[2 * tid + 1]; }
                 for (int t = tid; t < npair; t += nth) {
-                    const int e = xa.hpairs[2 * t], e2 = xa.hpairs[2 * t + 1];
+                    const int e = pe_n, e2 = pe2_n;
+                    if (t + nth < npair) { pe_n = xa.hpairs[2 * (t + nth)]; pe2_n = xa.hpairs[2 * (t + nth) + 1]; }   // next pair: in flight
                     float in[CCSD_SMALLW], out[CCSD_SMALLW];
 #pragma unroll
                     for (int c = 0; c < CCSD_SMALLW; ++c) {
@@ -1946,8 +1955,8 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                         in[c] = v;
                     }
                     if (w4_0) small_mlp_lds<4>(s_hw, h0.matt.n, in, out); else small_mlp_lds<CCSD_SMALLW>(s_hw, h0.matt.n, in, out);
-                    const float fh = s_flags[edges[2 * e]] * s_flags[edges[2 * e + 1]];
-                    const float fh2 = s_flags[edges[2 * e2]] * s_flags[edges[2 * e2 + 1]];
+                    const float fh = s_flags[edge_i(e)] * s_flags[edge_j(e)];
+                    const float fh2 = s_flags[edge_i(e2)] * s_flags[edge_j(e2)];
 #pragma unroll
                     for (int o = 0; o < CCSD_SMALLW; ++o)
                         if (o < h0.cout) {
@@ -2046,7 +2055,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                         in[c] = sacc;
                     }
                     if (w4_1) small_mlp_lds<4>(s_hw + p.hw_stride, h1.matt.n, in, out); else small_mlp_lds<CCSD_SMALLW>(s_hw + p.hw_stride, h1.matt.n, in, out);
-                    const float fh = s_flags[edges[2 * e]] * s_flags[edges[2 * e + 1]];
+                    const float fh = s_flags[edge_i(e)] * s_flags[edge_j(e)];
 #pragma unroll
                     for (int o = 0; o < CCSD_SMALLW; ++o)
                         if (o < h1.cout) { const float tv = tanh_f(out[o] * fh * fh); s_hd[(p.a_cinit + h0.cout + o) * E + e] = tv + tv; }
@@ -2058,7 +2067,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
             for (int t = tid; t < p.a_nch_hodge * E; t += nth) {
                 int c, e;
                 dE.divmod(t, c, e);
-                const int i = edges[2 * e], j = edges[2 * e + 1];
+                const int i = edge_i(e), j = edge_j(e);
                 const float v = s_hd[t];
                 s_chan[(p.a_nch_graph + c) * NN + i * N + j] = v;
                 s_chan[(p.a_nch_graph + c) * NN + j * N + i] = v;
@@ -2077,7 +2086,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
             const int rows = (NN - p0) < fc ? (NN - p0) : fc;
             if (m.chain) {
                 // symmetric input channels, masked diagonal: the E unordered pairs suffice (see the edge MLP above)
-                auto epf = [&](int e, int f, float v) { (void)f; const int i = edges[2 * e], j = edges[2 * e + 1]; f0[i * N + j] = v; f0[j * N + i] = v; };
+                auto epf = [&](int e, int f, float v) { (void)f; const int i = edge_i(e), j = edge_j(e); f0[i * N + j] = v; f0[j * N + i] = v; };
                 if (m.chain == 3) mlp_chain<2, 4, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
                 else if (m.chain == 4) mlp_chain<3, 5, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
                 else if (m.chain == 5) mlp_chain<3, 6, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);

@@ -74,6 +74,7 @@ struct PlanD {
     int o_wst, wst_floats;      // weight staging buffer (0 floats: weights are read in place)
     int o_hw, hw_stride;        // zero-padded hodge mlp_attention weight blocks (stride between the two layers)
     int o_deg;                  // degree scratch of the dense hodge layer
+    int o_edge;                 // LDS copy of the edge table (E ints)
     int chan_global;            // 1: the channel stack [a_fdim][N*N] lives in the HBM workspace (large graphs), not in LDS
 };
 
@@ -322,6 +323,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             p->o_x = carve(N * F);
             p->o_adj = carve(NN);
             p->o_an = carve(cg * N > N ? cg * N : N);                       // D^-1/2 per channel of the group
+            p->o_edge = carve(E);
             const int phase0 = o;
             p->o_xcat = carve(p->x_fdim * p->ldn);                          // X-network phase ...
             p->o_h1 = carve(2 * p->x_fdim * p->ldn);
