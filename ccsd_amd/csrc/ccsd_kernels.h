@@ -374,7 +374,11 @@ CCSD_DEV void mlp_chain_tile(const MlpD& m, const float* __restrict__ wp, const 
         for (int f = 0; f < m.out; ++f) epi(row, f, a[f]);
     }
 #else
-    const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+    // The lane id is made opaque here: otherwise the per-lane index / address arithmetic of EVERY shape instantiated in a
+    // kernel is hoisted above the shape dispatch and spilled to scratch (42 MB of spill writes per k_xa launch, PMC).
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const int l15 = lane & 15, kq = lane >> 4;
     const int prow = rowoff((p0 + l15 < rows) ? p0 + l15 : rows - 1);      // clamped: rows beyond `rows` are never stored
     const int in = m.in;
     chain_f32x4 xin[NI], h0[NH], h1[NH], yo[NO];
