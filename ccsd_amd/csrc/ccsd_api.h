@@ -333,9 +333,9 @@ static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Work
     xa.wp = pl->wp; xa.hpairs = pl->hpairs;
     const dim3 xblk(CCSD_NTHREADS == 1 ? 1 : xa_threads);
     const size_t xlds = (size_t)pl->h.xa_lds_floats * 4;
-#define XA_GO(G_) CCSD_LAUNCH((k_xa<G_>), dim3(B), xblk, xlds, stream, (const PlanD*)pl->d, (const float*)pl->w, \
-                              (const unsigned char*)pl->edges, xa, na)
-    if (pl->h.chan_global) XA_GO(true); else XA_GO(false);
+#define XA_GO(G_, XA_, BLK_, LDS_, STR_) CCSD_LAUNCH((k_xa<G_>), dim3(B), BLK_, LDS_, STR_, (const PlanD*)pl->d, (const float*)pl->w, \
+                                                     (const unsigned char*)pl->edges, XA_, na)
+    { if (pl->h.chan_global) XA_GO(true, xa, xblk, xlds, stream); else XA_GO(false, xa, xblk, xlds, stream); }
 #undef XA_GO
     prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
     LAUNCH_CHECK();

@@ -1583,8 +1583,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
     float* s_x = sm + p.o_x;
     float* s_adj = sm + p.o_adj;
     float* s_dinv = sm + p.o_an;
-    float* s_tmp = sm + p.o_tmp;
-    float* s_red = sm + p.o_red;
+    float* s_red = sm + (xa.do_a ? p.o_red : p.o_xcat);   // block reductions: a region that is idle at the end of the launch
     float* s_R = sm + p.o_c0;            // shared region: GCN scratch | MLP hidden activations | dense hodge layer
     const FastDiv dN(N), dNN(NN), dF(F), dE(E > 0 ? E : 1);
     const float* wp = xa.wp;

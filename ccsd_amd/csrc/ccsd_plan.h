@@ -75,6 +75,7 @@ struct PlanD {
     int o_hw, hw_stride;        // zero-padded hodge mlp_attention weight blocks (stride between the two layers)
     int o_deg;                  // degree scratch of the dense hodge layer
     int o_edge;                 // LDS copy of the edge table (E ints)
+    int x_lds_floats;           // LDS of an X-network-only launch (the ScoreNetworkX phase's regions)
     int chan_global;            // 1: the channel stack [a_fdim][N*N] lives in the HBM workspace (large graphs), not in LDS
 };
 
@@ -326,21 +327,32 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             p->o_edge = carve(E);
             const int phase0 = o;
             p->o_xcat = carve(p->x_fdim * p->ldn);                          // X-network phase ...
-            p->o_h1 = carve(2 * p->x_fdim * p->ldn);
-            p->o_h2 = carve(2 * p->x_fdim * p->ldn);
+            // hidden activations of the head: in registers when it is chained (then h1 only receives the F outputs)
+            p->o_h1 = carve(p->x_fin.chain ? (F > 4 ? F : 4) * p->ldn : 2 * p->x_fdim * p->ldn);
+            p->o_h2 = carve(p->x_fin.chain ? 4 : 2 * p->x_fdim * p->ldn);
             const int xphase_end = o;
+            p->x_lds_floats = xphase_end + 64;
             o = phase0;                                                     // ... aliased by the A-network phase
             p->o_chan = gch ? 0 : carve(p->a_fdim * NN);
-            p->o_tmp = carve(cg * NN);                                      // raw attention of a channel group
-            p->o_att = carve(cinmax * NN);                                  // contiguous with o_tmp (hodge scratch aliases both)
+            p->o_tmp = o;                                                   // (raw attention scratch: gone, symmetrisation is fused)
+            p->o_att = carve(cinmax * NN);                                  // attention of every input channel
             p->o_xcur = carve(fmaxA * p->ldn);
             p->o_xnext = carve(fmaxA * p->ldn);
+            const int o_after_xnext = o;
             p->o_vcat = carve(mchid * p->ldn);                              // hidden layer of multi_channel
             p->o_deg = p->o_vcat;
             if (p->h_L) {
                 // the hodge branch runs after the attention stack: its Q|K scratch reuses [raw attention | attention]
-                if (hq_floats <= (cg + cinmax) * NN) p->o_hq = p->o_tmp; else p->o_hq = carve(hq_floats);
-                if (p->h_L > 1 && p->hl[1].cin * E > mchid * p->ldn) p->o_deg = carve(p->hl[1].cin * E);
+                // the hodge branch runs after the attention stack: its Q|K scratch reuses [attention | node features |
+                // multi_channel hidden] (all dead by then); the degree scratch then needs its own slot
+                if (hq_floats <= o - p->o_att) {
+                    p->o_hq = p->o_att;
+                    if (p->h_L > 1 && (hq_floats > o_after_xnext - p->o_att || p->hl[1].cin * E > mchid * p->ldn))
+                        p->o_deg = carve(p->hl[1].cin * E);
+                } else {
+                    p->o_hq = carve(hq_floats);
+                    if (p->h_L > 1 && p->hl[1].cin * E > mchid * p->ldn) p->o_deg = carve(p->hl[1].cin * E);
+                }
                 p->o_hd = carve(p->a_nch_hodge * E);
                 p->o_hw = carve(2 * hw_n * 72);
                 p->hw_stride = hw_n * 72;
