@@ -703,3 +703,12 @@ extern "C" int ccsd_quantize(const float* in, int64_t n, float thr, int64_t* out
     LAUNCH_CHECK();
     return CCSD_OK;
 }
+
+extern "C" int ccsd_rank2_cells(const float* rank2, int32_t B, int32_t E, int64_t K, float thr, uint64_t* bits, int32_t* counts,
+                                void* stream) {
+    if (!rank2 || !bits || !counts || B < 1 || E < 1 || K < 1 || K > (1 << 24)) return set_err(CCSD_ERR_INVALID, "bad argument");
+    CCSD_LAUNCH(k_rank2_cells, dim3(B), dim3(CCSD_NTHREADS), 0, stream, rank2, (int)E, (int)K, thr, (unsigned long long*)bits, (int*)counts);
+    LAUNCH_CHECK();
+    return CCSD_OK;
+}
+

@@ -2346,3 +2346,47 @@ __global__ void k_quantize(const float* __restrict__ in, long long n, float thr,
         out[t] = q;
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// k_rank2_cells: sparse form of the quantised rank-2 incidence matrix -- the input cc_from_incidence needs
+// (cc_utils.py:243-262: column k holds a rank-2 cell iff any of its entries is non-zero after quantize()).
+// bits[b][k / 64] bit (k % 64) = any_e( rank2[b][e][k] >= thr );  counts[b] = number of set bits.
+// One workgroup per complex; a wave covers 64 consecutive columns per pass (coalesced rows), its ballot is the word.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_rank2_cells(const float* __restrict__ rank2, int E, int K, float thr, unsigned long long* __restrict__ bits,
+                              int* __restrict__ counts) {
+    const int b = blockIdx.x, W = (K + 63) >> 6;
+    const float* Fb = rank2 + (size_t)b * E * K;
+#ifdef CCSD_EMU
+    int total = 0;
+    for (int wd = 0; wd < W; ++wd) {
+        unsigned long long m = 0;
+        for (int q = 0; q < 64; ++q) {
+            const int k = 64 * wd + q;
+            bool any = false;
+            if (k < K)
+                for (int e = 0; e < E; ++e) any = any || Fb[(size_t)e * K + k] >= thr;
+            if (any) { m |= 1ull << q; ++total; }
+        }
+        bits[(size_t)b * W + wd] = m;
+    }
+    counts[b] = total;
+#else
+    __shared__ int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    int mine = 0;
+    for (int wd = wave; wd < W; wd += nw) {
+        const int k = 64 * wd + lane, kc = k < K ? k : K - 1;
+        bool any = false;
+        for (int e = 0; e < E; ++e) any = any || Fb[(size_t)e * K + kc] >= thr;
+        const unsigned long long m = __ballot(any && k < K);
+        if (lane == 0) { bits[(size_t)b * W + wd] = m; mine += __popcll(m); }
+    }
+    if (lane == 0 && mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[b] = s_cnt;
+#endif
+}
+

@@ -194,6 +194,32 @@ class PCEngine:
         return out
 
 
+    def rank2_cells(self, rank2: torch.Tensor, thr: float = 0.5) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Sparse form of quantize(rank2): (bits (B, ceil(K/64)) int64 -- bit k%64 of word k//64 set iff column k holds a
+        rank-2 cell --, counts (B,) int32).  cells_from_bits turns a row into the cell tuples cc_from_incidence adds."""
+        rank2 = rank2.contiguous()
+        B, E, K = rank2.shape
+        bits = torch.zeros(B, (K + 63) // 64, dtype=torch.int64, device=rank2.device)
+        counts = torch.zeros(B, dtype=torch.int32, device=rank2.device)
+        self.lib.check(self.lib.ccsd_rank2_cells(_ptr(rank2), B, E, K, float(thr), _ptr(bits), _ptr(counts), self._stream()))
+        return bits, counts
+
+
+def cells_from_bits(bits_row, N: int, d_min: int, d_max: int):
+    """Cell tuples of one complex from its bitmask row, in the reference's enumeration order (get_cells,
+    cc_utils.py:72-94: itertools.combinations(range(N), d) for d = d_min..d_max)."""
+    from itertools import combinations
+
+    words = [int(w) & 0xFFFFFFFFFFFFFFFF for w in bits_row.tolist()]
+    out, k = [], 0
+    for d in range(d_min, d_max + 1):
+        for combi in combinations(range(N), d):
+            if (words[k >> 6] >> (k & 63)) & 1:
+                out.append(combi)
+            k += 1
+    return out
+
+
 class _Null:
     def __enter__(self):
         return self

@@ -171,6 +171,8 @@ class Sampler:
         if self.is_cc:
             out["rank2"] = rank2
             out["rank2_int"] = quant.quantize(rank2, 0.5).to(torch.uint8)
+            # sparse form for cc_from_incidence (cc_utils.py:243-262): which of the K candidate cells exist, per complex
+            out["rank2_cell_bits"], out["rank2_cell_count"] = quant.rank2_cells(rank2, 0.5)
         out["sampling_time"] = torch.tensor(sampling_time)
         self.result = out
         if save:

@@ -25,7 +25,8 @@
  *                              (solver.py:210-313, 367-463) + RSDE.sde/discretize (sde.py:180-340)
  * ccsd_s4_apply                the update half of one S4_solver step (solver.py:1296-1352, 1446-1529)
  * ccsd_sampler_run             the whole pc_sampler / s4_solver loop (solver.py:1109-1174, 1266-1352)
- * ccsd_quantize_mol            quantize_mol / quantize (graph_utils.py:181-213)
+ * ccsd_quantize                quantize_mol / quantize (graph_utils.py:181-213)
+ * ccsd_rank2_cells             the rank-2 part of cc_from_incidence's input, as a cell bitmask (cc_utils.py:243-262)
  */
 #ifndef CCSD_HIP_H
 #define CCSD_HIP_H
@@ -178,13 +179,21 @@ int ccsd_sampler_run(ccsd_plan_t* plan, int32_t B, const float* flags_dev, uint6
  * quantize(t, thr): t<thr ? 0 : 1. */
 int ccsd_quantize(const float* in_dev, int64_t n, float thr, int64_t* out_dev, void* stream);
 
+/* Sparse form of the quantised rank-2 incidence matrix, the input of cc_from_incidence (cc_utils.py:243-262): column k
+ * of rank2 (B,E,K) holds a rank-2 cell iff any entry of the column is >= thr (quantize(), graph_utils.py:181-192).
+ * bits_dev: (B, ceil(K/64)) uint64, bit (k % 64) of word k / 64; counts_dev: (B,) int32 number of cells.  The column index
+ * k enumerates itertools.combinations(range(N), d) for d = d_min..d_max (get_cells, cc_utils.py:72-94).  Replaces the
+ * (B,E,K) fp32 device-to-host copy after sampling by ~K/8 bytes per complex. */
+int ccsd_rank2_cells(const float* rank2_dev, int32_t B, int32_t E, int64_t K, float thr, uint64_t* bits_dev,
+                     int32_t* counts_dev, void* stream);
+
 /* Measurement hooks (bench.py): time every launch of selected kernels with HIP events on the launch stream.
- * kernel_id: 0 k_xa, 1 k_gemm_p, 2 k_hf_score, 3 k_gemm_h, 4 k_langevin_apply, 5 k_r2; each call adds one kernel to the
+ * kernel_id: 0 k_xa, 1 k_gemm_p, 2 k_hf_score, 3 k_gemm_h, 4 k_langevin_apply, 5 k_r2, 6 k_s4_apply; each call adds one kernel to the
  * selection, -1 clears it.  ccsd_profile_read synchronises on that kernel's events and returns launches + summed ms. */
 int ccsd_profile_kernel(ccsd_plan_t* plan, int32_t kernel_id);
 int ccsd_profile_read(ccsd_plan_t* plan, int32_t kernel_id, int64_t* launches, double* total_ms);
-/* Diagnostic: when dev_buffer (B x 32 int64, device) is non-NULL, thread 0 of every workgroup of k_r2 (slots 0-15)
- * and k_xa (slots 16-31) stores the shader clock at its phase boundaries (tools/stamps.py).  NULL disables. */
+/* Diagnostic: when dev_buffer (B x 64 int64, device) is non-NULL, thread 0 of every workgroup of k_r2 (slots 0-31)
+ * and k_xa (slots 32-63) stores the shader clock at its phase boundaries (tools/stamps.py).  NULL disables. */
 int ccsd_debug_stamps(ccsd_plan_t* plan, void* dev_buffer);
 
 #ifdef __cplusplus

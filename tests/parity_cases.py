@@ -289,3 +289,31 @@ def case_error_behaviour(lib, device):
     # state-dict mismatch
     with pytest.raises(RuntimeError):
         loader.load_model(meta["params_x"]).load_state_dict({"bogus": torch.zeros(1)})
+
+
+def case_rank2_cells(lib, device):
+    """ccsd_rank2_cells: the cell bitmask equals `quantize(rank2)[:, :, k].any()` per column (cc_utils.py:243-262), counts and
+    the tuple enumeration follow get_cells (cc_utils.py:72-94); ragged K (not a multiple of 64), empty and full complexes."""
+    from itertools import combinations
+
+    from ccsd_amd.engine import cells_from_bits
+
+    eng = PCEngine(None, None, None, None, None, None, N=9, F=1, is_cc=False, device=device, lib=lib)
+    torch.manual_seed(3)
+    for (N, d_min, d_max) in ((9, 3, 9), (5, 3, 4), (12, 3, 4)):
+        E, K = rank2_dim(N, d_min, d_max)
+        B = 5
+        r = torch.rand(B, E, K) * 0.6                  # most entries below the 0.5 threshold
+        r[0] = 0.0                                     # empty complex
+        r[1] = 1.0                                     # every cell present
+        r[2, :, K - 1] = 0.9                           # last (ragged) column
+        r = r.to(device)
+        bits, counts = eng.rank2_cells(r, 0.5)
+        q = (r.cpu() >= 0.5).any(dim=1)                # (B, K)
+        assert counts.cpu().tolist() == q.sum(dim=1).tolist()
+        cells = [c for d in range(d_min, d_max + 1) for c in combinations(range(N), d)]
+        for b in range(B):
+            want = [cells[k] for k in range(K) if q[b, k]]
+            assert cells_from_bits(bits[b].cpu(), N, d_min, d_max) == want
+        assert counts[0].item() == 0 and counts[1].item() == K
+

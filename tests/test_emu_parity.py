@@ -70,6 +70,10 @@ def test_error_behaviour(lib):
     pc.case_error_behaviour(lib, DEV)
 
 
+def test_rank2_cells_sparse_output(lib):
+    pc.case_rank2_cells(lib, DEV)
+
+
 @pytest.mark.parametrize("env", [{"CCSD_NO_FUSED_R2": "1"}, {"CCSD_XA_PASS": "1"}, {"CCSD_NO_FUSED_APPLY": "1"}, {"CCSD_XA_GCH": "1"}])
 def test_alternative_kernel_paths_qm9(lib, env, monkeypatch):
     """The general tiled rank-2 kernels / the LDS-staged-weights variant / the unfused apply pass / the HBM channel

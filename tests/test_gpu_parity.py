@@ -65,6 +65,10 @@ def test_error_behaviour(lib):
     pc.case_error_behaviour(lib, DEV)
 
 
+def test_rank2_cells_sparse_output(lib):
+    pc.case_rank2_cells(lib, DEV)
+
+
 def test_one_step_vs_oracle_qm9_b64(lib):
     """Bigger, ragged batch (realistic QM9 node-count mix) against the oracle on the same draws."""
     pc.case_one_step_vs_oracle_large("ccsd_qm9_CC", lib, DEV, 64, [9, 9, 9, 8, 9, 7, 9, 9, 6, 9, 5, 9, 4, 9, 3, 2],
