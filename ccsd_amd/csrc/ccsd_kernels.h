@@ -1277,17 +1277,19 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                 // refilled only after the MFMAs that read it have been issued, so the load lands in the same registers
                 constexpr int D = 4;
                 float4 ab[D], bb0[D], bb1[D];
+                unsigned int fb[D];                                   // cell-mask bytes of the block (masked-A kind only)
 #pragma unroll
                 for (int u = 0; u < D; ++u) {
                     const int bl = u < nblk ? u : nblk - 1;
                     ab[u] = *reinterpret_cast<const float4*>(pa + 16 * bl);
                     bb0[u] = ld0(bl); bb1[u] = ld1(bl);
+                    fb[u] = k1 ? *reinterpret_cast<const unsigned int*>(sFrb + 16 * bl + 4 * kq) : 0u;
                 }
                 auto block = [&](int u, int blk, bool refill) {
                     float4 a4 = ab[u];
                     const float4 b40 = bb0[u], b41 = bb1[u];
                     if (k1) {
-                        const unsigned int f4 = *reinterpret_cast<const unsigned int*>(sFrb + 16 * blk + 4 * kq);
+                        const unsigned int f4 = fb[u];
                         const float fr0 = (float)(f4 & 0xffu), fr1 = (float)((f4 >> 8) & 0xffu), fr2 = (float)((f4 >> 16) & 0xffu),
                                     fr3 = (float)(f4 >> 24);
                         if (GEN1) {   // general mlp_value: rank2' element-wise on the fly (hodge_attention.py:322-323)
@@ -1322,6 +1324,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                         const int bl = blk + D < nblk ? blk + D : nblk - 1;   // clamped: a harmless reload at the tail
                         ab[u] = *reinterpret_cast<const float4*>(pa + 16 * bl);
                         bb0[u] = ld0(bl); bb1[u] = ld1(bl);
+                        if (k1) fb[u] = *reinterpret_cast<const unsigned int*>(sFrb + 16 * bl + 4 * kq);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 };
