@@ -231,7 +231,8 @@ def main():
     B = args.batch or wl["batch"]
     eng = PCEngine(meta["params_x"], parts["x"], meta["params_adj"], parts["adj"], meta.get("params_rank2"), parts.get("rank2"),
                    N=N, F=F, is_cc=is_cc, d_min=d_min, d_max=d_max, sdes=sdes, predictor=wl["predictor"], corrector=wl["corrector"],
-                   snr=wl["snr"], scale_eps=wl["scale_eps"], n_steps=1, probability_flow=False, denoise=True, eps=1e-4, device=dev)
+                   snr=wl["snr"], scale_eps=wl["scale_eps"], n_steps=1, probability_flow=False, denoise=True, eps=1e-4, device=dev,
+                   batch_hint=B)
     E, K = eng.E, eng.K
     flags = hist_flags(B * world, N, wl["hist"])[rank * B:(rank + 1) * B].to(dev)
     state, scratch, result = eng.alloc_state(B), eng.alloc_state(B), eng.alloc_state(B)

@@ -42,7 +42,7 @@ class Config(C.Structure):
             "f_num_layers", "f_num_linears", "f_nhid", "f_c_hid", "f_c_final", "f_cnum", "f_num_layers_mlp",
             "f_use_hodge_mask",
             "predictor", "corrector", "n_corr_steps", "probability_flow", "denoise")]
-        + [("snr", C.c_float), ("scale_eps", C.c_float), ("diff_steps", C.c_int32)]
+        + [("snr", C.c_float), ("scale_eps", C.c_float), ("diff_steps", C.c_int32), ("batch_hint", C.c_int32)]
     )
 
 

@@ -632,6 +632,7 @@ __global__ __launch_bounds__(256) void k_gemm_h(const float* __restrict__ rank2,
     __shared__ float As[T_BK * T_LD];
     __shared__ float Bs[T_BK * T_LD];
     const int b = blockIdx.z, m0 = blockIdx.y * T_BM, n0 = blockIdx.x * T_BN;
+    if (blockIdx.x < blockIdx.y) return;        // H is symmetric: upper-triangle tiles only, mirrored on store
     const float* Fb = rank2 + (size_t)b * E * K;
     TileAcc acc;
     tile_zero(acc);
@@ -653,7 +654,11 @@ __global__ __launch_bounds__(256) void k_gemm_h(const float* __restrict__ rank2,
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int m = m0 + ml + s;
-            if (m < E) Hb[(size_t)m * E + n] = (zero_diag && m == n) ? 0.f : v[s];
+            if (m < E) {
+                const float hv = (zero_diag && m == n) ? 0.f : v[s];
+                Hb[(size_t)m * E + n] = hv;
+                if (blockIdx.x != blockIdx.y) Hb[(size_t)n * E + m] = hv;
+            }
         }
     });
 }

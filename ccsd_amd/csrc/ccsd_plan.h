@@ -157,9 +157,9 @@ static inline void ccsd_pack_mlp(const MlpD& m, const float* w, float* packed) {
     }
 }
 
-static inline int round_ld(int rows) {  // multiple of 16, and == 16 mod 32 (conflict-free MFMA A-fragment reads)
-    int r = (rows + 15) / 16 * 16;
-    if (r % 32 == 0) r += 16;
+static inline int round_ld(int rows) {  // node-row stride of the feature-major LDS arrays: multiple of 8, never a multiple of 32
+    int r = (rows + 7) / 8 * 8;          // (== 16 mod 32 is conflict-free for the MFMA A-fragment reads, 8 / 24 mod 32 two-way)
+    if (r % 32 == 0) r += 8;
     return r;
 }
 
@@ -310,9 +310,14 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     const char* skip = getenv("CCSD_XA_PASS");
     // Large graphs (zinc250k: 46 channels x 38 x 38 = 266 KB): second round of candidates with the channel stack in the
     // HBM workspace (L2-resident, one slab per graph) and only the per-layer working set in LDS.  CCSD_XA_GCH=1 forces it.
+    // Start at the budget that keeps ceil(batch / #CUs) workgroups co-resident per CU (batch_hint; unknown = 4 per CU, the
+    // qm9_CC B = 1024 case), then grow.  Within a budget the channel stack in LDS is tried before the HBM variant: with the
+    // residency the batch needs, more workgroups per CU buy nothing and the HBM stack costs.
     const int gch_first = getenv("CCSD_XA_GCH") ? 1 : 0;
-    for (int gch = gch_first; gch < 2 && best_total < 0; ++gch)
-    for (int pass = (skip && !gch) ? atoi(skip) : 0; pass < NCAND && best_total < 0; ++pass) {
+    int need = c->batch_hint > 0 ? (c->batch_hint + 255) / 256 : 4;
+    need = need < 1 ? 1 : need > 4 ? 4 : need;
+    for (int pass = skip ? atoi(skip) : 4 - need; pass < NCAND && best_total < 0; ++pass)
+    for (int gch = gch_first; gch < 2 && best_total < 0; ++gch) {
         if (stage_on[pass] && (wst_full == 0 || gch)) continue;
         p->chan_global = gch;
         wst = stage_on[pass] ? wst_full : 0;

@@ -24,7 +24,8 @@ class PCEngine:
                  sd_rank2, *, N: int, F: int, is_cc: bool, d_min: int = 0, d_max: int = 0,
                  sdes: Optional[Sequence[SDE]] = None, predictor: str = "Euler", corrector: str = "None",
                  snr: float = 0.1, scale_eps: float = 1.0, n_steps: int = 1, probability_flow: bool = False,
-                 denoise: bool = True, eps: float = 1e-3, device="cuda", lib: Optional[_lib.Library] = None):
+                 denoise: bool = True, eps: float = 1e-3, device="cuda", lib: Optional[_lib.Library] = None,
+                 batch_hint: int = 0):
         self.lib = lib if lib is not None else _lib.get_library()
         self.device = torch.device(device)
         if self.lib.is_hip:
@@ -48,7 +49,7 @@ class PCEngine:
         self.n_steps, self.corrector, self.denoise = n_steps, corrector, denoise
         cfg = _plan.make_config(px, pa, pf, predictor=predictor, corrector=corrector, snr=snr, scale_eps=scale_eps,
                                 n_steps=n_steps, probability_flow=probability_flow, denoise=denoise,
-                                diff_steps=self.diff_steps)
+                                diff_steps=self.diff_steps, batch_hint=batch_hint)
         blob = _plan.pack_weights(px, sd_x if params_x is not None else None, pa, sd_adj if params_adj is not None else None,
                                   pf, sd_rank2 if (is_cc and params_rank2 is not None) else None)
         self.cfg = cfg

@@ -145,7 +145,7 @@ def _check_supported(p: dict):
 
 
 def make_config(px: dict, pa: dict, pf: Optional[dict], *, predictor="Euler", corrector="None", snr=0.1, scale_eps=1.0,
-                n_steps=1, probability_flow=False, denoise=True, diff_steps=1) -> _lib.Config:
+                n_steps=1, probability_flow=False, denoise=True, diff_steps=1, batch_hint=0) -> _lib.Config:
     for p in (px, pa, pf):
         if p is not None:
             _check_supported(p)
@@ -187,6 +187,7 @@ def make_config(px: dict, pa: dict, pf: Optional[dict], *, predictor="Euler", co
     c.predictor, c.corrector = preds[predictor], corrs[corrector]
     c.n_corr_steps, c.probability_flow, c.denoise = int(n_steps), int(probability_flow), int(denoise)
     c.snr, c.scale_eps, c.diff_steps = float(snr), float(scale_eps), int(diff_steps)
+    c.batch_hint = int(batch_hint)
     return c
 
 

@@ -90,7 +90,8 @@ def get_pc_sampler(sde_x: SDE, sde_adj: SDE, shape_x: Sequence[int], shape_adj: 
             cache.clear()
             cache[key] = PCEngine(*args, N=N, F=F, is_cc=is_cc, d_min=d_min or 0, d_max=d_max or 0, sdes=sdes,
                                   predictor=predictor, corrector=corrector, snr=snr, scale_eps=scale_eps, n_steps=n_steps,
-                                  probability_flow=probability_flow, denoise=denoise, eps=eps, device=device, lib=lib)
+                                  probability_flow=probability_flow, denoise=denoise, eps=eps, device=device, lib=lib,
+                                  batch_hint=B)
         return cache[key]
 
     def draw(shape, dev):

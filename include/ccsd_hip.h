@@ -86,6 +86,8 @@ typedef struct {
     int32_t predictor, corrector, n_corr_steps, probability_flow, denoise;
     float snr, scale_eps;
     int32_t diff_steps;         /* sde_adj.N == number of rows of step_coef */
+    int32_t batch_hint;         /* expected batch per launch (0 = unknown): picks the LDS layout of the graph-network kernel so
+                                 * that ceil(batch / #CUs) workgroups are co-resident per CU; any batch stays correct */
 } ccsd_config_t;
 
 typedef struct ccsd_plan ccsd_plan_t;
