@@ -40,7 +40,5 @@ for k in sorted(lab):
 span = (d[:, 5].max() - d[:, 0].min())
 hs = [12, 16, 17, 18, 19, 20, 13]
 print("hodge: fill/hq0, dense pairs, deg, MFMA proj, diag att, scatter:", [int(np.median(x[:, hs[i + 1]] - x[:, hs[i]])) for i in range(6)])
-ls = [5, 21, 22, 23, 24, 6]
-print("L1: dinv+barrier, gcn tiles (wave 0), barrier wait, att pairs (wave 0), mc + barrier:", [int(np.median(x[:, ls[i + 1]] - x[:, ls[i]])) for i in range(5)])
 print("final MLP: chain (wave 0)", int(np.median(x[:, 11] - x[:, 13])), " wait barrier", int(np.median(x[:, 15] - x[:, 11])), " epilogue", int(np.median(x[:, 14] - x[:, 15])))
 print("k_r2 first-start to last-end cycles:", span, " k_xa:", x[:, 14].max() - x[:, 0].min())
