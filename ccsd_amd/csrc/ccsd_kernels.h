@@ -473,7 +473,9 @@ CCSD_DEV void gcn_tile(const float* xT, int ldn, int fin, int N, const float* A,
     }
 #else
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));          // keeps each instantiation's index arithmetic inside it (see mlp_chain_tile)
+    const int l15 = lane & 15, kq = lane >> 4;
     const int col = col0 + l15;
     const bool cok = col < ncols;
     const int colc = cok ? col : ncols - 1;
