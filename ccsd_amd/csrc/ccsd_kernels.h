@@ -629,15 +629,17 @@ CCSD_DEV float cell_on(unsigned long long off, const unsigned long long* __restr
 // k_gemm_h: H[b] = (F[b] F[b]^T) * hodge_mask           hodge_laplacian + mask, cc_utils.py:929, 964-969
 // grid (ceil(E/64), ceil(E/64), B)
 // ---------------------------------------------------------------------------------------------
+#define H_BK 32   // k per slab (two 16-wide MFMA k blocks)
+#define H_LD 40   // LDS row stride in floats: 16-byte aligned rows, == 8 mod 32 -> conflict-free ds_read_b128 fragments
 __global__ __launch_bounds__(256) void k_gemm_h(const float* __restrict__ rank2, float* __restrict__ H, int E, int K,
                                                 int zero_diag) {
-    __shared__ float As[T_BK * T_LD];
-    __shared__ float Bs[T_BK * T_LD];
     const int b = blockIdx.z, m0 = blockIdx.y * T_BM, n0 = blockIdx.x * T_BN;
     if (blockIdx.x < blockIdx.y) return;        // H is symmetric: upper-triangle tiles only, mirrored on store
     const float* Fb = rank2 + (size_t)b * E * K;
     TileAcc acc;
     tile_zero(acc);
+#ifdef CCSD_EMU
+    static float As[T_BK * T_LD], Bs[T_BK * T_LD];
     for (int k0 = 0; k0 < K; k0 += T_BK) {
         for (int idx = threadIdx.x; idx < T_BM * T_BK; idx += blockDim.x) {
             const int r = idx / T_BK, kk = idx % T_BK, k = k0 + kk;
@@ -645,10 +647,68 @@ __global__ __launch_bounds__(256) void k_gemm_h(const float* __restrict__ rank2,
             As[kk * T_LD + r] = (ra < E && k < K) ? Fb[(size_t)ra * K + k] : 0.f;
             Bs[kk * T_LD + r] = (rb < E && k < K) ? Fb[(size_t)rb * K + k] : 0.f;
         }
-        __syncthreads();
         tile_mma(acc, As, Bs);
-        __syncthreads();
     }
+#else
+    // Both operands are rows of F, contiguous along the contraction index: the slabs are straight row copies
+    // (As[row][k], 16-byte vectors, no transposition), and with the MFMA k slot kq of step j of a 16-wide block assigned
+    // to k = 16*t + 4*kq + j a lane's four-step fragment is one ds_read_b128.  The next slab's global loads are issued
+    // before the MFMAs of the current one.
+    __shared__ __align__(16) float As[T_BM * H_LD];
+    __shared__ __align__(16) float Bs[T_BN * H_LD];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const bool diag = blockIdx.x == blockIdx.y, vec = (K & 3) == 0;
+    // thread -> (row, 4-float column group) of the 64 x 32 slab: two groups per thread and matrix
+    const int r0 = tid >> 3, c4 = (tid & 7) * 4;
+    auto ldg = [&](int row, int k) -> float4 {
+        const int rc = row < E ? row : E - 1;
+        const float* src = Fb + (size_t)rc * K;
+        float4 v;
+        if (vec && k + 3 < K) v = *reinterpret_cast<const float4*>(src + k);
+        else {
+            v.x = k < K ? src[k] : 0.f; v.y = k + 1 < K ? src[k + 1] : 0.f;
+            v.z = k + 2 < K ? src[k + 2] : 0.f; v.w = k + 3 < K ? src[k + 3] : 0.f;
+        }
+        if (row >= E) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        return v;
+    };
+    float4 ra[2], rb[2];
+    ra[0] = ldg(m0 + r0, c4); ra[1] = ldg(m0 + r0 + 32, c4);
+    if (!diag) { rb[0] = ldg(n0 + r0, c4); rb[1] = ldg(n0 + r0 + 32, c4); }
+    const float* Bp = diag ? As : Bs;
+    for (int k0 = 0; k0 < K; k0 += H_BK) {
+        __syncthreads();                                   // the previous slab's MFMAs are done reading LDS
+        *reinterpret_cast<float4*>(As + r0 * H_LD + c4) = ra[0];
+        *reinterpret_cast<float4*>(As + (r0 + 32) * H_LD + c4) = ra[1];
+        if (!diag) {
+            *reinterpret_cast<float4*>(Bs + r0 * H_LD + c4) = rb[0];
+            *reinterpret_cast<float4*>(Bs + (r0 + 32) * H_LD + c4) = rb[1];
+        }
+        __syncthreads();
+        if (k0 + H_BK < K) {                               // next slab: in flight during the MFMAs
+            ra[0] = ldg(m0 + r0, k0 + H_BK + c4); ra[1] = ldg(m0 + r0 + 32, k0 + H_BK + c4);
+            if (!diag) { rb[0] = ldg(n0 + r0, k0 + H_BK + c4); rb[1] = ldg(n0 + r0 + 32, k0 + H_BK + c4); }
+        }
+#pragma unroll
+        for (int t = 0; t < H_BK / 16; ++t) {
+            const float4 a0 = *reinterpret_cast<const float4*>(As + (wm + l15) * H_LD + 16 * t + 4 * kq);
+            const float4 a1 = *reinterpret_cast<const float4*>(As + (wm + 16 + l15) * H_LD + 16 * t + 4 * kq);
+            const float4 b0 = *reinterpret_cast<const float4*>(Bp + (wn + l15) * H_LD + 16 * t + 4 * kq);
+            const float4 b1 = *reinterpret_cast<const float4*>(Bp + (wn + 16 + l15) * H_LD + 16 * t + 4 * kq);
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc.a[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[j], bv0[j], acc.a[0][0], 0, 0, 0);
+                acc.a[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[j], bv1[j], acc.a[0][1], 0, 0, 0);
+                acc.a[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[j], bv0[j], acc.a[1][0], 0, 0, 0);
+                acc.a[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[j], bv1[j], acc.a[1][1], 0, 0, 0);
+            }
+        }
+    }
+#endif
     float* Hb = H + (size_t)b * E * E;
     tile_foreach4(acc, [&](int ml, int nl, const float* v) {
         const int n = n0 + nl;
