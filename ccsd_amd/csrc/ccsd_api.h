@@ -307,9 +307,11 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
     {
         const HodgeLayerD& h = p.hl[0];
         dim3 g((h.wc + T_BN - 1) / T_BN, (rows + T_BM - 1) / T_BM, 1);
+        prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_P, stream);
         CCSD_LAUNCH(k_gemm_p, g, dim3(CCSD_NTHREADS), 0, stream, rank2, (const float*)pl->w, w.P0, rows, p.E, p.K, h.wc,
                     h.wcat, 0, h.mval, h.cin, (const float*)nullptr, (const unsigned long long*)w.offbits,
                     (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells);
+        prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_P, stream);
         LAUNCH_CHECK();
     }
     if (p.h_L > 1) {

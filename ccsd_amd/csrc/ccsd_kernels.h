@@ -868,8 +868,6 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
                                                   const unsigned char* __restrict__ edges,
                                                   const unsigned long long* __restrict__ cells, RankEpi ep,
                                                   NoiseArgs na) {
-    __shared__ float As[T_BK * T_LD];
-    __shared__ float Bs[T_BK * T_LD];
     __shared__ float red[64];
     const PlanD& p = *plan;
     const int E = p.E, K = p.K;
@@ -878,6 +876,8 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
     const float* Hb = H + (size_t)b * E * E;
     TileAcc acc;
     tile_zero(acc);
+#ifdef CCSD_EMU
+    static float As[T_BK * T_LD], Bs[T_BK * T_LD];
     if (p.f_cnum == 2) {
         for (int k0 = 0; k0 < E; k0 += T_BK) {
             for (int idx = threadIdx.x; idx < T_BM * T_BK; idx += blockDim.x) {
@@ -888,11 +888,80 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
                 const int kk = idx / T_BN, c = idx % T_BN, k = k0 + kk, col = n0 + c;
                 Bs[kk * T_LD + c] = (k < E && col < K) ? Fb[(size_t)k * K + col] : 0.f;
             }
-            __syncthreads();
             tile_mma(acc, As, Bs);
-            __syncthreads();
         }
     }
+#else
+    // (H F) tile: A = rows of H (contraction index contiguous: row-copy slab As[row][k], one ds_read_b128 per 16-wide k
+    // block with the permuted k slots k = 16t + 4kq + j); B = rows of F, k-major slab Bs[k][col] read with the same
+    // permutation (row stride 68: 4 * 68 == 16 mod 32 keeps the four kq groups on disjoint banks).  Next slab's global
+    // loads are issued before the MFMAs of the current one.
+    constexpr int BLD = 68;
+    __shared__ __align__(16) float As[T_BM * H_LD];
+    __shared__ __align__(16) float Bs[H_BK * BLD];
+    if (p.f_cnum == 2) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+        const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+        const bool vec = (K & 3) == 0;
+        // A slab 64 x 32: thread -> (row ar + 8u, column ak), u < 8 (scalar: E is not 16-byte friendly in general)
+        const int ar = tid >> 5, ak = tid & 31;
+        // B slab 32 x 64: thread -> (k row bk + 16u, 4-float column group bc4), u < 2
+        const int bk = tid >> 4, bc4 = (tid & 15) * 4;
+        float ra[8];
+        float4 rb[2];
+        auto load_slab = [&](int k0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = m0 + ar + 8 * u, k = k0 + ak;
+                const float v = Hb[(size_t)(row < E ? row : E - 1) * E + (k < E ? k : E - 1)];
+                ra[u] = (row < E && k < E) ? v : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = k0 + bk + 16 * u, col = n0 + bc4;
+                const float* src = Fb + (size_t)(k < E ? k : E - 1) * K;
+                float4 v;
+                if (vec && col + 3 < K) v = *reinterpret_cast<const float4*>(src + col);
+                else {
+                    v.x = col < K ? src[col] : 0.f; v.y = col + 1 < K ? src[col + 1] : 0.f;
+                    v.z = col + 2 < K ? src[col + 2] : 0.f; v.w = col + 3 < K ? src[col + 3] : 0.f;
+                }
+                if (k >= E) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[u] = v;
+            }
+        };
+        load_slab(0);
+        for (int k0 = 0; k0 < E; k0 += H_BK) {
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) As[(ar + 8 * u) * H_LD + ak] = ra[u];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) *reinterpret_cast<float4*>(Bs + (bk + 16 * u) * BLD + bc4) = rb[u];
+            __syncthreads();
+            if (k0 + H_BK < E) load_slab(k0 + H_BK);
+#pragma unroll
+            for (int t = 0; t < H_BK / 16; ++t) {
+                const float4 a0 = *reinterpret_cast<const float4*>(As + (wm + l15) * H_LD + 16 * t + 4 * kq);
+                const float4 a1 = *reinterpret_cast<const float4*>(As + (wm + 16 + l15) * H_LD + 16 * t + 4 * kq);
+                const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+                float bv0[4], bv1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float* br = Bs + (16 * t + 4 * kq + j) * BLD + wn + l15;
+                    bv0[j] = br[0]; bv1[j] = br[16];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc.a[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[j], bv0[j], acc.a[0][0], 0, 0, 0);
+                    acc.a[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[j], bv1[j], acc.a[0][1], 0, 0, 0);
+                    acc.a[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[j], bv0[j], acc.a[1][0], 0, 0, 0);
+                    acc.a[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[j], bv1[j], acc.a[1][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+#endif
     const unsigned long long off = offbits[b];
     float s_net = 0.f, s_z = 0.f;
     tile_foreach4(acc, [&](int ml, int nl, const float* hf) {
