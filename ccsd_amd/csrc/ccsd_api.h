@@ -308,6 +308,19 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
         const HodgeLayerD& h = p.hl[0];
         dim3 g((h.wc + T_BN - 1) / T_BN, (rows + T_BM - 1) / T_BM, 1);
         prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_P, stream);
+#ifndef CCSD_EMU
+        const int nt = (h.wc + 15) / 16, Kp = (p.K + 31) & ~31;
+        if (nt <= 4 && getenv("CCSD_OLD_GEMM_P") == nullptr) {     // narrow projections: no 64-column padding
+            const dim3 g0((rows + T_BM - 1) / T_BM);
+            const float* WT = (const float*)pl->wp + h.wcatT;
+            switch (nt) {
+                case 1: hipLaunchKernelGGL(k_gemm_p0<1>, g0, dim3(256), 0, (hipStream_t)stream, rank2, WT, w.P0, rows, p.K, Kp, h.wc); break;
+                case 2: hipLaunchKernelGGL(k_gemm_p0<2>, g0, dim3(256), 0, (hipStream_t)stream, rank2, WT, w.P0, rows, p.K, Kp, h.wc); break;
+                case 3: hipLaunchKernelGGL(k_gemm_p0<3>, g0, dim3(256), 0, (hipStream_t)stream, rank2, WT, w.P0, rows, p.K, Kp, h.wc); break;
+                default: hipLaunchKernelGGL(k_gemm_p0<4>, g0, dim3(256), 0, (hipStream_t)stream, rank2, WT, w.P0, rows, p.K, Kp, h.wc); break;
+            }
+        } else
+#endif
         CCSD_LAUNCH(k_gemm_p, g, dim3(CCSD_NTHREADS), 0, stream, rank2, (const float*)pl->w, w.P0, rows, p.E, p.K, h.wc,
                     h.wcat, 0, h.mval, h.cin, (const float*)nullptr, (const unsigned long long*)w.offbits,
                     (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells);

@@ -782,6 +782,83 @@ __global__ __launch_bounds__(256) void k_gemm_p(const float* __restrict__ rank2,
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_gemm_p0: layer-0 hodge projections  P_0[r][c] = sum_k rank2[r][k] * Wcat_0[k][c]  (DenseHCNConv out = rank2 @ W,
+// hodge_layers.py:185) over the flattened rows r = b*E + e, for narrow outputs (wc <= 64: 16 columns for every shipped
+// network).  One workgroup = 64 rows x all pad16(wc) columns: both operands are row copies (rank2 rows, rows of the
+// transposed packed weights Wcat^T[col][Kp]) read back as ds_read_b128 permuted-k fragments; wave w owns rows
+// 16w..16w+15 and every 16-column tile, so no MFMA is spent on the 64-column padding of the general tile engine.
+// ---------------------------------------------------------------------------------------------
+#ifndef CCSD_EMU
+template <int NT>
+__global__ __launch_bounds__(256) void k_gemm_p0(const float* __restrict__ rank2, const float* __restrict__ WT, float* __restrict__ P,
+                                                 int rows, int K, int Kp, int wc) {
+    __shared__ __align__(16) float As[T_BM * H_LD];
+    __shared__ __align__(16) float Bs[16 * NT * H_LD];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * T_BM;
+    const bool vec = (K & 3) == 0;
+    const int r0 = tid >> 3, c4 = (tid & 7) * 4;           // (row, 4-float column group) of a 64 x 32 slab; rows r0, r0 + 32
+    auto lda = [&](int row, int k) -> float4 {
+        const float* src = rank2 + (size_t)(row < rows ? row : rows - 1) * K;
+        float4 v;
+        if (vec && k + 3 < K) v = *reinterpret_cast<const float4*>(src + k);
+        else {
+            v.x = k < K ? src[k] : 0.f; v.y = k + 1 < K ? src[k + 1] : 0.f;
+            v.z = k + 2 < K ? src[k + 2] : 0.f; v.w = k + 3 < K ? src[k + 3] : 0.f;
+        }
+        return v;
+    };
+    f32x4 acc[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 ra[2], rb[(NT + 1) / 2];
+    auto load_slab = [&](int k0) {
+        ra[0] = lda(m0 + r0, k0 + c4); ra[1] = lda(m0 + r0 + 32, k0 + c4);
+#pragma unroll
+        for (int u = 0; u < (NT + 1) / 2; ++u) {           // 16*NT weight rows x 8 float4: tid + 256u < 128*NT
+            const int idx = tid + 256 * u, wr = idx >> 3;
+            rb[u] = wr < 16 * NT ? *reinterpret_cast<const float4*>(WT + (size_t)wr * Kp + k0 + (idx & 7) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    load_slab(0);
+    for (int k0 = 0; k0 < Kp; k0 += H_BK) {
+        __syncthreads();
+        *reinterpret_cast<float4*>(As + r0 * H_LD + c4) = ra[0];
+        *reinterpret_cast<float4*>(As + (r0 + 32) * H_LD + c4) = ra[1];
+#pragma unroll
+        for (int u = 0; u < (NT + 1) / 2; ++u) {
+            const int idx = tid + 256 * u, wr = idx >> 3;
+            if (wr < 16 * NT) *reinterpret_cast<float4*>(Bs + wr * H_LD + (idx & 7) * 4) = rb[u];
+        }
+        __syncthreads();
+        if (k0 + H_BK < Kp) load_slab(k0 + H_BK);
+#pragma unroll
+        for (int t = 0; t < H_BK / 16; ++t) {
+            const float4 a = *reinterpret_cast<const float4*>(As + (16 * wave + l15) * H_LD + 16 * t + 4 * kq);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                const float4 bq = *reinterpret_cast<const float4*>(Bs + (16 * c + l15) * H_LD + 16 * t + 4 * kq);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc[c], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const int n = 16 * c + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * wave + 4 * kq + r;
+            if (m < rows && n < wc) P[(size_t)m * wc + n] = acc[c][r];
+        }
+    }
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------
 // k_edgecoef: acoef[b][c][e] = (adj^(c+1))[i_e][j_e]      pow_tensor + adj_to_hodgedual,
 // graph_utils.py:285-292, cc_utils.py:1525-1536.  One workgroup per graph; LDS: 3*N*N floats.
 // ---------------------------------------------------------------------------------------------
