@@ -360,14 +360,15 @@ static int launch_hf(const ccsd_plan* pl, int B, const float* rank2, RankEpi& ep
     const PlanD& p = pl->h;
     dim3 g((p.K + T_BN - 1) / T_BN, (p.E + T_BM - 1) / T_BM, B);
     prof_mark(const_cast<ccsd_plan*>(pl), KID_HF, stream);
-    if (p.f_affine)
-        CCSD_LAUNCH(k_hf_score<true>, g, dim3(CCSD_NTHREADS), 0, stream, (const PlanD*)pl->d, (const float*)pl->w, rank2,
-                    (const float*)w.H, (const unsigned long long*)w.offbits, (const unsigned char*)pl->edges,
-                    (const unsigned long long*)pl->cells, ep, na);
-    else
-        CCSD_LAUNCH(k_hf_score<false>, g, dim3(CCSD_NTHREADS), 0, stream, (const PlanD*)pl->d, (const float*)pl->w, rank2,
-                    (const float*)w.H, (const unsigned long long*)w.offbits, (const unsigned char*)pl->edges,
-                    (const unsigned long long*)pl->cells, ep, na);
+#define HF_ARGS (const PlanD*)pl->d, (const float*)pl->w, rank2, (const float*)w.H, (const unsigned long long*)w.offbits, \
+                (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, ep, na
+    int fw = p.f_fdim > p.f_cnum ? p.f_fdim : p.f_cnum;       // widest layer of ScoreNetworkF's per-element MLPs
+    for (int l = 0; l < p.f_L; ++l) { const MlpD& m = p.fl[l]; const int wd = m.n > 1 && m.hid > m.in ? (m.hid > m.out ? m.hid : m.out) : (m.in > m.out ? m.in : m.out); if (wd > fw) fw = wd; }
+    if (p.f_fin.n > 1 && p.f_fin.hid > fw) fw = p.f_fin.hid;
+    if (p.f_affine) CCSD_LAUNCH((k_hf_score<true, 8>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS);
+    else if (fw <= 8) CCSD_LAUNCH((k_hf_score<false, 8>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS);
+    else CCSD_LAUNCH((k_hf_score<false, CCSD_FW>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS);
+#undef HF_ARGS
     prof_mark(const_cast<ccsd_plan*>(pl), KID_HF, stream);
     LAUNCH_CHECK();
     return CCSD_OK;

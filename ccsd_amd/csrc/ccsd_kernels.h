@@ -904,41 +904,42 @@ struct RankEpi {
     float* part;             // NORMS: [B][ntiles][2] partial sums of net^2 and z^2
 };
 
-template <bool AFFINE>
+// FW: width the per-element MLPs are padded to (8 when every layer of the network fits, else CCSD_FW = 16)
+template <bool AFFINE, int FW = CCSD_FW>
 CCSD_DEV float fnet_element(const PlanD& p, const float* __restrict__ w, float f, float hf, float m) {
     if (AFFINE) return m * fmaf(p.f_alpha, f, fmaf(p.f_beta, hf, p.f_gamma));
     // general path: channels [F, HF] -> L x (MLP, mask) -> concat -> final MLP -> mask
-    float ch[CCSD_FW];
+    float ch[FW];
 #pragma unroll
-    for (int i = 0; i < CCSD_FW; ++i) ch[i] = 0.f;
+    for (int i = 0; i < FW; ++i) ch[i] = 0.f;
     ch[0] = f;
     if (p.f_cnum == 2) ch[1] = hf;
     int ci0 = 0, co0 = p.f_cnum;
     for (int l = 0; l < p.f_L; ++l) {
-        float in[CCSD_FW], out[CCSD_FW];
+        float in[FW], out[FW];
 #pragma unroll
-        for (int i = 0; i < CCSD_FW; ++i) {
+        for (int i = 0; i < FW; ++i) {
             float v = 0.f;
 #pragma unroll
-            for (int j = 0; j < CCSD_FW; ++j)
+            for (int j = 0; j < FW; ++j)
                 if (j == ci0 + i) v = ch[j];
             in[i] = v;
         }
-        small_mlp<CCSD_FW>(p.fl[l], w, in, out);
+        small_mlp<FW>(p.fl[l], w, in, out);
         const int no = p.fl[l].out;
 #pragma unroll
-        for (int j = 0; j < CCSD_FW; ++j)
+        for (int j = 0; j < FW; ++j)
 #pragma unroll
-            for (int i = 0; i < CCSD_FW; ++i)
+            for (int i = 0; i < FW; ++i)
                 if (i < no && j == co0 + i) ch[j] = m * out[i];   // mask_rank2 after every layer (hodge_layers.py:90)
         ci0 = co0; co0 += no;
     }
-    float out[CCSD_FW];
-    small_mlp<CCSD_FW>(p.f_fin, w, ch, out);
+    float out[FW];
+    small_mlp<FW>(p.f_fin, w, ch, out);
     return m * out[0];
 }
 
-template <bool AFFINE>
+template <bool AFFINE, int FW>
 __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan, const float* __restrict__ w,
                                                   const float* __restrict__ rank2, const float* __restrict__ H,
                                                   const unsigned long long* __restrict__ offbits,
@@ -1054,7 +1055,7 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
             const size_t gi = ((size_t)b * E + e) * K + k;
             const float f = Fb[(size_t)e * K + k];
             const float m = edge_on(off, edges, e) * fr;          // flags_left * flags_right, cc_utils.py:590
-            const float net = fnet_element<AFFINE>(p, w, f, hf[s], m);
+            const float net = fnet_element<AFFINE, FW>(p, w, f, hf[s], m);
             const float zz = z[s] * m;                            // gen_noise_rank2, cc_utils.py:613-615
             if (ep.mode == MODE_SCORE) {
                 ep.out[gi] = ep.sscale * net;
