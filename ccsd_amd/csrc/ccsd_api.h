@@ -378,7 +378,7 @@ static int launch_r2(const ccsd_plan* pl, int B, const float* rank2, const float
                      RankEpi& ep, NoiseArgs& na, Workspace& w, void* stream, const CorrFuse* cf = nullptr) {
     R2Args ra{};
     if (cf) ra.cf = *cf;
-    ra.rank2 = rank2; ra.adj = adj; ra.flags = flags; ra.P0 = w.P0; ra.P1 = w.P1; ra.want_p = want_p;
+    ra.rank2 = rank2; ra.adj = adj; ra.flags = flags; ra.offbits = w.offbits; ra.P0 = w.P0; ra.P1 = w.P1; ra.want_p = want_p;
     ra.ldk = pl->r2_ldk; ra.ldh = pl->r2_ldh; ra.dbg = pl->dbg; ra.wp = pl->wp;
     prof_mark(const_cast<ccsd_plan*>(pl), KID_R2, stream);
     const dim3 blk(CCSD_NTHREADS == 1 ? 1 : 512);

@@ -1201,6 +1201,7 @@ CCSD_DEV void corr_coef(const CorrFuse& cf, int t, float* c1, float* c2) {
 
 struct R2Args {
     const float* rank2; const float* adj; const float* flags;
+    const unsigned long long* offbits;     // per-sample bitmask of switched-off nodes
     float* P0; float* P1;
     int want_p;            // write the hodge projections (the A-network will run on the same state)
     int ldk, ldh;
@@ -1235,12 +1236,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
 
     // ---- phase 0: rank2 block -> LDS; masks; adjacency powers
     stamp(ra.dbg, 0);
-    if (tid == 0) {
-        unsigned long long m = 0;
-        for (int n = 0; n < N; ++n)
-            if (ra.flags[(size_t)b * N + n] == 0.f) m |= 1ull << n;
-        s_off = m;
-    }
+    if (tid == 0) s_off = ra.offbits[b];      // switched-off nodes (k_flagbits): one load instead of a serial walk over the flags
     if (((E * K) & 3) == 0) {
         // the block is 16-byte aligned and a multiple of 16 bytes: batches of four float4 loads in flight per thread
         const float4* F4 = reinterpret_cast<const float4*>(Fg);
