@@ -1237,14 +1237,29 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     // ---- phase 0: rank2 block -> LDS; masks; adjacency powers
     stamp(ra.dbg, 0);
     if (tid == 0) s_off = ra.offbits[b];      // switched-off nodes (k_flagbits): one load instead of a serial walk over the flags
+    // With the fused Langevin apply (predictor launches of ccsd_sampler_run) the raw scores of the norms pass are loaded
+    // alongside and F + c1*net goes to LDS in the same pass (same fma as k_langevin_apply; the noise term follows below).
+    float c1f = 0.f, c2f = 0.f;
+    if (ra.cf.on) corr_coef(ra.cf, 2, &c1f, &c2f);
+    const float* Ng = ra.cf.on ? ra.cf.net_r + (size_t)b * E * K : Fg;
     if (((E * K) & 3) == 0) {
         // the block is 16-byte aligned and a multiple of 16 bytes: batches of four float4 loads in flight per thread
         const float4* F4 = reinterpret_cast<const float4*>(Fg);
+        const float4* N4 = reinterpret_cast<const float4*>(Ng);
         const int n4 = (E * K) >> 2;
         for (int base = tid; base < n4; base += 4 * nth) {
-            float4 v[4];
+            float4 v[4], nv[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i4 = base + u * nth; if (i4 < n4) v[u] = F4[i4]; }
+            for (int u = 0; u < 4; ++u) { const int i4 = base + u * nth; v[u] = F4[i4 < n4 ? i4 : n4 - 1]; }
+            if (ra.cf.on) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int i4 = base + u * nth; nv[u] = N4[i4 < n4 ? i4 : n4 - 1]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v[u].x = fmaf(c1f, nv[u].x, v[u].x); v[u].y = fmaf(c1f, nv[u].y, v[u].y);
+                    v[u].z = fmaf(c1f, nv[u].z, v[u].z); v[u].w = fmaf(c1f, nv[u].w, v[u].w);
+                }
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i4 = base + u * nth;
@@ -1264,7 +1279,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
         for (int t = tid; t < E * K; t += nth) {
             int e, k;
             dK.divmod(t, e, k);
-            sF[e * ldk + k] = Fg[t];
+            sF[e * ldk + k] = ra.cf.on ? fmaf(c1f, Ng[t], Fg[t]) : Fg[t];
         }
     }
     for (int t = tid; t < E * (Kp4 - K); t += nth) { const int e = t / (Kp4 - K), k = K + t % (Kp4 - K); sF[e * ldk + k] = 0.f; }
@@ -1308,40 +1323,8 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     }
     __syncthreads();
     if (ra.cf.on) {
-        // fused Langevin corrector apply on the LDS-resident block: F <- F + c1*net + c2*z (masked)
-        float c1, c2;
-        corr_coef(ra.cf, 2, &c1, &c2);
-        const float* Ng = ra.cf.net_r + (size_t)b * E * K;
-        if (((E * K) & 3) == 0) {
-            const float4* N4 = reinterpret_cast<const float4*>(Ng);
-            const int n4 = (E * K) >> 2;
-            for (int base = tid; base < n4; base += 4 * nth) {
-                float4 v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const int i4 = base + u * nth; v[u] = N4[i4 < n4 ? i4 : n4 - 1]; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i4 = base + u * nth;
-                    if (i4 < n4) {
-                        int e, k;
-                        dK.divmod(4 * i4, e, k);
-                        const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            sF[e * ldk + k] = fmaf(c1, vv[q], sF[e * ldk + k]);
-                            if (++k == K) { k = 0; ++e; }
-                        }
-                    }
-                }
-            }
-        } else {
-            for (int t = tid; t < E * K; t += nth) {
-                int e, k;
-                dK.divmod(t, e, k);
-                sF[e * ldk + k] = fmaf(c1, Ng[t], sF[e * ldk + k]);
-            }
-        }
-        __syncthreads();
+        // fused Langevin corrector apply on the LDS-resident block, noise term: F <- (F + c1*net) + c2*z (masked)
+        const float c2 = c2f;
         NoiseArgs nc = na;
         nc.zr = nullptr; nc.draw_r = ra.cf.draw_r;
         const int egn = (E + 3) >> 2;
