@@ -199,6 +199,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="complexes per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not time the kernels with HIP events")
+    ap.add_argument("--event-stride", type=int, default=17, help="bracket every n-th launch of a kernel with HIP events (odd: a kernel's norms / predictor launches alternate)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -261,6 +262,7 @@ def main():
     if not args.no_kernel_events:
         for kname in knames:                               # HIP events around those kernels' launches, on their stream
             eng.profile_kernel(kname)
+        eng.profile_stride(args.event_stride)              # every n-th launch: dense bracketing costs ~6 % of the step
     sync()
     t0 = time.perf_counter()
     run_steps(0, args.steps)

@@ -23,7 +23,7 @@ TARGET_X, TARGET_ADJ, TARGET_RANK2 = 0, 1, 2
 EXPORTS = [
     "ccsd_plan_create", "ccsd_plan_destroy", "ccsd_weight_count", "ccsd_rank2_dims", "ccsd_workspace_bytes",
     "ccsd_last_error", "ccsd_score", "ccsd_init_state", "ccsd_corrector_norms", "ccsd_corrector_apply",
-    "ccsd_predictor", "ccsd_s4_apply", "ccsd_sampler_run", "ccsd_quantize", "ccsd_rank2_cells", "ccsd_profile_kernel", "ccsd_profile_read", "ccsd_debug_stamps",
+    "ccsd_predictor", "ccsd_s4_apply", "ccsd_sampler_run", "ccsd_quantize", "ccsd_rank2_cells", "ccsd_profile_kernel", "ccsd_profile_stride", "ccsd_profile_read", "ccsd_debug_stamps",
 ]
 KERNEL_IDS = {"k_xa": 0, "k_gemm_p": 1, "k_hf_score": 2, "k_gemm_h": 3, "k_langevin_apply": 4, "k_r2": 5, "k_s4_apply": 6}
 
@@ -113,6 +113,8 @@ class Library:
         L.ccsd_rank2_cells.restype = C.c_int
         L.ccsd_profile_kernel.argtypes = [vp, i32]
         L.ccsd_profile_kernel.restype = C.c_int
+        L.ccsd_profile_stride.argtypes = [vp, i32]
+        L.ccsd_profile_stride.restype = C.c_int
         L.ccsd_profile_read.argtypes = [vp, i32, P(i64), P(C.c_double)]
         L.ccsd_profile_read.restype = C.c_int
         L.ccsd_debug_stamps.argtypes = [vp, vp]

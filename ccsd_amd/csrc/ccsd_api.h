@@ -31,6 +31,10 @@ struct ccsd_plan {
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     unsigned prof_mask = 0;
     size_t prof_used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // every prof_stride-th launch of a selected kernel is bracketed by events (event records break back-to-back dispatch:
+    // bracketing every launch costs ~6 % of the step)
+    int prof_stride = 1;
+    size_t prof_calls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #ifndef CCSD_EMU
     std::vector<hipEvent_t> prof_ev[8];
 #endif
@@ -40,6 +44,8 @@ enum { KID_XA = 0, KID_GEMM_P = 1, KID_HF = 2, KID_GEMM_H = 3, KID_LANGEVIN = 4,
 static void prof_mark(ccsd_plan* pl, int kid, void* stream) {
 #ifndef CCSD_EMU
     if (!(pl->prof_mask & (1u << kid))) return;
+    const size_t call = pl->prof_calls[kid]++;                 // two calls per launch: before and after
+    if (pl->prof_stride > 1 && (call >> 1) % (size_t)pl->prof_stride != 0) return;
     std::vector<hipEvent_t>& ev = pl->prof_ev[kid];
     if (pl->prof_used[kid] == ev.size()) {
         hipEvent_t e;
@@ -87,7 +93,13 @@ extern "C" int ccsd_profile_kernel(ccsd_plan_t* plan, int32_t kernel_id) {
     if (!plan) return set_err(CCSD_ERR_INVALID, "NULL plan");
     if (kernel_id < 0) plan->prof_mask = 0;
     else if (kernel_id < 8) plan->prof_mask |= 1u << kernel_id;
-    for (int k = 0; k < 8; ++k) plan->prof_used[k] = 0;
+    for (int k = 0; k < 8; ++k) { plan->prof_used[k] = 0; plan->prof_calls[k] = 0; }
+    return CCSD_OK;
+}
+extern "C" int ccsd_profile_stride(ccsd_plan_t* plan, int32_t stride) {
+    if (!plan || stride < 1) return set_err(CCSD_ERR_INVALID, "bad argument");
+    plan->prof_stride = stride;
+    for (int k = 0; k < 8; ++k) plan->prof_calls[k] = 0;
     return CCSD_OK;
 }
 extern "C" int ccsd_profile_read(ccsd_plan_t* plan, int32_t kernel_id, int64_t* launches, double* total_ms) {

@@ -182,6 +182,10 @@ class PCEngine:
         """Add a kernel to the set timed with HIP events on the launch stream (None clears the set)."""
         self.lib.check(self.lib.ccsd_profile_kernel(self.handle, -1 if name is None else _lib.KERNEL_IDS[name]))
 
+    def profile_stride(self, stride: int):
+        """Bracket only every `stride`-th launch of the selected kernels with events."""
+        self.lib.check(self.lib.ccsd_profile_stride(self.handle, int(stride)))
+
     def profile_read(self, name: str) -> Tuple[int, float]:
         n, ms = C.c_int64(0), C.c_double(0.0)
         self.lib.check(self.lib.ccsd_profile_read(self.handle, _lib.KERNEL_IDS[name], C.byref(n), C.byref(ms)))

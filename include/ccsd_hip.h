@@ -193,6 +193,9 @@ int ccsd_rank2_cells(const float* rank2_dev, int32_t B, int32_t E, int64_t K, fl
  * kernel_id: 0 k_xa, 1 k_gemm_p, 2 k_hf_score, 3 k_gemm_h, 4 k_langevin_apply, 5 k_r2, 6 k_s4_apply; each call adds one kernel to the
  * selection, -1 clears it.  ccsd_profile_read synchronises on that kernel's events and returns launches + summed ms. */
 int ccsd_profile_kernel(ccsd_plan_t* plan, int32_t kernel_id);
+/* bracket only every stride-th launch of the selected kernels (default 1 = every launch): event records break
+ * back-to-back dispatch, so dense bracketing perturbs the timed region (~6 % of a qm9_CC step). */
+int ccsd_profile_stride(ccsd_plan_t* plan, int32_t stride);
 int ccsd_profile_read(ccsd_plan_t* plan, int32_t kernel_id, int64_t* launches, double* total_ms);
 /* Diagnostic: when dev_buffer (B x 64 int64, device) is non-NULL, thread 0 of every workgroup of k_r2 (slots 0-31)
  * and k_xa (slots 32-63) stores the shader clock at its phase boundaries (tools/stamps.py).  NULL disables. */
