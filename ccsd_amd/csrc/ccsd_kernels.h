@@ -1875,13 +1875,17 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
         float* s_xnext = sm + p.o_xnext;
         float* s_mch = sm + p.o_vcat;
         if (xa.cf.on) {
-            // fused corrector: rebuild the corrected (x, adj) (identical values to the X-network phase), then fan out
+            // fused corrector: the A-network sees the corrected (x, adj).  When the X-network phase of this launch has just
+            // built them from the same inputs (predictor launches: xA == xX, adjA == adjX) they are still in LDS.
+            const bool reuse = xa.do_x && xa.xA == xa.xX && xa.adjA == xa.adjX;
             __syncthreads();
-            for (int i = tid; i < N * F; i += nth) s_x[i] = xa.xA[(size_t)b * N * F + i];
-            for (int i = tid; i < NN; i += nth) s_adj[i] = xa.adjA[(size_t)b * NN + i];
-            __syncthreads();
-            corr_apply_xa(xa.cf, na, b, N, F, s_x, s_adj, s_flags);
-            __syncthreads();
+            if (!reuse) {
+                for (int i = tid; i < N * F; i += nth) s_x[i] = xa.xA[(size_t)b * N * F + i];
+                for (int i = tid; i < NN; i += nth) s_adj[i] = xa.adjA[(size_t)b * NN + i];
+                __syncthreads();
+                corr_apply_xa(xa.cf, na, b, N, F, s_x, s_adj, s_flags);
+                __syncthreads();
+            }
             for (int t = tid; t < N * F; t += nth) { int i, f; dF.divmod(t, i, f); s_xcur[f * ldn + i] = s_x[t]; }
             for (int i = tid; i < NN; i += nth) s_chan[i] = s_adj[i];
         } else {
