@@ -1231,12 +1231,20 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     float* sRed = sAdj + 3 * NN;           // [64]
     unsigned char* sFrb = reinterpret_cast<unsigned char*>(sRed + 64);   // [Kp4] flags_right (cell masks) as bytes
     __shared__ unsigned long long s_off;
+#ifndef CCSD_EMU
+    __shared__ int s_hdone;              // H-tile tasks finished (phase 1 -> 2 hand-over)
+#endif
     const float* Fg = ra.rank2 + (size_t)b * E * K;
     const FastDiv dK(K);
 
     // ---- phase 0: rank2 block -> LDS; masks; adjacency powers
     stamp(ra.dbg, 0);
-    if (tid == 0) s_off = ra.offbits[b];      // switched-off nodes (k_flagbits): one load instead of a serial walk over the flags
+    if (tid == 0) {
+        s_off = ra.offbits[b];                // switched-off nodes (k_flagbits): one load instead of a serial walk over the flags
+#ifndef CCSD_EMU
+        s_hdone = 0;
+#endif
+    }
     // With the fused Langevin apply (predictor launches of ccsd_sampler_run) the raw scores of the norms pass are loaded
     // alongside and F + c1*net goes to LDS in the same pass (same fma as k_langevin_apply; the noise term follows below).
     float c1f = 0.f, c2f = 0.f;
@@ -1368,6 +1376,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     // are double-buffered in registers one batch ahead.  No atomics: results are bitwise reproducible.
     stamp(ra.dbg, 2);
     const int ks = Kp4 >> 2;
+    int nHtasks = 0;
     const int nH = p.f_cnum == 2 ? MT * (MT + 1) / 2 : 0;
     const int nt0 = doP0 ? (wc0 + 15) >> 4 : 0, nt1 = doP1 ? (wc1 + 15) >> 4 : 0;
     const int ntask = nH + MT * nt0 + MT * nt1;
@@ -1418,6 +1427,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
         const float mval_b0 = lin1 ? w[h0.mval.b[0]] : 0.f;       // fetched before the k loops
         int npairs = 0;
         for (int i = 0; i < MT; ++i) npairs += (((p.f_cnum == 2 ? MT - i : 0) + nt0) + 1) / 2 + (nt1 + 1) / 2;
+        for (int i = 0; i < MT; ++i) nHtasks += ((p.f_cnum == 2 ? MT - i : 0) + 1) / 2;    // pairs that hold an H tile
         for (int pr = wave; pr < npairs; pr += nw) {
             // decode pair -> (row tile, list, first entry)
             int i = 0, kind = 0, first = 0, rem = pr;
@@ -1576,13 +1586,24 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                 }
             }
             if (pr == 0) stamp(ra.dbg, 6);
+            if (kind == 0 && first < nh) {
+                // this task wrote H tiles: publish (a wave's LDS operations complete in order)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) atomicAdd(&s_hdone, 1);
+            }
         }
     }
-#endif
     stamp(ra.dbg, 7);
-    __syncthreads();
+    // No workgroup barrier here: phase 2 only READS the rank-2 block (its results go straight to HBM), so a wave may start
+    // it as soon as H is complete -- the waves with the lighter phase-1 tasks do not wait for the projection tasks.
+    if (nHtasks > 0) {
+        int spins = 0;
+        while (__hip_atomic_load(&s_hdone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < nHtasks && ++spins < (1 << 22))
+            __builtin_amdgcn_s_sleep(4);
+    }
+#endif
 
-    // ---- phase 2: (H F) per 16-column tile, ScoreNetworkF element-wise, epilogue in place in LDS.
+    // ---- phase 2: (H F) per 16-column tile, ScoreNetworkF element-wise, epilogue straight to HBM.
     // H's A-fragments live in registers for the whole phase.
     stamp(ra.dbg, 3);
     float s_net = 0.f, s_z = 0.f;
@@ -1599,18 +1620,19 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
             const float f = sF[e * ldk + k];
             const float m = sFl[e] * fr;                         // flags_left * flags_right, cc_utils.py:590
             const float net = fnet_element<AFFINE>(p, w, f, hf[r], m);
+            const size_t gi = ((size_t)b * E + e) * K + k;
             if (ep.mode == MODE_SCORE) {
-                sF[e * ldk + k] = ep.sscale * net;
+                ep.out[gi] = ep.sscale * net;
             } else {
                 const float zz = z[r] * m;                       // gen_noise_rank2, cc_utils.py:613-615
                 if (ep.mode == MODE_NORMS) {
-                    sF[e * ldk + k] = net;
+                    ep.out[gi] = net;
                     s_net = fmaf(net, net, s_net);
                     s_z = fmaf(zz, zz, s_z);
                 } else {
                     const float mean = fmaf(ep.pa, f, ep.pb * net);
-                    if (ep.mean) ep.mean[((size_t)b * E + e) * K + k] = mean;
-                    sF[e * ldk + k] = fmaf(ep.pc, zz, mean);
+                    if (ep.mean) ep.mean[gi] = mean;
+                    ep.out[gi] = fmaf(ep.pc, zz, mean);
                 }
             }
         }
@@ -1646,6 +1668,8 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                 const float v = sH[(r < E ? r : E - 1) * ldh + (c < E ? c : E - 1)];
                 hA[i][s0] = (r < E && c < E) ? v : 0.f;
             }
+        // (static tile -> wave assignment: the per-thread accumulation order of the Langevin norms stays fixed, runs are
+        // bitwise reproducible)
         for (int tn = wave; tn < ntn; tn += nw) {
             const int n = 16 * tn + l15;
             const bool nin = n < K;
@@ -1675,31 +1699,8 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
         }
     }
 #endif
-    __syncthreads();
-    // ---- phase 3
+    // (no phase 3: the epilogue wrote the results to HBM)
     stamp(ra.dbg, 4);
-    float* og = ep.out + (size_t)b * E * K;
-    if (((E * K) & 3) == 0) {
-        float4* O4 = reinterpret_cast<float4*>(og);
-        const int n4 = (E * K) >> 2;
-        for (int i4 = tid; i4 < n4; i4 += nth) {
-            int e, k;
-            dK.divmod(4 * i4, e, k);
-            float vv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                vv[q] = sF[e * ldk + k];
-                if (++k == K) { k = 0; ++e; }
-            }
-            O4[i4] = make_float4(vv[0], vv[1], vv[2], vv[3]);
-        }
-    } else {
-        for (int t = tid; t < E * K; t += nth) {
-            int e, k;
-            dK.divmod(t, e, k);
-            og[t] = sF[e * ldk + k];
-        }
-    }
     if (ep.mode == MODE_NORMS) {
         const float tn_ = block_sum(s_net, sRed);
         const float tz_ = block_sum(s_z, sRed);
