@@ -46,6 +46,10 @@ WORKLOADS = {
                      snr=0.2, scale_eps=0.9, flop_x=945_440, flop_a=58_489_296, flop_f=0,
                      desc="zinc250k (graph-only substitute for the infeasible zinc250k_CC, SURVEY 8d 5a) N=38 F=9, B={B} per GPU, "
                           "VP(x)/VE(adj), Reverse+Langevin snr=0.2 scale_eps=0.9, 1000 scales; synthetic node-count mix"),
+    "qm9_Base_CC": dict(ckpt="ccsd_qm9_Base_CC", batch=1024, hist=QM9_HIST, predictor="Reverse", corrector="Langevin", snr=0.2,
+                        scale_eps=0.7, flop_x=None, flop_a=None, flop_f=None,
+                        desc="qm9_Base_CC (ScoreNetworkA_Base_CC ablation) N=9 F=4 E=36 K=466, B={B} per GPU, VE x3, Reverse+Langevin "
+                             "snr=0.2 scale_eps=0.7 n_steps=1, 1000 scales"),
     "enzymes_small_CC": dict(ckpt="ccsd_enzymes_small_CC", batch=64, hist={12: 6, 11: 5, 10: 5, 9: 4, 8: 4, 6: 3, 4: 2}, predictor="S4",
                              corrector="None", snr=0.15, scale_eps=0.7, flop_x=None, flop_a=None, flop_f=None,
                              desc="ENZYMES_small_CC N=12 F=10 E=66 K=715, B={B} per GPU, VP(x)/VE/VE, S4 solver snr=0.15 scale_eps=0.7, 1000 scales"),

@@ -12,6 +12,18 @@
 static thread_local std::string g_last_error;
 static int set_err(int st, const std::string& m) { g_last_error = m; return st; }
 
+// widest layer of ScoreNetworkF's per-element MLPs
+static inline int fnet_width(const PlanD& p) {
+    int fw = p.f_fdim > p.f_cnum ? p.f_fdim : p.f_cnum;
+    for (int l = 0; l < p.f_L; ++l) {
+        const MlpD& m = p.fl[l];
+        const int wd = m.n > 1 && m.hid > m.in ? (m.hid > m.out ? m.hid : m.out) : (m.in > m.out ? m.in : m.out);
+        if (wd > fw) fw = wd;
+    }
+    if (p.f_fin.n > 1 && p.f_fin.hid > fw) fw = p.f_fin.hid;
+    return fw;
+}
+
 struct ccsd_plan {
     ccsd_config_t cfg;
     PlanD h;                    // host copy
@@ -218,14 +230,16 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
         int ldk = Kp4; while ((ldk & 31) != 8 && (ldk & 31) != 24) ldk += 4;   // conflict-free ds_read_b128 fragment reads (16 rows x 4 k-quads)
         int ldh = Ep4 | 1;                                                 // odd stride; H fragments are read once per wave
         const size_t fl = (size_t)E * ldk + (size_t)E * ldh + 64 * 2 + (size_t)p.a_cinit * E + 3 * N * N + 64 + (Kp4 + 3) / 4 + 4;
-        const bool wc_ok = true;
+        const bool wc_ok = fnet_width(p) <= CCSD_FW;        // the fused kernel's per-element MLPs are padded to <= 16
         if (fl * 4 + 64 <= 160 * 1024 && wc_ok) {
             pl->fused_r2 = 1; pl->r2_ldk = ldk; pl->r2_ldh = ldh; pl->r2_lds = fl * 4;
         }
     }
 #ifndef CCSD_EMU
     if ((size_t)pl->h.xa_lds_floats * 4 > 64 * 1024)
-        PC(rt_set_max_dyn_smem(pl->h.chan_global ? (const void*)k_xa<true> : (const void*)k_xa<false>, (size_t)pl->h.xa_lds_floats * 4));
+        PC(rt_set_max_dyn_smem(pl->h.hb_L ? (pl->h.chan_global ? (const void*)k_xa<true, true> : (const void*)k_xa<false, true>)
+                                          : (pl->h.chan_global ? (const void*)k_xa<true, false> : (const void*)k_xa<false, false>),
+                               (size_t)pl->h.xa_lds_floats * 4));
     if (pl->fused_r2 && pl->r2_lds > 64 * 1024) {
         const int MT = (E + 15) / 16;
         const bool aff = pl->h.f_affine != 0, gen1 = pl->h.h_L > 1 && pl->h.hl[0].mval.n > 1;
@@ -360,9 +374,10 @@ static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Work
     xa.wp = pl->wp; xa.hpairs = pl->hpairs;
     const dim3 xblk(CCSD_NTHREADS == 1 ? 1 : xa_threads);
     const size_t xlds = (size_t)pl->h.xa_lds_floats * 4;
-#define XA_GO(G_, XA_, BLK_, LDS_, STR_) CCSD_LAUNCH((k_xa<G_>), dim3(B), BLK_, LDS_, STR_, (const PlanD*)pl->d, (const float*)pl->w, \
-                                                     (const unsigned char*)pl->edges, XA_, na)
-    { if (pl->h.chan_global) XA_GO(true, xa, xblk, xlds, stream); else XA_GO(false, xa, xblk, xlds, stream); }
+#define XA_GO(G_, HB_, XA_, BLK_, LDS_, STR_) CCSD_LAUNCH((k_xa<G_, HB_>), dim3(B), BLK_, LDS_, STR_, (const PlanD*)pl->d, (const float*)pl->w, \
+                                                          (const unsigned char*)pl->edges, XA_, na)
+    if (pl->h.hb_L) { if (pl->h.chan_global) XA_GO(true, true, xa, xblk, xlds, stream); else XA_GO(false, true, xa, xblk, xlds, stream); }
+    else { if (pl->h.chan_global) XA_GO(true, false, xa, xblk, xlds, stream); else XA_GO(false, false, xa, xblk, xlds, stream); }
 #undef XA_GO
     prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
     LAUNCH_CHECK();
@@ -374,12 +389,11 @@ static int launch_hf(const ccsd_plan* pl, int B, const float* rank2, RankEpi& ep
     prof_mark(const_cast<ccsd_plan*>(pl), KID_HF, stream);
 #define HF_ARGS (const PlanD*)pl->d, (const float*)pl->w, rank2, (const float*)w.H, (const unsigned long long*)w.offbits, \
                 (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, ep, na
-    int fw = p.f_fdim > p.f_cnum ? p.f_fdim : p.f_cnum;       // widest layer of ScoreNetworkF's per-element MLPs
-    for (int l = 0; l < p.f_L; ++l) { const MlpD& m = p.fl[l]; const int wd = m.n > 1 && m.hid > m.in ? (m.hid > m.out ? m.hid : m.out) : (m.in > m.out ? m.in : m.out); if (wd > fw) fw = wd; }
-    if (p.f_fin.n > 1 && p.f_fin.hid > fw) fw = p.f_fin.hid;
+    const int fw = fnet_width(p);
     if (p.f_affine) CCSD_LAUNCH((k_hf_score<true, 8>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS);
     else if (fw <= 8) CCSD_LAUNCH((k_hf_score<false, 8>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS);
-    else CCSD_LAUNCH((k_hf_score<false, CCSD_FW>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS);
+    else if (fw <= CCSD_FW) CCSD_LAUNCH((k_hf_score<false, CCSD_FW>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS);
+    else CCSD_LAUNCH((k_hf_score<false, CCSD_FWMAX>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS);
 #undef HF_ARGS
     prof_mark(const_cast<ccsd_plan*>(pl), KID_HF, stream);
     LAUNCH_CHECK();

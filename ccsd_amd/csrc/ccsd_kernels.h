@@ -1769,7 +1769,9 @@ CCSD_DEV void gcn_dinv(const float* a, float* dinv, int nc, int N) {
 // (zinc250k, N = 38: 266 KB) and lives in a per-graph slab of the workspace instead; a workgroup's waves share one
 // CU and its L1, so __syncthreads() orders those global accesses exactly like the LDS ones.
 // Weights are read in place from L2.
-template <bool GCH>
+// HB: the plan holds HodgeBaselineLayers (ScoreNetworkA_Base_CC); a separate instantiation keeps that branch out of the
+// register allocation of the headline variants.
+template <bool GCH, bool HB>
 __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict__ plan, const float* __restrict__ w,
                                             const unsigned char* __restrict__ edges, XaArgs xa, NoiseArgs na) {
     CCSD_DYN_SMEM(sm);
@@ -2050,7 +2052,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
 
         stamp(xa.dbg, 12);
         // ---- hodge branch of ScoreNetworkA_CC (ScoreNetwork_A_CC.py:295-316)
-        if (p.h_L > 0) {
+        if (!HB && p.h_L > 0) {
             float* s_hd = sm + p.o_hd;          // [hodge channel][E]: diagonals that reach the final MLP
             float* s_hq = sm + p.o_hq;          // [channel][E][2*adim]
             float* s_h1m = s_R;                 // [cout0][E][E] dense output of the first hodge layer
@@ -2267,6 +2269,132 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                 __syncthreads();
             }
             stamp(xa.dbg, 20);
+            // hodgedual_to_adj (cc_utils.py:1552-1588): scatter the diagonals behind the graph channels
+            for (int t = tid; t < p.a_nch_hodge * E; t += nth) {
+                int c, e;
+                dE.divmod(t, c, e);
+                const int i = edge_i(e), j = edge_j(e);
+                const float v = s_hd[t];
+                s_chan[(p.a_nch_graph + c) * NN + i * N + j] = v;
+                s_chan[(p.a_nch_graph + c) * NN + j * N + i] = v;
+            }
+            __syncthreads();
+        }
+
+        // ---- hodge branch of ScoreNetworkA_Base_CC (ScoreNetwork_A_Base_CC.py:295-316): HodgeBaselineLayers
+        // (hodge_layers.py:385-416) on the E x E hodge adjacency channels.  Their rank-2 outputs (bmm + mlp_rank2) never
+        // reach the score and are not evaluated; of the last layer only the diagonal does (hodgedual_to_adj), so the dense
+        // E x E output of the first layer is produced a chunk of rows at a time and consumed on the spot.
+        if (HB && p.hb_L > 0) {
+            float* s_hd = sm + p.o_hd;            // [hodge channel][E]: diagonals that reach the final MLP
+            float* s_g = sm + p.o_hbg;            // [cin0][E][hid0]: hidden rows of the first layer's BaselineBlocks
+            const HodgeBaseD& b0 = p.hb[0];
+            const int hd0 = b0.hid;
+            const FastDiv dh0(hd0), dEh0(E * hd0);
+            // adj_to_hodgedual: row e of input channel c is a_c[e] * onehot(e)  =>  hidden = elu(W1[:, e] * a_c[e] + b1)
+            for (int t = tid; t < p.a_cinit * E; t += nth) {
+                int c, e;
+                dE.divmod(t, c, e);
+                s_hd[t] = s_chan[c * NN + pair_off(e)];
+            }
+            for (int t = tid; t < b0.cin * E * hd0; t += nth) {
+                int c, r, e, h;
+                dEh0.divmod(t, c, r);
+                dh0.divmod(r, e, h);
+                const float* blk = w + b0.blk_base + c * b0.blk_stride;       // W1[hid][E] b1[hid] W2[E][hid] b2[E]
+                const float a = s_chan[c * NN + pair_off(e)];
+                s_g[t] = elu1(fmaf(blk[h * E + e], a, blk[hd0 * E + h]));
+            }
+            __syncthreads();
+            // tanh(mlp_layer(H_c))[e][e2] from the hidden row of e (BaselineBlock.forward, hodge_layers.py:264)
+            auto blockv = [&](int c, int e, int e2) {
+                const float* blk = w + b0.blk_base + c * b0.blk_stride;
+                const float* w2 = blk + hd0 * E + hd0 + e2 * hd0;
+                const float* g = s_g + (c * E + e) * hd0;
+                float acc = 0.f;
+                for (int h = 0; h < hd0; ++h) acc = fmaf(g[h], w2[h], acc);
+                return tanh_f(acc + blk[hd0 * E + hd0 + E * hd0 + e2]);
+            };
+            // mlp_hodge over the symmetrised channels -> mask_hodge_adjs -> tanh -> + transpose, element (e, e2) of layer 0
+            auto layer0 = [&](int e, int e2, float* out) {
+                float in[CCSD_FW];
+#pragma unroll
+                for (int c = 0; c < CCSD_FW; ++c) in[c] = 0.f;
+#pragma unroll
+                for (int c = 0; c < CCSD_FW; ++c)
+                    if (c < b0.cin) in[c] = e == e2 ? blockv(c, e, e) : (blockv(c, e, e2) + blockv(c, e2, e)) * 0.5f;
+                small_mlp<CCSD_FW>(b0.mh, w, in, out);
+                const float fh = s_flags[edge_i(e)] * s_flags[edge_j(e)] * s_flags[edge_i(e2)] * s_flags[edge_j(e2)];
+#pragma unroll
+                for (int o = 0; o < CCSD_FW; ++o) { const float tv = tanh_f(out[o] * fh); out[o] = tv + tv; }
+            };
+            if (p.hb_L == 1) {
+                for (int e = tid; e < E; e += nth) {
+                    float out[CCSD_FW];
+                    layer0(e, e, out);
+#pragma unroll
+                    for (int o = 0; o < CCSD_FW; ++o)
+                        if (o < b0.cout) s_hd[(p.a_cinit + o) * E + e] = out[o];
+                }
+                __syncthreads();
+            } else {
+                const HodgeBaseD& b1 = p.hb[1];
+                const int hd1 = b1.hid, R = p.hb_rows;
+                float* s_row = s_R;                           // [cout0][R][E]: rows r0 .. r0 + R of layer 0's output
+                float* s_g2 = s_R + b0.cout * R * E;          // [R][cin1][hid1]: hidden rows of the second layer's blocks
+                float* s_d2 = sm + p.o_hbd;                   // [cin1][E]: diagonal of tanh(mlp_layer(H1_c))
+                const FastDiv dch1(b1.cin * hd1);
+                for (int r0 = 0; r0 < E; r0 += R) {
+                    const int nr = (E - r0) < R ? (E - r0) : R;
+                    for (int t = tid; t < nr * E; t += nth) {
+                        int er, e2;
+                        dE.divmod(t, er, e2);
+                        const int e = r0 + er;
+                        float out[CCSD_FW];
+                        layer0(e, e2, out);
+#pragma unroll
+                        for (int o = 0; o < CCSD_FW; ++o)
+                            if (o < b0.cout) {
+                                s_row[(o * R + er) * E + e2] = out[o];
+                                if (e == e2) s_hd[(p.a_cinit + o) * E + e] = out[o];
+                            }
+                    }
+                    __syncthreads();
+                    for (int t = tid; t < nr * b1.cin * hd1; t += nth) {
+                        int er, r, c, h;
+                        dch1.divmod(t, er, r);
+                        c = r / hd1; h = r - c * hd1;
+                        const float* blk = w + b1.blk_base + c * b1.blk_stride;
+                        const float* w1 = blk + h * E;
+                        const float* row = s_row + (c * R + er) * E;
+                        float acc = 0.f;
+                        for (int e2 = 0; e2 < E; ++e2) acc = fmaf(row[e2], w1[e2], acc);
+                        s_g2[t] = elu1(acc + blk[hd1 * E + h]);
+                    }
+                    __syncthreads();
+                    for (int t = tid; t < nr * b1.cin; t += nth) {
+                        const int er = t / b1.cin, c = t - er * b1.cin, e = r0 + er;
+                        const float* blk = w + b1.blk_base + c * b1.blk_stride;
+                        const float* w2 = blk + hd1 * E + hd1 + e * hd1;
+                        const float* g = s_g2 + t * hd1;
+                        float acc = 0.f;
+                        for (int h = 0; h < hd1; ++h) acc = fmaf(g[h], w2[h], acc);
+                        s_d2[c * E + e] = tanh_f(acc + blk[hd1 * E + hd1 + E * hd1 + e]);
+                    }
+                    __syncthreads();
+                }
+                for (int e = tid; e < E; e += nth) {
+                    float in[CCSD_FW], out[CCSD_FW];
+#pragma unroll
+                    for (int c = 0; c < CCSD_FW; ++c) in[c] = c < b1.cin ? s_d2[(c < b1.cin ? c : 0) * E + e] : 0.f;
+                    small_mlp<CCSD_FW>(b1.mh, w, in, out);
+                    const float fh = s_flags[edge_i(e)] * s_flags[edge_j(e)];
+#pragma unroll
+                    for (int o = 0; o < CCSD_FW; ++o)
+                        if (o < b1.cout) { const float tv = tanh_f(out[o] * fh * fh); s_hd[(p.a_cinit + b0.cout + o) * E + e] = tv + tv; }
+                }
+                __syncthreads();
+            }
             // hodgedual_to_adj (cc_utils.py:1552-1588): scatter the diagonals behind the graph channels
             for (int t = tid; t < p.a_nch_hodge * E; t += nth) {
                 int c, e;

@@ -11,7 +11,8 @@
 #define CCSD_MAXHL 2      // hodge layers handled by the HIP path
 #define CCSD_MAXFL 4      // HodgeNetworkLayers in ScoreNetworkF
 #define CCSD_SMALLW 8     // widest per-thread MLP in the hodge branch
-#define CCSD_FW 16        // widest per-thread MLP in ScoreNetworkF's general path
+#define CCSD_FW 16        // widest per-thread MLP in ScoreNetworkF's general path (fused kernel; hodge baseline mlp_hodge)
+#define CCSD_FWMAX 32     // ... in the tiled k_hf_score path
 
 struct MlpD {
     int n, in, hid, out;
@@ -47,6 +48,15 @@ struct HodgeLayerD {
     MlpD mval, matt;
 };
 
+// HodgeBaselineLayer of ScoreNetworkA_Base_CC (hodge_layers.py:273-416).  Per input channel a BaselineBlock: row-wise
+// MLP E -> hid -> E (block = W1[hid][E] b1[hid] W2[E][hid] b2[E]); mlp_hodge mixes the channels per (e, e').  The layer's
+// rank-2 output (bmm + mlp_rank2) never reaches the score (ScoreNetwork_A_Base_CC.py:303-321) and is not evaluated.
+struct HodgeBaseD {
+    int cin, cout, hid;
+    int blk_base, blk_stride;
+    MlpD mh;
+};
+
 struct PlanD {
     int N, F, E, K, is_cc;
     float snr, seps;
@@ -59,6 +69,9 @@ struct PlanD {
     AttnLayerD al[CCSD_MAXL];
     int h_L;
     HodgeLayerD hl[CCSD_MAXHL];
+    int hb_L;                     // ScoreNetworkA_Base_CC: HodgeBaselineLayers (0 otherwise)
+    HodgeBaseD hb[CCSD_MAXHL];
+    int o_hbg, o_hbd, hb_rows;    // k_xa LDS: hidden rows of layer 0 [cin][E][hid]; diagonals of layer 1's blocks [cin][E]; rows per chunk
     MlpD a_fin;
     // ScoreNetworkF
     int f_L, f_cnum, f_hmask, f_fdim, f_affine;
@@ -216,8 +229,32 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     int fdim = c->a_c_hid * (p->a_L - 1) + c->a_c_final + c->a_c_init;
     if (fdim != ch) { pb.fail(CCSD_ERR_INVALID, "ScoreNetworkA channel count inconsistent (num_layers==1 needs c_hid==c_final)"); return 0; }
     // ---- hodge branch
-    p->h_L = 0; p->a_nch_hodge = 0;
-    if (c->a_is_cc_net) {
+    p->h_L = 0; p->a_nch_hodge = 0; p->hb_L = 0;
+    if (c->a_is_cc_net == 2) {
+        if (!c->is_cc) { pb.fail(CCSD_ERR_INVALID, "ScoreNetworkA_Base_CC is only for combinatorial complexes"); return 0; }
+        if (c->h_num_layers < 1 || c->h_num_layers > CCSD_MAXHL) {
+            pb.fail(CCSD_ERR_UNSUPPORTED, "HIP path supports 1 or 2 HodgeBaselineLayers"); return 0; }
+        p->hb_L = c->h_num_layers;
+        int hch = c->a_c_init;
+        for (int l = 0; l < p->hb_L; ++l) {
+            HodgeBaseD& h = p->hb[l];
+            const bool first = (l == 0), last = (l == p->hb_L - 1) && !first;
+            h.cin = first ? c->a_c_init : c->h_c_hid;
+            h.cout = last ? c->h_c_final : c->h_c_hid;
+            h.hid = first ? c->h_nhid : c->h_adim;
+            if (h.hid < 1) { pb.fail(CCSD_ERR_INVALID, "HodgeBaselineLayer hidden width < 1"); return 0; }
+            h.blk_stride = 2 * h.hid * E + h.hid + E;
+            h.blk_base = pb.take((int64_t)h.cin * h.blk_stride);
+            const int hid = 2 * (h.cin > h.cout ? h.cin : h.cout);
+            h.mh = pb.mlp(c->h_num_linears, h.cin, hid, h.cout);
+            if (h.cin > CCSD_FW || (c->h_num_linears > 1 && hid > CCSD_FW) || h.cout > CCSD_FW) {
+                pb.fail(CCSD_ERR_UNSUPPORTED, "HodgeBaselineLayer mlp_hodge wider than 16"); return 0; }
+            hch += h.cout;
+        }
+        p->a_nch_hodge = hch;
+        int hf = c->h_c_hid * (p->hb_L - 1) + c->h_c_final + c->a_c_init;
+        if (hf != hch) { pb.fail(CCSD_ERR_INVALID, "hodge channel count inconsistent (num_layers_h==1 needs c_hid_h==c_final_h)"); return 0; }
+    } else if (c->a_is_cc_net) {
         if (!c->is_cc) { pb.fail(CCSD_ERR_INVALID, "ScoreNetworkA_CC is only for combinatorial complexes"); return 0; }
         if (c->h_num_layers < 1 || c->h_num_layers > CCSD_MAXHL) {
             pb.fail(CCSD_ERR_UNSUPPORTED, "HIP path supports 1 or 2 HodgeAdjAttentionLayers"); return 0; }
@@ -260,14 +297,14 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             const bool first = (l == 0), last = (l == p->f_L - 1) && !first;
             const int cin = first ? c->f_cnum : c->f_c_hid, cout = last ? c->f_c_final : c->f_c_hid;
             p->fl[l] = pb.mlp(c->f_num_linears, cin, c->f_nhid, cout);
-            if (cin > CCSD_FW || cout > CCSD_FW || c->f_nhid > CCSD_FW) { pb.fail(CCSD_ERR_UNSUPPORTED, "ScoreNetworkF layer wider than 16"); return 0; }
+            if (cin > CCSD_FWMAX || cout > CCSD_FWMAX || c->f_nhid > CCSD_FWMAX) { pb.fail(CCSD_ERR_UNSUPPORTED, "ScoreNetworkF layer wider than 32"); return 0; }
             fch += cout;
         }
         p->f_fdim = c->f_c_hid * (p->f_L - 1) + c->f_c_final + c->f_cnum;
         if (p->f_fdim != fch) { pb.fail(CCSD_ERR_INVALID, "ScoreNetworkF channel count inconsistent"); return 0; }
         p->f_fin = pb.mlp(c->f_num_layers_mlp, p->f_fdim, 2 * p->f_fdim, 1);
-        if (p->f_fdim > CCSD_FW || (c->f_num_layers_mlp > 1 && 2 * p->f_fdim > CCSD_FW)) {
-            pb.fail(CCSD_ERR_UNSUPPORTED, "ScoreNetworkF final MLP wider than 16"); return 0; }
+        if (p->f_fdim > CCSD_FWMAX || (c->f_num_layers_mlp > 1 && 2 * p->f_fdim > CCSD_FWMAX)) {
+            pb.fail(CCSD_ERR_UNSUPPORTED, "ScoreNetworkF final MLP wider than 32"); return 0; }
         p->f_affine = (c->f_num_linears == 1 && c->f_num_layers_mlp == 1) ? 1 : 0;
     }
     const size_t nweights = (size_t)pb.cur;
@@ -362,6 +399,15 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
                 p->o_hw = carve(2 * hw_n * 72);
                 p->hw_stride = hw_n * 72;
             }
+            int hb_rmin = 0;
+            if (p->hb_L) {
+                // the baseline hodge branch runs after the attention stack too
+                int g = p->hb[0].cin * E * p->hb[0].hid;
+                p->o_hbg = (g <= o - p->o_att) ? p->o_att : carve(g);
+                p->o_hbd = carve(p->hb_L > 1 ? p->hb[1].cin * E : 4);
+                p->o_hd = carve(p->a_nch_hodge * E);
+                if (p->hb_L > 1) hb_rmin = p->hb[0].cout * (E + p->hb[1].hid);     // one row of layer 0's output + its hidden row
+            }
             if (xphase_end > o) o = xphase_end;
             p->o_wst = carve(wst);
             p->wst_floats = wst;
@@ -370,6 +416,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             if (N * c->x_nhid > rmin) rmin = N * c->x_nhid;
             if (h1m_floats > rmin) rmin = h1m_floats;
             if (NN > rmin) rmin = NN;                                       // raw output of the chained final MLP
+            if (hb_rmin > rmin) rmin = hb_rmin;
             if (o + rmin > budget) continue;
             bool pair_chained = true;
             for (int l = 0; l < p->a_L; ++l) pair_chained = pair_chained && p->al[l].mlp.chain != 0;
@@ -383,6 +430,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             if (!pair_chained && 2 * pw_pair * ld_of(pchp) > r) r = 2 * pw_pair * ld_of(pchp);
             p->cg = cg; p->pch = pch; p->ldp = ld_of(pch); p->pchp = pchp; p->ldpp = ld_of(pchp);
             p->o_c0 = carve(r > 64 ? r : 64); p->o_c1 = p->o_c0;
+            if (hb_rmin) { p->hb_rows = (r > 64 ? r : 64) / hb_rmin; if (p->hb_rows > E) p->hb_rows = E; }
             p->o_red = p->o_c0;                                              // block reductions run when R is idle
             p->xa_lds_floats = o;
             best_total = o;

@@ -185,6 +185,23 @@ class ScoreNetworkA_CC(_ScoreNetwork):
                          conv=conv, conv_hodge=conv_hodge, use_bn=use_bn, is_cc=is_cc)
 
 
+class ScoreNetworkA_Base_CC(_ScoreNetwork):
+    """ScoreNetwork_A_Base_CC.py:28-323: the AttentionLayer stack of ScoreNetworkA plus HodgeBaselineLayers."""
+    model_type, target = "ScoreNetworkA_Base_CC", _lib.TARGET_ADJ
+
+    def __init__(self, max_feat_num: int, max_node_num: int, d_min: int, d_max: int, nhid: int, nhid_h: int,
+                 num_layers: int, num_layers_h: int, num_linears: int, num_linears_h: int, c_init: int, c_hid: int,
+                 c_hid_h: int, c_final: int, c_final_h: int, adim: int, hidden_h: int, num_heads: int = 4,
+                 conv: str = "GCN", use_bn: bool = False, is_cc: bool = True):
+        if not is_cc:
+            raise ValueError("ScoreNetworkA_Base_CC is only for combinatorial complexes")
+        super().__init__(max_feat_num=max_feat_num, max_node_num=max_node_num, d_min=d_min, d_max=d_max, nhid=nhid,
+                         nhid_h=nhid_h, num_layers=num_layers, num_layers_h=num_layers_h, num_linears=num_linears,
+                         num_linears_h=num_linears_h, c_init=c_init, c_hid=c_hid, c_hid_h=c_hid_h, c_final=c_final,
+                         c_final_h=c_final_h, adim=adim, hidden_h=hidden_h, num_heads=num_heads, conv=conv, use_bn=use_bn,
+                         is_cc=is_cc)
+
+
 class ScoreNetworkF(_ScoreNetwork):
     model_type, target = "ScoreNetworkF", _lib.TARGET_RANK2
 
@@ -196,14 +213,14 @@ class ScoreNetworkF(_ScoreNetwork):
                          use_hodge_mask=use_hodge_mask, use_bn=use_bn, is_cc=is_cc)
 
 
-MODEL_TYPES = {c.model_type: c for c in (ScoreNetworkX, ScoreNetworkA, ScoreNetworkA_CC, ScoreNetworkF)}
+MODEL_TYPES = {c.model_type: c for c in (ScoreNetworkX, ScoreNetworkA, ScoreNetworkA_CC, ScoreNetworkA_Base_CC, ScoreNetworkF)}
 
 
 def load_model(params: Dict[str, Any]) -> _ScoreNetwork:
     """loader.load_model (loader.py:83-101)."""
     p = dict(params)
     t = p.pop("model_type", None)
-    if t in ("ScoreNetworkX_GMH", "ScoreNetworkA_Base_CC"):
+    if t in ("ScoreNetworkX_GMH",):
         raise NotImplementedError(f"{t} is not built in this round (SURVEY.md section 8f row 4)")
     if t not in MODEL_TYPES:
         raise ValueError(

@@ -65,6 +65,17 @@ def hodge_layer_dims(p: dict):
     return dims
 
 
+def hodge_base_dims(p: dict):
+    """(cin, cout, hidden) per HodgeBaselineLayer (ScoreNetwork_A_Base_CC.py:153-195)."""
+    L = p["num_layers_h"]
+    dims = []
+    for l in range(L):
+        first, last = l == 0, (l == L - 1 and l != 0)
+        dims.append((p["c_init"] if first else p["c_hid_h"], p["c_final_h"] if last else p["c_hid_h"],
+                     p["nhid_h"] if first else p["hidden_h"]))
+    return dims
+
+
 def fnet_layer_dims(p: dict):
     L = p["num_layers"]
     dims = []
@@ -84,7 +95,7 @@ def state_dict_shapes(params: dict) -> Shapes:
             s += [(f"layers.{l}.weight", (F if l == 0 else H, H)), (f"layers.{l}.bias", (H,))]
         fdim = F + params["depth"] * H
         s += _mlp_shapes("final.", 3, fdim, 2 * fdim, F)
-    elif t in ("ScoreNetworkA", "ScoreNetworkA_CC"):
+    elif t in ("ScoreNetworkA", "ScoreNetworkA_CC", "ScoreNetworkA_Base_CC"):
         for l, (cin, cout, fin, ad, fo) in enumerate(attn_layer_dims(params)):
             for c in range(cin):
                 for g, o in (("q", ad), ("k", ad), ("v", fo)):
@@ -104,6 +115,15 @@ def state_dict_shapes(params: dict) -> Shapes:
                 s += _mlp_shapes(f"layers_hodge.{l}.mlp_value.", params["num_linears_h"], cin, hid, 1)
                 s += _mlp_shapes(f"layers_hodge.{l}.mlp_attention.", params["num_linears_h"], cin, hid, cout)
             fdim += params["c_hid_h"] * (params["num_layers_h"] - 1) + params["c_final_h"] + params["c_init"]
+        if t == "ScoreNetworkA_Base_CC":
+            E, _ = rank2_dim(params["max_node_num"], params["d_min"], params["d_max"])
+            for l, (cin, cout, hd) in enumerate(hodge_base_dims(params)):
+                for c in range(cin):
+                    s += _mlp_shapes(f"layers_hodge.{l}.layers.{c}.mlp_layer.", 2, E, hd, E)
+                hid = 2 * max(cin, cout)
+                s += _mlp_shapes(f"layers_hodge.{l}.mlp_rank2.", params["num_linears_h"], cin, hid, 1)
+                s += _mlp_shapes(f"layers_hodge.{l}.mlp_hodge.", params["num_linears_h"], cin, hid, cout)
+            fdim += params["c_hid_h"] * (params["num_layers_h"] - 1) + params["c_final_h"] + params["c_init"]
         s += _mlp_shapes("final.", 3, fdim, 2 * fdim, 1)
     elif t == "ScoreNetworkF":
         for l, (cin, cout) in enumerate(fnet_layer_dims(params)):
@@ -112,7 +132,8 @@ def state_dict_shapes(params: dict) -> Shapes:
         s += _mlp_shapes("final.", params["num_layers_mlp"], fdim, 2 * fdim, 1)
     else:
         raise ValueError(
-            f"Model Name <{t}> is unknown. Please select from [ScoreNetworkX, ScoreNetworkA, ScoreNetworkA_CC, ScoreNetworkF]")
+            f"Model Name <{t}> is unknown. Please select from [ScoreNetworkX, ScoreNetworkA, ScoreNetworkA_CC, "
+            "ScoreNetworkA_Base_CC, ScoreNetworkF]")
     return s
 
 
@@ -151,7 +172,7 @@ def make_config(px: dict, pa: dict, pf: Optional[dict], *, predictor="Euler", co
             _check_supported(p)
     if px["model_type"] != "ScoreNetworkX":
         raise NotImplementedError(f"{px['model_type']} is not supported by the HIP path yet")
-    if pa["model_type"] not in ("ScoreNetworkA", "ScoreNetworkA_CC"):
+    if pa["model_type"] not in ("ScoreNetworkA", "ScoreNetworkA_CC", "ScoreNetworkA_Base_CC"):
         raise NotImplementedError(f"{pa['model_type']} is not supported by the HIP path yet")
     is_cc = pf is not None
     c = _lib.Config()
@@ -169,6 +190,14 @@ def make_config(px: dict, pa: dict, pf: Optional[dict], *, predictor="Euler", co
         c.h_num_layers, c.h_num_linears = pa["num_layers_h"], pa["num_linears_h"]
         c.h_nhid, c.h_adim, c.h_c_hid, c.h_c_final = pa["nhid_h"], pa["adim_h"], pa["c_hid_h"], pa["c_final_h"]
         c.h_num_heads = pa.get("num_heads_h", 4)
+    elif pa["model_type"] == "ScoreNetworkA_Base_CC":
+        # a_is_cc_net = 2: HodgeBaselineLayer stack (h_adim carries hidden_h; heads unused)
+        if not pa.get("is_cc", True):
+            raise ValueError("ScoreNetworkA_Base_CC is only for combinatorial complexes")
+        c.a_is_cc_net = 2
+        c.h_num_layers, c.h_num_linears = pa["num_layers_h"], pa["num_linears_h"]
+        c.h_nhid, c.h_adim, c.h_c_hid, c.h_c_final = pa["nhid_h"], pa["hidden_h"], pa["c_hid_h"], pa["c_final_h"]
+        c.h_num_heads = 1
     if is_cc:
         if pf["model_type"] != "ScoreNetworkF":
             raise NotImplementedError(f"{pf['model_type']} is not supported by the HIP path yet")
@@ -246,6 +275,17 @@ def pack_weights(px: dict, sdx: Optional[Dict], pa: dict, sda: Optional[Dict], p
                 for k, shp in shapes_a.items():
                     if k.startswith(pre):
                         chunks.append(get(sda, k, shp).ravel())
+    if pa["model_type"] == "ScoreNetworkA_Base_CC":
+        # per layer: the BaselineBlocks' row MLPs channel by channel, then mlp_hodge.  mlp_rank2 only feeds the rank-2
+        # output of the layer, which never reaches the score (ScoreNetwork_A_Base_CC.py:303-321): checked, not packed.
+        for l, (cin, cout, hd) in enumerate(hodge_base_dims(pa)):
+            for pre in [f"layers_hodge.{l}.layers.{c}.mlp_layer." for c in range(cin)] + [f"layers_hodge.{l}.mlp_hodge."]:
+                for k, shp in shapes_a.items():
+                    if k.startswith(pre):
+                        chunks.append(get(sda, k, shp).ravel())
+            for k, shp in shapes_a.items():
+                if k.startswith(f"layers_hodge.{l}.mlp_rank2."):
+                    get(sda, k, shp)
     for k, shp in shapes_a.items():
         if k.startswith("final."):
             chunks.append(get(sda, k, shp).ravel())

@@ -432,6 +432,45 @@ def score_network_a_cc(w: Weights, p: dict, x: Tensor, adj: Tensor, rank2: Tenso
     return mask_adjs(score, flags)
 
 
+def hodge_baseline_layer(w: Weights, hodge_adj: Tensor, rank2: Tensor, flags: Optional[Tensor],
+                         N: int, d_min: int, d_max: int) -> Tuple[Tensor, Tensor]:
+    """HodgeBaselineLayer.forward (hodge_layers.py:385-416) over BaselineBlock.forward (hodge_layers.py:247-270)."""
+    cin = hodge_adj.shape[1]
+    r_list, h_list = [], []
+    for c in range(cin):
+        h = torch.tanh(mlp(_sub(w, f"layers.{c}.mlp_layer."), hodge_adj[:, c], F.elu))   # row-wise E -> hidden -> E
+        r_list.append(torch.bmm(h, rank2).unsqueeze(-1))
+        h_list.append(((h + h.transpose(-1, -2)) / 2).unsqueeze(-1))
+    h_out = mask_hodge_adjs(mlp(_sub(w, "mlp_hodge."), torch.cat(h_list, dim=-1), F.elu).permute(0, 3, 1, 2), flags)
+    h_out = torch.tanh(h_out)
+    h_out = h_out + h_out.transpose(-1, -2)
+    r_out = mlp(_sub(w, "mlp_rank2."), torch.cat(r_list, dim=-1), F.elu).squeeze(-1)
+    return h_out, mask_rank2(r_out, N, d_min, d_max, flags)
+
+
+def score_network_a_base_cc(w: Weights, p: dict, x: Tensor, adj: Tensor, rank2: Tensor, flags: Optional[Tensor]) -> Tensor:
+    """ScoreNetwork_A_Base_CC.py:266-323."""
+    N, d_min, d_max = p["max_node_num"], p["d_min"], p["d_max"]
+    adjc = pow_tensor(adj, p["c_init"])
+    hodge_adjc = adj_to_hodgedual(adjc)
+    adj_list = [adjc]
+    _x = x.clone()
+    for k in range(p["num_layers"]):
+        _x, adjc = attention_layer(_sub(w, f"layers.{k}."), _x, adjc, flags, p.get("num_heads", 4), p.get("conv", "GCN"))
+        adj_list.append(adjc)
+    hodge_list = [hodge_adjc]
+    _r = rank2.clone()
+    for k in range(p["num_layers_h"]):
+        hodge_adjc, _r = hodge_baseline_layer(_sub(w, f"layers_hodge.{k}."), hodge_adjc, _r, flags, N, d_min, d_max)
+        hodge_list.append(hodge_adjc)
+    adjs = torch.cat(adj_list, dim=1).permute(0, 2, 3, 1)
+    hodge = hodgedual_to_adj(torch.cat(hodge_list, dim=1)).permute(0, 2, 3, 1)
+    out = torch.cat([adjs, hodge], dim=-1)
+    score = mlp(_sub(w, "final."), out, F.elu).view(*adjs.shape[:-1])
+    score = score * _nodiag_mask(N).unsqueeze(0)
+    return mask_adjs(score, flags)
+
+
 def score_network_f(w: Weights, p: dict, x: Tensor, adj: Tensor, rank2: Tensor, flags: Optional[Tensor]) -> Tensor:
     """ScoreNetwork_F.py:175-217 (x, adj ignored); HodgeNetworkLayer hodge_layers.py:86-92."""
     N, d_min, d_max = p["max_node_num"], p["d_min"], p["d_max"]
@@ -459,6 +498,8 @@ def run_network(params: dict, w: Weights, x: Tensor, adj: Tensor, rank2: Optiona
         return score_network_a(w, params, x, adj, flags)
     if t == "ScoreNetworkA_CC":
         return score_network_a_cc(w, params, x, adj, rank2, flags)
+    if t == "ScoreNetworkA_Base_CC":
+        return score_network_a_base_cc(w, params, x, adj, rank2, flags)
     if t == "ScoreNetworkF":
         return score_network_f(w, params, x, adj, rank2, flags)
     raise ValueError(f"Model Name <{t}> is unknown.")

@@ -17,13 +17,14 @@ def lib():
     return emu_library()
 
 
-@pytest.mark.parametrize("name", ["ccsd_qm9_CC", "gdss_community_small"])
+@pytest.mark.parametrize("name", ["ccsd_qm9_CC", "gdss_community_small", "ccsd_qm9_Base_CC"])
 def test_forward_vs_reference_golden(lib, name):
     pc.case_forward_vs_reference_golden(name, lib, DEV)
 
 
-def test_forward_community_small_cc(lib):
-    pc.case_forward_vs_reference_golden("ccsd_community_small_CC", lib, DEV)
+@pytest.mark.parametrize("name", ["ccsd_community_small_CC", "ccsd_community_small_Base_CC"])
+def test_forward_community_small_cc(lib, name):
+    pc.case_forward_vs_reference_golden(name, lib, DEV)
 
 
 @pytest.mark.parametrize("name", ["ccsd_enzymes_small_CC", "gdss_zinc250k"])
@@ -44,6 +45,7 @@ def test_kat_small_general_paths(lib):
 @pytest.mark.parametrize("gname,ckpt,case", [
     ("ccsd_qm9_CC", "ccsd_qm9_CC", "k10"),
     ("ccsd_qm9_CC", "ccsd_qm9_CC", "n1000_first3"),
+    ("ccsd_qm9_Base_CC", "ccsd_qm9_Base_CC", "n1000_first3"),
     ("gdss_community_small", "gdss_community_small", "k10"),
     ("gdss_community_small", "gdss_community_small", "n1000_first3"),
     ("ccsd_qm9_CC_nsteps2_none", "ccsd_qm9_CC", "k6"),

@@ -20,7 +20,8 @@ def lib():
 
 
 @pytest.mark.parametrize("name", ["ccsd_qm9_CC", "ccsd_community_small_CC", "gdss_community_small",
-                                  "ccsd_enzymes_small_CC", "gdss_zinc250k"])
+                                  "ccsd_enzymes_small_CC", "gdss_zinc250k", "ccsd_qm9_Base_CC",
+                                  "ccsd_community_small_Base_CC"])
 def test_forward_vs_reference_golden(lib, name):
     pc.case_forward_vs_reference_golden(name, lib, DEV)
 
@@ -37,6 +38,7 @@ def test_kat_small_general_paths(lib):
     ("ccsd_qm9_CC", "ccsd_qm9_CC", "k10"),
     ("ccsd_qm9_CC", "ccsd_qm9_CC", "k50"),
     ("ccsd_qm9_CC", "ccsd_qm9_CC", "n1000_first3"),
+    ("ccsd_qm9_Base_CC", "ccsd_qm9_Base_CC", "n1000_first3"),
     ("ccsd_community_small_CC", "ccsd_community_small_CC", "k5"),
     ("ccsd_community_small_CC", "ccsd_community_small_CC", "n1000_first2"),
     ("gdss_community_small", "gdss_community_small", "k10"),

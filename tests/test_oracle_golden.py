@@ -24,7 +24,7 @@ def _close(out, ref, err_msg=""):
     np.testing.assert_allclose(out, ref, rtol=2e-5, atol=2e-5, err_msg=err_msg)
 
 
-CC = ["ccsd_qm9_CC", "ccsd_community_small_CC", "ccsd_enzymes_small_CC"]
+CC = ["ccsd_qm9_CC", "ccsd_community_small_CC", "ccsd_enzymes_small_CC", "ccsd_qm9_Base_CC", "ccsd_community_small_Base_CC"]
 GRAPH = ["gdss_community_small", "gdss_zinc250k"]
 
 
@@ -151,6 +151,7 @@ G5 = [
     ("ccsd_community_small_CC", "ccsd_community_small_CC", ["k5", "n1000_first2"]),
     ("gdss_community_small", "gdss_community_small", ["k10", "n1000_first3"]),
     ("gdss_zinc250k", "gdss_zinc250k", ["k5"]),
+    ("ccsd_qm9_Base_CC", "ccsd_qm9_Base_CC", ["k10", "n1000_first3"]),
     ("ccsd_qm9_CC_nsteps2_none", "ccsd_qm9_CC", ["k6"]),
     ("ccsd_qm9_CC_langevin2", "ccsd_qm9_CC", ["k4"]),
     # S4_solver (solver.py:1179-1563)

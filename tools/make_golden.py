@@ -46,6 +46,9 @@ CHECKPOINTS = {
     "ccsd_enzymes_small_CC": ("checkpoints/ENZYMES_small_CC/ccsd_enzymes_small_CC.pth", True),
     "gdss_community_small": ("checkpoints/community_small/gdss_community_small.pth", False),
     "gdss_zinc250k": ("checkpoints/ZINC250k/gdss_zinc250k.pth", False),
+    # ScoreNetworkA_Base_CC (HodgeBaselineLayer) ablation checkpoints
+    "ccsd_qm9_Base_CC": ("checkpoints/QM9/ccsd_qm9_Base_CC.pth", True),
+    "ccsd_community_small_Base_CC": ("checkpoints/community_small_CC/ccsd_community_small_Base_CC.pth", True),
 }
 
 
@@ -374,6 +377,13 @@ def main():
         g5_pc_runs("s4_ccsd_qm9_CC", cks["ccsd_qm9_CC"], True, 4, [9, 8, 7, 5], s4, {"k6": (6, None)}, seed=7)
         g5_pc_runs("s4_gdss_community_small", cks["gdss_community_small"], False, 4, [20, 18, 14, 12], s4,
                    {"k5": (5, None)}, seed=9)
+    if not only or "base" in only:
+        # ScoreNetworkA_Base_CC (ScoreNetwork_A_Base_CC.py, hodge_layers.py:202-416): forwards and short sampler runs
+        g1_network_forwards("ccsd_qm9_Base_CC", cks["ccsd_qm9_Base_CC"], True, 4, [9, 8, 7, 5])
+        g1_network_forwards("ccsd_community_small_Base_CC", cks["ccsd_community_small_Base_CC"], True, 2, [20, 14])
+        g5_pc_runs("ccsd_qm9_Base_CC", cks["ccsd_qm9_Base_CC"], True, 4, [9, 8, 7, 5],
+                   dict(predictor="Reverse", corrector="Langevin", snr=0.2, scale_eps=0.7, n_steps=1),
+                   {"k10": (10, None), "n1000_first3": (None, 3)}, seed=42)
     if not only or "refkat" in only:
         reference_kat_status()
 
