@@ -13,7 +13,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(HERE, "libccsd_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_WEIGHTS, ERR_RUNTIME, ERR_WORKSPACE = range(6)
 SDE_VP, SDE_VE, SDE_SUBVP = 0, 1, 2
 PRED_EULER, PRED_REVERSE, PRED_S4 = 0, 1, 2
@@ -43,6 +43,7 @@ class Config(C.Structure):
             "f_use_hodge_mask",
             "predictor", "corrector", "n_corr_steps", "probability_flow", "denoise")]
         + [("snr", C.c_float), ("scale_eps", C.c_float), ("diff_steps", C.c_int32), ("batch_hint", C.c_int32)]
+        + [(n, C.c_int32) for n in ("x_gmh", "x_num_linears", "x_c_init", "x_c_hid", "x_c_final", "x_adim", "x_num_heads")]
     )
 
 

@@ -12,6 +12,13 @@
 static thread_local std::string g_last_error;
 static int set_err(int st, const std::string& m) { g_last_error = m; return st; }
 
+// the k_xa instantiation a plan launches (for hipFuncSetAttribute)
+static inline const void* xa_kernel(const PlanD& p) {
+    const int variant = p.hb_L ? XA_HB : p.x_gmh ? XA_GMH : XA_PLAIN;
+    if (p.chan_global) return variant == XA_HB ? (const void*)k_xa<true, XA_HB> : variant == XA_GMH ? (const void*)k_xa<true, XA_GMH> : (const void*)k_xa<true, XA_PLAIN>;
+    return variant == XA_HB ? (const void*)k_xa<false, XA_HB> : variant == XA_GMH ? (const void*)k_xa<false, XA_GMH> : (const void*)k_xa<false, XA_PLAIN>;
+}
+
 // widest layer of ScoreNetworkF's per-element MLPs
 static inline int fnet_width(const PlanD& p) {
     int fw = p.f_fdim > p.f_cnum ? p.f_fdim : p.f_cnum;
@@ -201,6 +208,7 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
         std::vector<float> packed(pl->npacked + 4, 0.f);
         ccsd_pack_mlp(pl->h.x_fin, weights, packed.data());
         for (int l = 0; l < pl->h.a_L; ++l) ccsd_pack_mlp(pl->h.al[l].mlp, weights, packed.data());
+        if (pl->h.x_gmh) for (int l = 0; l < pl->h.x_depth; ++l) ccsd_pack_mlp(pl->h.gl[l].mlp, weights, packed.data());
         ccsd_pack_mlp(pl->h.a_fin, weights, packed.data());
         for (int l = 0; l < pl->h.h_L; ++l) {   // Wcat^T of the hodge projections for k_r2
             const HodgeLayerD& h = pl->h.hl[l];
@@ -237,9 +245,7 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     }
 #ifndef CCSD_EMU
     if ((size_t)pl->h.xa_lds_floats * 4 > 64 * 1024)
-        PC(rt_set_max_dyn_smem(pl->h.hb_L ? (pl->h.chan_global ? (const void*)k_xa<true, true> : (const void*)k_xa<false, true>)
-                                          : (pl->h.chan_global ? (const void*)k_xa<true, false> : (const void*)k_xa<false, false>),
-                               (size_t)pl->h.xa_lds_floats * 4));
+        PC(rt_set_max_dyn_smem(xa_kernel(pl->h), (size_t)pl->h.xa_lds_floats * 4));
     if (pl->fused_r2 && pl->r2_lds > 64 * 1024) {
         const int MT = (E + 15) / 16;
         const bool aff = pl->h.f_affine != 0, gen1 = pl->h.h_L > 1 && pl->h.hl[0].mval.n > 1;
@@ -280,7 +286,7 @@ static Workspace carve_ws(const ccsd_plan* pl, int B, void* base) {
     w.ntiles = p.is_cc ? ((p.K + T_BN - 1) / T_BN) * ((p.E + T_BM - 1) / T_BM) : 0;
     w.part = (float*)take((size_t)B * (w.ntiles ? w.ntiles : 1) * 2 * 4);
     w.sums = (float*)take(64);
-    w.chan = (float*)take(p.chan_global ? (size_t)B * p.a_fdim * p.N * p.N * 4 : 0);
+    w.chan = (float*)take(p.chan_global ? (size_t)B * p.chan_rows * p.N * p.N * 4 : 0);
     w.bytes = o;
     return w;
 }
@@ -374,10 +380,18 @@ static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Work
     xa.wp = pl->wp; xa.hpairs = pl->hpairs;
     const dim3 xblk(CCSD_NTHREADS == 1 ? 1 : xa_threads);
     const size_t xlds = (size_t)pl->h.xa_lds_floats * 4;
-#define XA_GO(G_, HB_, XA_, BLK_, LDS_, STR_) CCSD_LAUNCH((k_xa<G_, HB_>), dim3(B), BLK_, LDS_, STR_, (const PlanD*)pl->d, (const float*)pl->w, \
-                                                          (const unsigned char*)pl->edges, XA_, na)
-    if (pl->h.hb_L) { if (pl->h.chan_global) XA_GO(true, true, xa, xblk, xlds, stream); else XA_GO(false, true, xa, xblk, xlds, stream); }
-    else { if (pl->h.chan_global) XA_GO(true, false, xa, xblk, xlds, stream); else XA_GO(false, false, xa, xblk, xlds, stream); }
+#define XA_GO(G_, V_, XA_, BLK_, LDS_, STR_) CCSD_LAUNCH((k_xa<G_, V_>), dim3(B), BLK_, LDS_, STR_, (const PlanD*)pl->d, (const float*)pl->w, \
+                                                         (const unsigned char*)pl->edges, XA_, na)
+    const int variant = pl->h.hb_L ? XA_HB : pl->h.x_gmh ? XA_GMH : XA_PLAIN;
+    if (pl->h.chan_global) {
+        if (variant == XA_HB) XA_GO(true, XA_HB, xa, xblk, xlds, stream);
+        else if (variant == XA_GMH) XA_GO(true, XA_GMH, xa, xblk, xlds, stream);
+        else XA_GO(true, XA_PLAIN, xa, xblk, xlds, stream);
+    } else {
+        if (variant == XA_HB) XA_GO(false, XA_HB, xa, xblk, xlds, stream);
+        else if (variant == XA_GMH) XA_GO(false, XA_GMH, xa, xblk, xlds, stream);
+        else XA_GO(false, XA_PLAIN, xa, xblk, xlds, stream);
+    }
 #undef XA_GO
     prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
     LAUNCH_CHECK();

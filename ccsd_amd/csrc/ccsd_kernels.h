@@ -1712,6 +1712,9 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
 // ---------------------------------------------------------------------------------------------
 // k_xa: ScoreNetworkX + ScoreNetworkA / ScoreNetworkA_CC for one graph per workgroup.
 // ---------------------------------------------------------------------------------------------
+#define XA_PLAIN 0
+#define XA_HB 1
+#define XA_GMH 2
 struct XaArgs {
     // inputs: the X-network and the A-network may see different (x, adj) when the Langevin
     // corrector runs more than one inner step (solver.py:759-784)
@@ -1769,13 +1772,14 @@ CCSD_DEV void gcn_dinv(const float* a, float* dinv, int nc, int N) {
 // (zinc250k, N = 38: 266 KB) and lives in a per-graph slab of the workspace instead; a workgroup's waves share one
 // CU and its L1, so __syncthreads() orders those global accesses exactly like the LDS ones.
 // Weights are read in place from L2.
-// HB: the plan holds HodgeBaselineLayers (ScoreNetworkA_Base_CC); a separate instantiation keeps that branch out of the
-// register allocation of the headline variants.
-template <bool GCH, bool HB>
+// VAR: XA_PLAIN; XA_HB: the plan holds HodgeBaselineLayers (ScoreNetworkA_Base_CC); XA_GMH: the X-network is
+// ScoreNetworkX_GMH.  Separate instantiations keep those branches out of the register allocation of the headline variant.
+template <bool GCH, int VAR>
 __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict__ plan, const float* __restrict__ w,
                                             const unsigned char* __restrict__ edges, XaArgs xa, NoiseArgs na) {
     CCSD_DYN_SMEM(sm);
     const PlanD& p = *plan;
+    constexpr bool HB = VAR == XA_HB, GMH = VAR == XA_GMH;
     const int N = p.N, F = p.F, NN = N * N, E = p.E, ldn = p.ldn;
     const int b = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
     float* s_flags = sm + p.o_flags;
@@ -1807,10 +1811,55 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
         for (int i = tid; i < NN; i += nth) s_adj[i] = xa.adjX[(size_t)b * NN + i];
         if (xa.cf.on) { __syncthreads(); corr_apply_xa(xa.cf, na, b, N, F, s_x, s_adj, s_flags); }
         __syncthreads();
+        const int H = p.x_nhid;
+        if (GMH) {
+            float* s_chan = GCH ? xa.chan_ws + (size_t)b * p.chan_rows * NN : sm + p.o_chan;
+            // unordered pair e -> (i, j), i < j: the edge table, copied to LDS once (the global copy costs an L2 round trip
+            // at the head of every per-pair phase)
+            int* s_edge = reinterpret_cast<int*>(sm + p.o_edge);
+            for (int e = tid; e < E; e += nth) s_edge[e] = ((int)edges[2 * e] << 8) | (int)edges[2 * e + 1];
+            auto edge_i = [&](int e) { return s_edge[e] >> 8; };
+            auto edge_j = [&](int e) { return s_edge[e] & 255; };
+            auto pair_off = [&](int e) { const int v = s_edge[e]; return (v >> 8) * N + (v & 255); };
+            float* s_att = sm + p.o_att;
+            float* s_xcur = sm + p.o_xcur;
+            float* s_xnext = sm + p.o_xnext;
+            float* s_mch = sm + p.o_vcat;
+            // ScoreNetworkX_GMH.forward_graph (ScoreNetwork_X.py:290-318): x_list = [x, tanh(AttentionLayer_k(...))...]
+            for (int t = tid; t < N * F; t += nth) { int i, f; dF.divmod(t, i, f); s_xcat[f * ldn + i] = s_x[t]; s_xcur[f * ldn + i] = s_x[t]; }
+            for (int i = tid; i < NN; i += nth) s_chan[i] = s_adj[i];
+            __syncthreads();
+            for (int c = 1; c < p.g_cinit; ++c) {                  // pow_tensor (graph_utils.py:285-292)
+                for (int t = tid; t < NN; t += nth) {
+                    int i, j;
+                    dN.divmod(t, i, j);
+                    float acc = 0.f;
+                    for (int k = 0; k < N; ++k) acc = fmaf(s_chan[(c - 1) * NN + i * N + k], s_adj[k * N + j], acc);
+                    s_chan[c * NN + t] = acc;
+                }
+                __syncthreads();
+            }
+            auto gmh_tap = [&](int l) {
+                for (int t = tid; t < N * H; t += nth) {
+                    int o, i;
+                    dN.divmod(t, o, i);
+                    const float v = tanh_f(s_xcur[o * ldn + i]);   // x = self.activation(x): feeds the next layer and x_list
+                    s_xcur[o * ldn + i] = v;
+                    s_xcat[(F + l * H + o) * ldn + i] = v;
+                }
+                __syncthreads();
+            };
+#define ATTN_LAYERS p.gl
+#define ATTN_NL p.x_depth
+#define ATTN_TAP(l) gmh_tap(l)
+#include "ccsd_attn_stack.inc"
+#undef ATTN_LAYERS
+#undef ATTN_NL
+#undef ATTN_TAP
+        } else {
         gcn_dinv(s_adj, s_dinv, 1, N);
         for (int t = tid; t < N * F; t += nth) { int i, f; dF.divmod(t, i, f); s_xcat[f * ldn + i] = s_x[t]; }
         __syncthreads();
-        const int H = p.x_nhid;
         for (int l = 0; l < p.x_depth; ++l) {
             const int fin = l ? H : F;
             const float* src = s_xcat + (l ? (F + (l - 1) * H) : 0) * ldn;
@@ -1823,6 +1872,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                            [&](int k, int col) { return W[k * H + col]; }, [&](int col) { return B[col]; },
                            [&](int i, int col, float v) { dst[col * ldn + i] = tanh_f(v); });
             __syncthreads();
+        }
         }
         const MlpD& m = p.x_fin;
         if (m.chain) {
@@ -1865,7 +1915,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
     stamp(xa.dbg, 1);
     // ================= ScoreNetworkA / ScoreNetworkA_CC =================
     if (xa.do_a) {
-        float* s_chan = GCH ? xa.chan_ws + (size_t)b * p.a_fdim * NN : sm + p.o_chan;
+        float* s_chan = GCH ? xa.chan_ws + (size_t)b * p.chan_rows * NN : sm + p.o_chan;
         // unordered pair e -> (i, j), i < j: the edge table, copied to LDS once (the global copy costs an L2 round trip
         // at the head of every per-pair phase)
         int* s_edge = reinterpret_cast<int*>(sm + p.o_edge);
@@ -1912,143 +1962,13 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
             }
             __syncthreads();
         }
-        // ---- AttentionLayer stack (attention.py:270-304); channels are processed `cg` at a time
-        for (int l = 0; l < p.a_L; ++l) {
-            if (l < 3) stamp(xa.dbg, 2 + 3 * l);
-            const AttnLayerD& L = p.al[l];
-            const int cols = 2 * L.adim + L.fout;
-            const FastDiv dcols(cols), dNcols(N * cols);
-            const float inv_scale = (float)sqrt((double)L.fout);  // attention.py:121: / math.sqrt(out_dim)
-            const float* wl = w;
-            // multi_channel MLP, first Linear: its input is cat_c V_c, accumulated group by group
-            for (int t = tid; t < L.mc.hid * N; t += nth) { int hh, i; dN.divmod(t, hh, i); s_mch[hh * ldn + i] = wl[L.mc.b[0] + hh]; }
-            const float rscale = 1.0f / inv_scale, ratt = 0.5f / (float)L.nchunk;
-            for (int c0 = 0; c0 < L.cin; c0 += p.cg) {
-                const int gc = (L.cin - c0) < p.cg ? (L.cin - c0) : p.cg;
-                float* s_qkv = s_R;                       // [channel of the group][node][Q | K | V]
-                const float* ac = s_chan + (L.ci0 + c0) * NN;
-                gcn_dinv(ac, s_dinv, gc, N);
-                __syncthreads();
-                // Q, K, V = DenseGCNConv(x, A_c) (attention.py:103-105) for every channel of the group: (channel, 16-column
-                // tile) tasks over the waves, both products of a task on MFMA (gcn_tile)
-                const int nct = (cols + 15) >> 4;
-                for (int task = wave_id; task < gc * nct; task += n_waves) {
-                    const int c = task / nct, ct = task % nct;
-                    const float* wb = wl + L.attn_base + (c0 + c) * L.attn_stride;
-                    float* qo = s_qkv + c * N * cols;
-                    const int ad = L.adim, fo = L.fout, fi = L.fin;
-                    gcn_tile_n(s_xcur, ldn, fi, N, ac + c * NN, s_dinv + c * N, 16 * ct, cols,
-                               [&](int k, int col) {
-                                   const int part = col < ad ? 0 : col < 2 * ad ? 1 : 2;
-                                   const int o = col - part * ad, ow = part == 2 ? fo : ad;
-                                   return wb[part * (fi * ad + ad) + k * ow + o];
-                               },
-                               [&](int col) {
-                                   const int part = col < ad ? 0 : col < 2 * ad ? 1 : 2;
-                                   const int o = col - part * ad;
-                                   return wb[part * (fi * ad + ad) + fi * (part == 2 ? fo : ad) + o];
-                               },
-                               [&](int i, int col, float v) { qo[i * cols + col] = v; });
-                }
-                __syncthreads();
-                // head chunks tanh(Q_h K_h^T / sqrt(out_dim)), mean over chunks, symmetrised (attention.py:111-130): one
-                // thread per (channel, unordered pair); the diagonal never reaches an output (see the edge MLP below)
-                for (int t = tid; t < gc * E; t += nth) {
-                    int c, e;
-                    dE.divmod(t, c, e);
-                    const int i = edge_i(e), j = edge_j(e);
-                    const float* qi = s_qkv + c * N * cols + i * cols;
-                    const float* qj = s_qkv + c * N * cols + j * cols;
-                    float s1 = 0.f, s2 = 0.f;
-                    for (int h = 0; h < L.nchunk; ++h) {
-                        float d1 = 0.f, d2 = 0.f;
-                        for (int u = 0; u < L.dsplit; ++u) {
-                            const int oq = h * L.dsplit + u, ok = L.adim + oq;
-                            d1 = fmaf(qi[oq], qj[ok], d1);
-                            d2 = fmaf(qj[oq], qi[ok], d2);
-                        }
-                        s1 += tanh_f(d1 * rscale);
-                        s2 += tanh_f(d2 * rscale);
-                    }
-                    const float av = (s1 + s2) * ratt;
-                    s_att[(c0 + c) * NN + i * N + j] = av;
-                    s_att[(c0 + c) * NN + j * N + i] = av;
-                }
-                for (int t = tid; t < L.mc.hid * N; t += nth) {  // += W0[:, blocks of this group] . V_c
-                    int hh, i;
-                    dN.divmod(t, hh, i);
-                    float acc = s_mch[hh * ldn + i];
-                    for (int c = 0; c < gc; ++c) {
-                        const float* w0 = wl + L.mc.w[0] + hh * L.mc.in + (c0 + c) * L.fout;
-                        const float* v = s_qkv + c * N * cols + i * cols + 2 * L.adim;
-#pragma unroll 4
-                        for (int o = 0; o < L.fout; ++o) acc = fmaf(v[o], w0[o], acc);
-                    }
-                    if (c0 + gc >= L.cin) acc = elu1(acc);   // last group: ELU of the multi_channel hidden layer
-                    s_mch[hh * ldn + i] = acc;
-                }
-                __syncthreads();
-            }
-            // node update: tanh(mask_x(multi_channel(cat V_c)))  (attention.py:292-293); the first Linear of the
-            // edge MLP (input [attention_c | adj_c] per (i,j), attention.py:295-300) shares the barrier interval
-            if (l < 3) stamp(xa.dbg, 3 + 3 * l);
-            float* chan_out = s_chan + L.co0 * NN;
-            const float* adj_in = s_chan + L.ci0 * NN;
-            const int pc = p.pchp, ldpp = p.ldpp;
-            float* hb0 = s_R;
-            float* hb1 = s_R + p.pw_pair * ldpp;
-            if (L.mlp.chain) {
-                // whole edge MLP per 16-pair tile in registers; the node MLP's second Linear shares the interval
-                // Every channel is a symmetric matrix and the diagonal never reaches an output (DenseGCNConv overwrites it,
-                // the final MLP masks it, the hodge branch takes triu(1)): evaluate the MLP on the E unordered pairs only and
-                // write  (_adj + _adj^T) * mask  (attention.py:301-302) to both halves from the epilogue.
-                mlp_chain<1, 1, 1>(L.mlp, wp, s_att, NN, adj_in, L.cin, E, pair_off,
-                                   [&](int e, int f, float v) {
-                                       const int i = edge_i(e), j = edge_j(e);
-                                       const float sv = (v + v) * s_flags[i] * s_flags[j];
-                                       chan_out[f * NN + i * N + j] = sv;
-                                       chan_out[f * NN + j * N + i] = sv;
-                                   });
-                block_linear<0>(s_xnext, ldn, s_mch, ldn, s_mch, L.mc.hid, wl + L.mc.w[1], wl + L.mc.b[1], L.mc.hid, L.mc.out, N);
-                __syncthreads();
-            } else
-            for (int p0 = 0; p0 < NN; p0 += pc) {
-                const int rows = (NN - p0) < pc ? (NN - p0) : pc;
-                const float* cur = s_att + p0; const float* cur2 = adj_in + p0; int ldc = NN, ksp = L.cin;
-                float* bufs[2] = {hb0, hb1};
-                for (int i = 0; i < L.mlp.n; ++i) {
-                    const bool last = i == L.mlp.n - 1;
-                    float* y = last ? chan_out + p0 : bufs[i & 1];
-                    const int ldy = last ? NN : ldpp;
-                    if (!last) block_linear<1>(y, ldy, cur, ldc, cur2, ksp, wl + L.mlp.w[i], wl + L.mlp.b[i], mlp_in(L.mlp, i), mlp_out(L.mlp, i), rows);
-                    else block_linear<0>(y, ldy, cur, ldc, cur2, ksp, wl + L.mlp.w[i], wl + L.mlp.b[i], mlp_in(L.mlp, i), mlp_out(L.mlp, i), rows);
-                    if (p0 == 0 && i == 0)
-                        block_linear<0>(s_xnext, ldn, s_mch, ldn, s_mch, L.mc.hid, wl + L.mc.w[1], wl + L.mc.b[1], L.mc.hid, L.mc.out, N);
-                    __syncthreads();
-                    cur = y; cur2 = y; ldc = ldy; ksp = mlp_out(L.mlp, i);
-                }
-            }
-            if (l < 3) stamp(xa.dbg, 4 + 3 * l);
-            // _adj + _adj^T, then mask_adjs (attention.py:301-302), in place per unordered pair; node tanh/mask
-            if (!L.mlp.chain)
-            for (int t = tid; t < L.cout * NN; t += nth) {
-                int o, ij, i, j;
-                dNN.divmod(t, o, ij);
-                dN.divmod(ij, i, j);
-                if (i > j) continue;
-                float* m = chan_out + o * NN;
-                const float sv = (m[i * N + j] + m[j * N + i]) * s_flags[i] * s_flags[j];
-                m[i * N + j] = sv;
-                m[j * N + i] = sv;
-            }
-            for (int t = tid; t < N * L.fout; t += nth) {
-                int o, i;
-                dN.divmod(t, o, i);
-                s_xnext[o * ldn + i] = tanh_f(s_xnext[o * ldn + i] * s_flags[i]);
-            }
-            __syncthreads();
-            float* t3 = s_xcur; s_xcur = s_xnext; s_xnext = t3;
-        }
+#define ATTN_LAYERS p.al
+#define ATTN_NL p.a_L
+#define ATTN_TAP(l) (void)0
+#include "ccsd_attn_stack.inc"
+#undef ATTN_LAYERS
+#undef ATTN_NL
+#undef ATTN_TAP
 
         stamp(xa.dbg, 12);
         // ---- hodge branch of ScoreNetworkA_CC (ScoreNetwork_A_CC.py:295-316)

@@ -69,9 +69,6 @@ struct PlanD {
     AttnLayerD al[CCSD_MAXL];
     int h_L;
     HodgeLayerD hl[CCSD_MAXHL];
-    int hb_L;                     // ScoreNetworkA_Base_CC: HodgeBaselineLayers (0 otherwise)
-    HodgeBaseD hb[CCSD_MAXHL];
-    int o_hbg, o_hbd, hb_rows;    // k_xa LDS: hidden rows of layer 0 [cin][E][hid]; diagonals of layer 1's blocks [cin][E]; rows per chunk
     MlpD a_fin;
     // ScoreNetworkF
     int f_L, f_cnum, f_hmask, f_fdim, f_affine;
@@ -90,6 +87,14 @@ struct PlanD {
     int o_edge;                 // LDS copy of the edge table (E ints)
     int x_lds_floats;           // LDS of an X-network-only launch (the ScoreNetworkX phase's regions)
     int chan_global;            // 1: the channel stack [a_fdim][N*N] lives in the HBM workspace (large graphs), not in LDS
+    // ---- variants off the headline path, kept behind the fields every launch reads (scalar-cache footprint)
+    int chan_rows;               // rows of the channel stack: max(a_fdim, g_nch)
+    int hb_L;                     // ScoreNetworkA_Base_CC: HodgeBaselineLayers (0 otherwise)
+    HodgeBaseD hb[CCSD_MAXHL];
+    int o_hbg, o_hbd, hb_rows;    // k_xa LDS: hidden rows of layer 0 [cin][E][hid]; diagonals of layer 1's blocks [cin][E]; rows per chunk
+    // ScoreNetworkX_GMH (x_gmh = 1): x_depth AttentionLayers gl[] on g_cinit adjacency powers, g_nch channels in all
+    int x_gmh, g_cinit, g_nch;
+    AttnLayerD gl[CCSD_MAXL];
 };
 
 #ifndef CCSD_DEVICE_ONLY
@@ -191,6 +196,40 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     // ---- ScoreNetworkX
     if (c->x_depth < 1 || c->x_depth > CCSD_MAXL) { pb.fail(CCSD_ERR_UNSUPPORTED, "x_depth out of range"); return 0; }
     p->x_depth = c->x_depth; p->x_nhid = c->x_nhid; p->x_fdim = F + c->x_depth * c->x_nhid;
+    // one AttentionLayer (attention.py:203-304) of a stack: dims, blob ranges, chained edge MLP
+    auto attn_layer = [&](AttnLayerD& a, bool first, bool last, int c_init, int c_hid, int c_final, int nhid, int adim,
+                          int heads, int num_linears, int& ch) -> bool {
+        a.cin = first ? c_init : c_hid;
+        a.cout = last ? c_final : c_hid;
+        a.fin = first ? F : nhid;
+        a.adim = first ? nhid : adim;
+        a.fout = nhid;
+        a.dsplit = a.adim / heads;
+        if (a.dsplit < 1 || a.adim % a.dsplit) { pb.fail(CCSD_ERR_INVALID, "attn_dim not divisible into head chunks"); return false; }
+        a.nchunk = a.adim / a.dsplit;
+        a.ci0 = ch - a.cin; a.co0 = ch; ch += a.cout;
+        a.attn_stride = 2 * (a.fin * a.adim + a.adim) + a.fin * a.fout + a.fout;
+        a.attn_base = pb.take((int64_t)a.cin * a.attn_stride);
+        a.w_lo = a.attn_base;
+        const int hid = 2 * (a.cin > a.cout ? a.cin : a.cout);
+        a.mlp = pb.mlp(num_linears, 2 * a.cin, hid, a.cout);
+        pb.chainify(a.mlp, CCSD_CHAIN_EDGE);
+        a.mc = pb.mlp(2, a.cin * a.fout, hid, a.fout);
+        a.w_hi = pb.cur;
+        return true;
+    };
+    p->x_gmh = c->x_gmh ? 1 : 0; p->g_cinit = 0; p->g_nch = 0;
+    if (p->x_gmh) {
+        if (c->x_num_heads < 1 || c->x_c_init < 1) { pb.fail(CCSD_ERR_INVALID, "bad heads/c_init (ScoreNetworkX_GMH)"); return 0; }
+        if (c->a_is_cc_net == 2) { pb.fail(CCSD_ERR_UNSUPPORTED, "ScoreNetworkX_GMH with ScoreNetworkA_Base_CC"); return 0; }
+        p->g_cinit = c->x_c_init;
+        int gch = c->x_c_init;
+        for (int l = 0; l < c->x_depth; ++l)
+            if (!attn_layer(p->gl[l], l == 0, l == c->x_depth - 1 && l != 0, c->x_c_init, c->x_c_hid, c->x_c_final, c->x_nhid,
+                            c->x_adim, c->x_num_heads, c->x_num_linears, gch)) return 0;
+        p->g_nch = gch;
+        p->x_gw[0] = p->gl[0].attn_base;
+    } else
     for (int l = 0; l < c->x_depth; ++l) {
         p->x_gw[l] = pb.take((int64_t)(l ? c->x_nhid : F) * c->x_nhid);
         p->x_gb[l] = pb.take(c->x_nhid);
@@ -205,25 +244,8 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     p->a_L = c->a_num_layers; p->a_cinit = c->a_c_init; p->a_is_cc = c->a_is_cc_net;
     int ch = c->a_c_init;
     for (int l = 0; l < p->a_L; ++l) {
-        AttnLayerD& a = p->al[l];
-        const bool first = (l == 0), last = (l == p->a_L - 1) && !first;
-        a.cin = first ? c->a_c_init : c->a_c_hid;
-        a.cout = last ? c->a_c_final : c->a_c_hid;
-        a.fin = first ? F : c->a_nhid;
-        a.adim = first ? c->a_nhid : c->a_adim;
-        a.fout = c->a_nhid;
-        a.dsplit = a.adim / c->a_num_heads;
-        if (a.dsplit < 1 || a.adim % a.dsplit) { pb.fail(CCSD_ERR_INVALID, "attn_dim not divisible into head chunks"); return 0; }
-        a.nchunk = a.adim / a.dsplit;
-        a.ci0 = ch - a.cin; a.co0 = ch; ch += a.cout;
-        a.attn_stride = 2 * (a.fin * a.adim + a.adim) + a.fin * a.fout + a.fout;
-        a.attn_base = pb.take((int64_t)a.cin * a.attn_stride);
-        a.w_lo = a.attn_base;
-        const int hid = 2 * (a.cin > a.cout ? a.cin : a.cout);
-        a.mlp = pb.mlp(c->a_num_linears, 2 * a.cin, hid, a.cout);
-        pb.chainify(a.mlp, CCSD_CHAIN_EDGE);
-        a.mc = pb.mlp(2, a.cin * a.fout, hid, a.fout);
-        a.w_hi = pb.cur;
+        if (!attn_layer(p->al[l], l == 0, l == p->a_L - 1 && l != 0, c->a_c_init, c->a_c_hid, c->a_c_final, c->a_nhid, c->a_adim,
+                        c->a_num_heads, c->a_num_linears, ch)) return 0;
     }
     p->a_nch_graph = ch;
     int fdim = c->a_c_hid * (p->a_L - 1) + c->a_c_final + c->a_c_init;
@@ -314,14 +336,21 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     p->ldn = round_ld(N);
     int fmaxA = F > c->a_nhid ? F : c->a_nhid;
     int colmax = 0, mchid = 0, cinmax = 0;
-    for (int l = 0; l < p->a_L; ++l) {
-        const AttnLayerD& a = p->al[l];
+    int pw_pair = 1;   // widest hidden activation of the per-layer edge MLPs
+    bool pair_chained_all = true;
+    auto layer_max = [&](const AttnLayerD& a) {
         int cols = 2 * a.adim + a.fout; if (cols > colmax) colmax = cols;
         if (a.mc.hid > mchid) mchid = a.mc.hid;
         if (a.cin > cinmax) cinmax = a.cin;
+        if (a.mlp.n > 1 && a.mlp.hid > pw_pair) pw_pair = a.mlp.hid;
+        pair_chained_all = pair_chained_all && a.mlp.chain != 0;
+    };
+    for (int l = 0; l < p->a_L; ++l) layer_max(p->al[l]);
+    if (p->x_gmh) {
+        for (int l = 0; l < p->x_depth; ++l) layer_max(p->gl[l]);
+        if (c->x_nhid > fmaxA) fmaxA = c->x_nhid;
     }
-    int pw_pair = 1;   // widest hidden activation of the per-layer edge MLPs
-    for (int l = 0; l < p->a_L; ++l) if (p->al[l].mlp.n > 1 && p->al[l].mlp.hid > pw_pair) pw_pair = p->al[l].mlp.hid;
+    p->chan_rows = p->a_fdim > p->g_nch ? p->a_fdim : p->g_nch;
     const int pw_fin = 2 * p->a_fdim;
     p->pw_pair = pw_pair;
     const int NNpad = (NN + 15) / 16 * 16;
@@ -373,9 +402,10 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             p->o_h1 = carve(p->x_fin.chain ? (F > 4 ? F : 4) * p->ldn : 2 * p->x_fdim * p->ldn);
             p->o_h2 = carve(p->x_fin.chain ? 4 : 2 * p->x_fdim * p->ldn);
             const int xphase_end = o;
-            p->x_lds_floats = xphase_end + 64;
-            o = phase0;                                                     // ... aliased by the A-network phase
-            p->o_chan = gch ? 0 : carve(p->a_fdim * NN);
+            p->x_lds_floats = xphase_end + 64;                              // (GMH: the whole layout, set below)
+            // (ScoreNetworkX_GMH runs the attention-stack machinery itself: its regions stay clear of the A-network phase's)
+            if (!p->x_gmh) o = phase0;                                      // ... aliased by the A-network phase
+            p->o_chan = gch ? 0 : carve(p->chan_rows * NN);
             p->o_tmp = o;                                                   // (raw attention scratch: gone, symmetrisation is fused)
             p->o_att = carve(cinmax * NN);                                  // attention of every input channel
             p->o_xcur = carve(fmaxA * p->ldn);
@@ -418,8 +448,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             if (NN > rmin) rmin = NN;                                       // raw output of the chained final MLP
             if (hb_rmin > rmin) rmin = hb_rmin;
             if (o + rmin > budget) continue;
-            bool pair_chained = true;
-            for (int l = 0; l < p->a_L; ++l) pair_chained = pair_chained && p->al[l].mlp.chain != 0;
+            const bool pair_chained = pair_chained_all;
             const bool fin_chained = p->a_fin.chain != 0;
             if (!fin_chained && o + 2 * pw_fin * 16 > budget) continue;
             int pch = 16, pchp = 16;
@@ -433,6 +462,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             if (hb_rmin) { p->hb_rows = (r > 64 ? r : 64) / hb_rmin; if (p->hb_rows > E) p->hb_rows = E; }
             p->o_red = p->o_c0;                                              // block reductions run when R is idle
             p->xa_lds_floats = o;
+            if (p->x_gmh) p->x_lds_floats = o;
             best_total = o;
         }
     }

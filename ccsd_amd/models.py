@@ -140,6 +140,17 @@ class ScoreNetworkX(_ScoreNetwork):
     __call__ = forward
 
 
+class ScoreNetworkX_GMH(ScoreNetworkX):
+    """ScoreNetwork_X.py:156-341: AttentionLayers in place of the GCN layers."""
+    model_type = "ScoreNetworkX_GMH"
+
+    def __init__(self, max_feat_num: int, depth: int, nhid: int, num_linears: int, c_init: int, c_hid: int, c_final: int,
+                 adim: int, num_heads: int = 4, conv: str = "GCN", use_bn: bool = False, is_cc: bool = False):
+        _ScoreNetwork.__init__(self, max_feat_num=max_feat_num, depth=depth, nhid=nhid, num_linears=num_linears, c_init=c_init,
+                               c_hid=c_hid, c_final=c_final, adim=adim, num_heads=num_heads, conv=conv, use_bn=use_bn,
+                               is_cc=is_cc)
+
+
 class ScoreNetworkA(_ScoreNetwork):
     model_type, target = "ScoreNetworkA", _lib.TARGET_ADJ
 
@@ -213,15 +224,13 @@ class ScoreNetworkF(_ScoreNetwork):
                          use_hodge_mask=use_hodge_mask, use_bn=use_bn, is_cc=is_cc)
 
 
-MODEL_TYPES = {c.model_type: c for c in (ScoreNetworkX, ScoreNetworkA, ScoreNetworkA_CC, ScoreNetworkA_Base_CC, ScoreNetworkF)}
+MODEL_TYPES = {c.model_type: c for c in (ScoreNetworkX, ScoreNetworkX_GMH, ScoreNetworkA, ScoreNetworkA_CC, ScoreNetworkA_Base_CC, ScoreNetworkF)}
 
 
 def load_model(params: Dict[str, Any]) -> _ScoreNetwork:
     """loader.load_model (loader.py:83-101)."""
     p = dict(params)
     t = p.pop("model_type", None)
-    if t in ("ScoreNetworkX_GMH",):
-        raise NotImplementedError(f"{t} is not built in this round (SURVEY.md section 8f row 4)")
     if t not in MODEL_TYPES:
         raise ValueError(
             f"Model Name <{t}> is unknown. Please select from [ScoreNetworkX, ScoreNetworkX_GMH, ScoreNetworkA, ScoreNetworkA_CC, ScoreNetworkA_Base_CC, ScoreNetworkF]")

@@ -54,6 +54,28 @@ def attn_layer_dims(p: dict):
     return dims
 
 
+def gmh_layer_dims(p: dict):
+    """(cin, cout, fin, adim, fout) per AttentionLayer of ScoreNetworkX_GMH (ScoreNetwork_X.py:208-252)."""
+    L = p["depth"]
+    dims = []
+    for l in range(L):
+        first, last = l == 0, (l == L - 1 and l != 0)
+        dims.append((p["c_init"] if first else p["c_hid"], p["c_final"] if last else p["c_hid"],
+                     p["max_feat_num"] if first else p["nhid"], p["nhid"] if first else p["adim"], p["nhid"]))
+    return dims
+
+
+def _attn_layer_shapes(l: int, cin: int, cout: int, fin: int, ad: int, fo: int, num_linears: int) -> Shapes:
+    s: Shapes = []
+    for c in range(cin):
+        for g, o in (("q", ad), ("k", ad), ("v", fo)):
+            s += [(f"layers.{l}.attn.{c}.gnn_{g}.weight", (fin, o)), (f"layers.{l}.attn.{c}.gnn_{g}.bias", (o,))]
+    hid = 2 * max(cin, cout)
+    s += _mlp_shapes(f"layers.{l}.mlp.", num_linears, 2 * cin, hid, cout)
+    s += _mlp_shapes(f"layers.{l}.multi_channel.", 2, cin * fo, hid, fo)
+    return s
+
+
 def hodge_layer_dims(p: dict):
     """(cin, cout, adim) per HodgeAdjAttentionLayer (ScoreNetwork_A_CC.py:155-205)."""
     L = p["num_layers_h"]
@@ -95,6 +117,12 @@ def state_dict_shapes(params: dict) -> Shapes:
             s += [(f"layers.{l}.weight", (F if l == 0 else H, H)), (f"layers.{l}.bias", (H,))]
         fdim = F + params["depth"] * H
         s += _mlp_shapes("final.", 3, fdim, 2 * fdim, F)
+    elif t == "ScoreNetworkX_GMH":
+        F, H = params["max_feat_num"], params["nhid"]
+        for l, dims in enumerate(gmh_layer_dims(params)):
+            s += _attn_layer_shapes(l, *dims, params["num_linears"])
+        fdim = F + params["depth"] * H
+        s += _mlp_shapes("final.", 3, fdim, 2 * fdim, F)
     elif t in ("ScoreNetworkA", "ScoreNetworkA_CC", "ScoreNetworkA_Base_CC"):
         for l, (cin, cout, fin, ad, fo) in enumerate(attn_layer_dims(params)):
             for c in range(cin):
@@ -132,8 +160,8 @@ def state_dict_shapes(params: dict) -> Shapes:
         s += _mlp_shapes("final.", params["num_layers_mlp"], fdim, 2 * fdim, 1)
     else:
         raise ValueError(
-            f"Model Name <{t}> is unknown. Please select from [ScoreNetworkX, ScoreNetworkA, ScoreNetworkA_CC, "
-            "ScoreNetworkA_Base_CC, ScoreNetworkF]")
+            f"Model Name <{t}> is unknown. Please select from [ScoreNetworkX, ScoreNetworkX_GMH, ScoreNetworkA, "
+            "ScoreNetworkA_CC, ScoreNetworkA_Base_CC, ScoreNetworkF]")
     return s
 
 
@@ -170,7 +198,7 @@ def make_config(px: dict, pa: dict, pf: Optional[dict], *, predictor="Euler", co
     for p in (px, pa, pf):
         if p is not None:
             _check_supported(p)
-    if px["model_type"] != "ScoreNetworkX":
+    if px["model_type"] not in ("ScoreNetworkX", "ScoreNetworkX_GMH"):
         raise NotImplementedError(f"{px['model_type']} is not supported by the HIP path yet")
     if pa["model_type"] not in ("ScoreNetworkA", "ScoreNetworkA_CC", "ScoreNetworkA_Base_CC"):
         raise NotImplementedError(f"{pa['model_type']} is not supported by the HIP path yet")
@@ -180,6 +208,12 @@ def make_config(px: dict, pa: dict, pf: Optional[dict], *, predictor="Euler", co
     c.N, c.F, c.is_cc = pa["max_node_num"], px["max_feat_num"], int(is_cc)
     c.d_min, c.d_max = (pf["d_min"], pf["d_max"]) if is_cc else (0, 0)
     c.x_depth, c.x_nhid = px["depth"], px["nhid"]
+    if px["model_type"] == "ScoreNetworkX_GMH":
+        if pa["model_type"] == "ScoreNetworkA_Base_CC":
+            raise NotImplementedError("ScoreNetworkX_GMH together with ScoreNetworkA_Base_CC is not supported by the HIP path")
+        c.x_gmh = 1
+        c.x_num_linears, c.x_c_init, c.x_c_hid, c.x_c_final = px["num_linears"], px["c_init"], px["c_hid"], px["c_final"]
+        c.x_adim, c.x_num_heads = px["adim"], px.get("num_heads", 4)
     c.a_num_layers, c.a_num_linears = pa["num_layers"], pa["num_linears"]
     c.a_c_init, c.a_c_hid, c.a_c_final = pa["c_init"], pa["c_hid"], pa["c_final"]
     c.a_nhid, c.a_adim, c.a_num_heads = pa["nhid"], pa["adim"], pa.get("num_heads", 4)
@@ -247,8 +281,25 @@ def pack_weights(px: dict, sdx: Optional[Dict], pa: dict, sda: Optional[Dict], p
         return {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
 
     sdx, sda, sdf = strip(sdx), strip(sda), strip(sdf)
-    for key, shape in state_dict_shapes(px):
-        chunks.append(get(sdx, key, shape).ravel())
+    if px["model_type"] == "ScoreNetworkX_GMH":
+        # AttentionLayers in the A-network's block order (per channel q, k, v; then mlp, multi_channel), then final
+        shapes_x = dict(state_dict_shapes(px))
+        for l, (cin, cout, fin, ad, fo) in enumerate(gmh_layer_dims(px)):
+            for c in range(cin):
+                for g in ("q", "k", "v"):
+                    for wb in ("weight", "bias"):
+                        k = f"layers.{l}.attn.{c}.gnn_{g}.{wb}"
+                        chunks.append(get(sdx, k, shapes_x[k]).ravel())
+            for pre in (f"layers.{l}.mlp.", f"layers.{l}.multi_channel."):
+                for k, shp in shapes_x.items():
+                    if k.startswith(pre):
+                        chunks.append(get(sdx, k, shp).ravel())
+        for k, shp in shapes_x.items():
+            if k.startswith("final."):
+                chunks.append(get(sdx, k, shp).ravel())
+    else:
+        for key, shape in state_dict_shapes(px):
+            chunks.append(get(sdx, key, shape).ravel())
     # A-network: everything in registration order except that the hodge q/k weights are concatenated
     shapes_a = dict(state_dict_shapes(pa))
     for l, (cin, cout, fin, ad, fo) in enumerate(attn_layer_dims(pa)):

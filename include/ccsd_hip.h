@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CCSD_ABI_VERSION 2
+#define CCSD_ABI_VERSION 3
 
 /* status codes; the Python shim re-raises the reference's exception types */
 enum {
@@ -78,7 +78,9 @@ typedef struct {
     int32_t x_depth, x_nhid;
     /* ScoreNetworkA / ScoreNetworkA_CC graph branch (ScoreNetwork_A.py:351-460) */
     int32_t a_num_layers, a_num_linears, a_c_init, a_c_hid, a_c_final, a_nhid, a_adim, a_num_heads;
-    /* ScoreNetworkA_CC hodge branch (ScoreNetwork_A_CC.py:155-205); a_is_cc_net=0 -> ScoreNetworkA */
+    /* ScoreNetworkA_CC hodge branch (ScoreNetwork_A_CC.py:155-205); a_is_cc_net=0 -> ScoreNetworkA;
+     * a_is_cc_net=2 -> ScoreNetworkA_Base_CC (ScoreNetwork_A_Base_CC.py:105-195): HodgeBaselineLayers, h_nhid = nhid_h,
+     * h_adim = hidden_h, h_num_heads unused */
     int32_t a_is_cc_net, h_num_layers, h_num_linears, h_nhid, h_adim, h_c_hid, h_c_final, h_num_heads;
     /* ScoreNetworkF (ScoreNetwork_F.py:24-145) */
     int32_t f_num_layers, f_num_linears, f_nhid, f_c_hid, f_c_final, f_cnum, f_num_layers_mlp, f_use_hodge_mask;
@@ -88,6 +90,8 @@ typedef struct {
     int32_t diff_steps;         /* sde_adj.N == number of rows of step_coef */
     int32_t batch_hint;         /* expected batch per launch (0 = unknown): picks the LDS layout of the graph-network kernel so
                                  * that ceil(batch / #CUs) workgroups are co-resident per CU; any batch stays correct */
+    /* ScoreNetworkX_GMH (ScoreNetwork_X.py:156-341) when x_gmh=1: x_depth AttentionLayers (x_nhid wide) instead of GCN layers */
+    int32_t x_gmh, x_num_linears, x_c_init, x_c_hid, x_c_final, x_adim, x_num_heads;
 } ccsd_config_t;
 
 typedef struct ccsd_plan ccsd_plan_t;

@@ -390,6 +390,19 @@ def score_network_x(w: Weights, x: Tensor, adj: Tensor, flags: Optional[Tensor])
     return mask_x(out, flags)
 
 
+def score_network_x_gmh(w: Weights, p: dict, x: Tensor, adj: Tensor, flags: Optional[Tensor]) -> Tensor:
+    """ScoreNetworkX_GMH.forward_graph (ScoreNetwork_X.py:290-318): AttentionLayers instead of GCN layers."""
+    adjc = pow_tensor(adj, p["c_init"])
+    x_list = [x]
+    for k in range(p["depth"]):
+        x, adjc = attention_layer(_sub(w, f"layers.{k}."), x, adjc, flags, p.get("num_heads", 4), p.get("conv", "GCN"))
+        x = torch.tanh(x)
+        x_list.append(x)
+    xs = torch.cat(x_list, dim=-1)
+    out = mlp(_sub(w, "final."), xs, F.elu).view(adj.shape[0], adj.shape[1], -1)
+    return mask_x(out, flags)
+
+
 def _nodiag_mask(n: int) -> Tensor:
     """default_mask (cc_utils.py:942)."""
     return torch.ones(n, n) - torch.eye(n)
@@ -494,6 +507,8 @@ def run_network(params: dict, w: Weights, x: Tensor, adj: Tensor, rank2: Optiona
     t = params["model_type"]
     if t == "ScoreNetworkX":
         return score_network_x(w, x, adj, flags)
+    if t == "ScoreNetworkX_GMH":
+        return score_network_x_gmh(w, params, x, adj, flags)
     if t == "ScoreNetworkA":
         return score_network_a(w, params, x, adj, flags)
     if t == "ScoreNetworkA_CC":

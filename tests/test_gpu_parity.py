@@ -30,6 +30,11 @@ def test_model_objects(lib):
     pc.case_model_objects_forward(lib, DEV)
 
 
+@pytest.mark.gpu
+def test_kat_gmh(lib):
+    pc.case_kat_gmh(lib, DEV)
+
+
 def test_kat_small_general_paths(lib):
     pc.case_kat_small_general(lib, DEV)
 

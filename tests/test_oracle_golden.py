@@ -146,6 +146,18 @@ def test_kat_small_models_general_path():
         _close(out.numpy(), g[f"{tag}/out"], tag)
 
 
+def test_kat_gmh_models():
+    """ScoreNetworkX_GMH built by the reference's constructor (no shipped checkpoint uses it)."""
+    g = load_golden("kat_gmh_models.npz")
+    meta = json.loads(str(g["meta"]))
+    for tag, params in meta.items():
+        flags, x, adj = (torch.from_numpy(g[f"{tag}/{k}"]) for k in ("flags", "x", "adj"))
+        w = {k[len(tag) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}/w/")}
+        with torch.no_grad():
+            out = O.run_network(params, w, x, adj, None, flags)
+        _close(out.numpy(), g[f"{tag}/out"], tag)
+
+
 G5 = [
     ("ccsd_qm9_CC", "ccsd_qm9_CC", ["k10", "k50", "n1000_first3"]),
     ("ccsd_community_small_CC", "ccsd_community_small_CC", ["k5", "n1000_first2"]),

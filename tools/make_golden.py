@@ -316,6 +316,40 @@ def kat_small_models():
     np.savez_compressed(os.path.join(GOLD, "kat_small_models.npz"), **out)
 
 
+def kat_gmh_models():
+    """ScoreNetworkX_GMH (ScoreNetwork_X.py:156-341) has no shipped checkpoint: randomly initialised networks from the
+    reference's constructor, one small (hyper-parameters of tests/models/test_ScoreNetwork_X.py) and one at the width of
+    GDSS's ZINC250k X-network, with perturbed biases."""
+    from ccsd.src.models.ScoreNetwork_X import ScoreNetworkX_GMH
+
+    out, meta = {}, {}
+    cases = {
+        "small": (dict(max_feat_num=10, depth=2, nhid=4, num_linears=2, c_init=2, c_hid=3, c_final=2, adim=4, num_heads=2,
+                       conv="GCN", use_bn=False, is_cc=False), 5, [5, 4, 3]),
+        "wide": (dict(max_feat_num=9, depth=3, nhid=16, num_linears=3, c_init=2, c_hid=8, c_final=4, adim=16, num_heads=4,
+                      conv="GCN", use_bn=False, is_cc=True), 12, [12, 9, 7, 2]),
+    }
+    torch.manual_seed(4242)
+    for tag, (p, N, counts) in cases.items():
+        m = ScoreNetworkX_GMH(**p)
+        for k, prm in m.named_parameters():
+            if k.endswith("bias"):
+                prm.data.normal_(0, 0.2)
+        m.eval()
+        B = len(counts)
+        flags = make_flags(B, N, counts)
+        x, adj, _ = masked_state(77, B, N, p["max_feat_num"], False, None, None, flags)
+        out[f"{tag}/flags"], out[f"{tag}/x"], out[f"{tag}/adj"] = flags.numpy(), x.numpy(), adj.numpy()
+        with torch.no_grad():
+            for k, v in m.state_dict().items():
+                out[f"{tag}/w/{k}"] = v.numpy()
+            out[f"{tag}/out"] = (m(x, adj, None, flags) if p["is_cc"] else m(x, adj, flags)).numpy()
+        meta[tag] = dict(p, model_type="ScoreNetworkX_GMH")
+    out["meta"] = json.dumps(meta)
+    np.savez_compressed(os.path.join(GOLD, "kat_gmh_models.npz"), **out)
+    print("kat_gmh", {k: v.shape for k, v in out.items() if k.endswith("/out")})
+
+
 def reference_kat_status():
     """Run the reference's own known-answer tests for the path in this container and record the result."""
     files = ["tests/models", "tests/utils/test_graph_utils.py", "tests/utils/test_cc_utils.py",
@@ -377,6 +411,8 @@ def main():
         g5_pc_runs("s4_ccsd_qm9_CC", cks["ccsd_qm9_CC"], True, 4, [9, 8, 7, 5], s4, {"k6": (6, None)}, seed=7)
         g5_pc_runs("s4_gdss_community_small", cks["gdss_community_small"], False, 4, [20, 18, 14, 12], s4,
                    {"k5": (5, None)}, seed=9)
+    if not only or "gmh" in only:
+        kat_gmh_models()
     if not only or "base" in only:
         # ScoreNetworkA_Base_CC (ScoreNetwork_A_Base_CC.py, hodge_layers.py:202-416): forwards and short sampler runs
         g1_network_forwards("ccsd_qm9_Base_CC", cks["ccsd_qm9_Base_CC"], True, 4, [9, 8, 7, 5])
