@@ -43,7 +43,8 @@ class Config(C.Structure):
             "f_use_hodge_mask",
             "predictor", "corrector", "n_corr_steps", "probability_flow", "denoise")]
         + [("snr", C.c_float), ("scale_eps", C.c_float), ("diff_steps", C.c_int32), ("batch_hint", C.c_int32)]
-        + [(n, C.c_int32) for n in ("x_gmh", "x_num_linears", "x_c_init", "x_c_hid", "x_c_final", "x_adim", "x_num_heads")]
+        + [(n, C.c_int32) for n in ("x_gmh", "x_num_linears", "x_c_init", "x_c_hid", "x_c_final", "x_adim", "x_num_heads",
+                                    "a_conv_mlp", "x_conv_mlp")]
     )
 
 

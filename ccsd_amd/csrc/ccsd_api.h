@@ -12,11 +12,20 @@
 static thread_local std::string g_last_error;
 static int set_err(int st, const std::string& m) { g_last_error = m; return st; }
 
-// the k_xa instantiation a plan launches (for hipFuncSetAttribute)
+// the k_xa variant a plan needs, and its instantiation (for hipFuncSetAttribute)
+static inline int xa_variant(const PlanD& p) {
+    bool conv_mlp = false;
+    for (int l = 0; l < p.a_L; ++l) conv_mlp = conv_mlp || p.al[l].conv_mlp;
+    if (p.x_gmh) for (int l = 0; l < p.x_depth; ++l) conv_mlp = conv_mlp || p.gl[l].conv_mlp;
+    if (conv_mlp || (p.hb_L && p.x_gmh)) return XA_GEN;
+    return p.hb_L ? XA_HB : p.x_gmh ? XA_GMH : XA_PLAIN;
+}
 static inline const void* xa_kernel(const PlanD& p) {
-    const int variant = p.hb_L ? XA_HB : p.x_gmh ? XA_GMH : XA_PLAIN;
-    if (p.chan_global) return variant == XA_HB ? (const void*)k_xa<true, XA_HB> : variant == XA_GMH ? (const void*)k_xa<true, XA_GMH> : (const void*)k_xa<true, XA_PLAIN>;
-    return variant == XA_HB ? (const void*)k_xa<false, XA_HB> : variant == XA_GMH ? (const void*)k_xa<false, XA_GMH> : (const void*)k_xa<false, XA_PLAIN>;
+    const int v = xa_variant(p);
+#define XA_FN(G_) (v == XA_HB ? (const void*)k_xa<G_, XA_HB> : v == XA_GMH ? (const void*)k_xa<G_, XA_GMH> : \
+                   v == XA_GEN ? (const void*)k_xa<G_, XA_GEN> : (const void*)k_xa<G_, XA_PLAIN>)
+    return p.chan_global ? XA_FN(true) : XA_FN(false);
+#undef XA_FN
 }
 
 // widest layer of ScoreNetworkF's per-element MLPs
@@ -382,14 +391,16 @@ static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Work
     const size_t xlds = (size_t)pl->h.xa_lds_floats * 4;
 #define XA_GO(G_, V_, XA_, BLK_, LDS_, STR_) CCSD_LAUNCH((k_xa<G_, V_>), dim3(B), BLK_, LDS_, STR_, (const PlanD*)pl->d, (const float*)pl->w, \
                                                          (const unsigned char*)pl->edges, XA_, na)
-    const int variant = pl->h.hb_L ? XA_HB : pl->h.x_gmh ? XA_GMH : XA_PLAIN;
+    const int variant = xa_variant(pl->h);
     if (pl->h.chan_global) {
         if (variant == XA_HB) XA_GO(true, XA_HB, xa, xblk, xlds, stream);
         else if (variant == XA_GMH) XA_GO(true, XA_GMH, xa, xblk, xlds, stream);
+        else if (variant == XA_GEN) XA_GO(true, XA_GEN, xa, xblk, xlds, stream);
         else XA_GO(true, XA_PLAIN, xa, xblk, xlds, stream);
     } else {
         if (variant == XA_HB) XA_GO(false, XA_HB, xa, xblk, xlds, stream);
         else if (variant == XA_GMH) XA_GO(false, XA_GMH, xa, xblk, xlds, stream);
+        else if (variant == XA_GEN) XA_GO(false, XA_GEN, xa, xblk, xlds, stream);
         else XA_GO(false, XA_PLAIN, xa, xblk, xlds, stream);
     }
 #undef XA_GO

@@ -1715,6 +1715,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
 #define XA_PLAIN 0
 #define XA_HB 1
 #define XA_GMH 2
+#define XA_GEN 3          /* everything, selected at run time from the plan: both of the above together, conv = "MLP" */
 struct XaArgs {
     // inputs: the X-network and the A-network may see different (x, adj) when the Langevin
     // corrector runs more than one inner step (solver.py:759-784)
@@ -1773,13 +1774,13 @@ CCSD_DEV void gcn_dinv(const float* a, float* dinv, int nc, int N) {
 // CU and its L1, so __syncthreads() orders those global accesses exactly like the LDS ones.
 // Weights are read in place from L2.
 // VAR: XA_PLAIN; XA_HB: the plan holds HodgeBaselineLayers (ScoreNetworkA_Base_CC); XA_GMH: the X-network is
-// ScoreNetworkX_GMH.  Separate instantiations keep those branches out of the register allocation of the headline variant.
+// ScoreNetworkX_GMH; XA_GEN: both, and conv = "MLP" attention.  Separate instantiations keep those branches out of the register allocation of the headline variant.
 template <bool GCH, int VAR>
 __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict__ plan, const float* __restrict__ w,
                                             const unsigned char* __restrict__ edges, XaArgs xa, NoiseArgs na) {
     CCSD_DYN_SMEM(sm);
     const PlanD& p = *plan;
-    constexpr bool HB = VAR == XA_HB, GMH = VAR == XA_GMH;
+    constexpr bool HB = VAR == XA_HB || VAR == XA_GEN, GMH = VAR == XA_GMH || VAR == XA_GEN, CONVMLP = VAR == XA_GEN;
     const int N = p.N, F = p.F, NN = N * N, E = p.E, ldn = p.ldn;
     const int b = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
     float* s_flags = sm + p.o_flags;
@@ -1812,7 +1813,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
         if (xa.cf.on) { __syncthreads(); corr_apply_xa(xa.cf, na, b, N, F, s_x, s_adj, s_flags); }
         __syncthreads();
         const int H = p.x_nhid;
-        if (GMH) {
+        if (GMH && p.x_gmh) {
             float* s_chan = GCH ? xa.chan_ws + (size_t)b * p.chan_rows * NN : sm + p.o_chan;
             // unordered pair e -> (i, j), i < j: the edge table, copied to LDS once (the global copy costs an L2 round trip
             // at the head of every per-pair phase)
@@ -1972,7 +1973,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
 
         stamp(xa.dbg, 12);
         // ---- hodge branch of ScoreNetworkA_CC (ScoreNetwork_A_CC.py:295-316)
-        if (!HB && p.h_L > 0) {
+        if (VAR != XA_HB && p.h_L > 0) {
             float* s_hd = sm + p.o_hd;          // [hodge channel][E]: diagonals that reach the final MLP
             float* s_hq = sm + p.o_hq;          // [channel][E][2*adim]
             float* s_h1m = s_R;                 // [cout0][E][E] dense output of the first hodge layer

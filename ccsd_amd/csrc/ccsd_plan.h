@@ -38,6 +38,7 @@ struct AttnLayerD {
     int cin, cout, fin, adim, fout, dsplit, nchunk;
     int ci0, co0;             // first input / output channel inside the channel stack
     int attn_base, attn_stride;  // per-channel block: Wq[fin][ad] bq Wk bk Wv[fin][fo] bv
+    int conv_mlp;                // conv="MLP": Q / K blocks are W1[2ad][fin] b1[2ad] W2[ad][2ad] b2[ad] (attention.py:168-178)
     int w_lo, w_hi;              // blob range of this layer's weights (attention blocks, mlp, multi_channel)
     MlpD mlp, mc;
 };
@@ -198,7 +199,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     p->x_depth = c->x_depth; p->x_nhid = c->x_nhid; p->x_fdim = F + c->x_depth * c->x_nhid;
     // one AttentionLayer (attention.py:203-304) of a stack: dims, blob ranges, chained edge MLP
     auto attn_layer = [&](AttnLayerD& a, bool first, bool last, int c_init, int c_hid, int c_final, int nhid, int adim,
-                          int heads, int num_linears, int& ch) -> bool {
+                          int heads, int num_linears, int conv_mlp, int& ch) -> bool {
         a.cin = first ? c_init : c_hid;
         a.cout = last ? c_final : c_hid;
         a.fin = first ? F : nhid;
@@ -208,7 +209,9 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
         if (a.dsplit < 1 || a.adim % a.dsplit) { pb.fail(CCSD_ERR_INVALID, "attn_dim not divisible into head chunks"); return false; }
         a.nchunk = a.adim / a.dsplit;
         a.ci0 = ch - a.cin; a.co0 = ch; ch += a.cout;
-        a.attn_stride = 2 * (a.fin * a.adim + a.adim) + a.fin * a.fout + a.fout;
+        a.conv_mlp = conv_mlp ? 1 : 0;
+        a.attn_stride = (a.conv_mlp ? 2 * (2 * a.adim * a.fin + 2 * a.adim + a.adim * 2 * a.adim + a.adim) : 2 * (a.fin * a.adim + a.adim)) +
+                        a.fin * a.fout + a.fout;
         a.attn_base = pb.take((int64_t)a.cin * a.attn_stride);
         a.w_lo = a.attn_base;
         const int hid = 2 * (a.cin > a.cout ? a.cin : a.cout);
@@ -221,12 +224,11 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     p->x_gmh = c->x_gmh ? 1 : 0; p->g_cinit = 0; p->g_nch = 0;
     if (p->x_gmh) {
         if (c->x_num_heads < 1 || c->x_c_init < 1) { pb.fail(CCSD_ERR_INVALID, "bad heads/c_init (ScoreNetworkX_GMH)"); return 0; }
-        if (c->a_is_cc_net == 2) { pb.fail(CCSD_ERR_UNSUPPORTED, "ScoreNetworkX_GMH with ScoreNetworkA_Base_CC"); return 0; }
         p->g_cinit = c->x_c_init;
         int gch = c->x_c_init;
         for (int l = 0; l < c->x_depth; ++l)
             if (!attn_layer(p->gl[l], l == 0, l == c->x_depth - 1 && l != 0, c->x_c_init, c->x_c_hid, c->x_c_final, c->x_nhid,
-                            c->x_adim, c->x_num_heads, c->x_num_linears, gch)) return 0;
+                            c->x_adim, c->x_num_heads, c->x_num_linears, c->x_conv_mlp, gch)) return 0;
         p->g_nch = gch;
         p->x_gw[0] = p->gl[0].attn_base;
     } else
@@ -245,7 +247,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     int ch = c->a_c_init;
     for (int l = 0; l < p->a_L; ++l) {
         if (!attn_layer(p->al[l], l == 0, l == p->a_L - 1 && l != 0, c->a_c_init, c->a_c_hid, c->a_c_final, c->a_nhid, c->a_adim,
-                        c->a_num_heads, c->a_num_linears, ch)) return 0;
+                        c->a_num_heads, c->a_num_linears, c->a_conv_mlp, ch)) return 0;
     }
     p->a_nch_graph = ch;
     int fdim = c->a_c_hid * (p->a_L - 1) + c->a_c_final + c->a_c_init;

@@ -65,10 +65,13 @@ def gmh_layer_dims(p: dict):
     return dims
 
 
-def _attn_layer_shapes(l: int, cin: int, cout: int, fin: int, ad: int, fo: int, num_linears: int) -> Shapes:
+def _attn_layer_shapes(l: int, cin: int, cout: int, fin: int, ad: int, fo: int, num_linears: int, conv: str = "GCN") -> Shapes:
     s: Shapes = []
     for c in range(cin):
         for g, o in (("q", ad), ("k", ad), ("v", fo)):
+            if conv == "MLP" and g != "v":      # attention.py:168-178: MLP(2, in_dim, 2 * attn_dim, attn_dim, tanh)
+                s += _mlp_shapes(f"layers.{l}.attn.{c}.gnn_{g}.", 2, fin, 2 * ad, ad)
+                continue
             s += [(f"layers.{l}.attn.{c}.gnn_{g}.weight", (fin, o)), (f"layers.{l}.attn.{c}.gnn_{g}.bias", (o,))]
     hid = 2 * max(cin, cout)
     s += _mlp_shapes(f"layers.{l}.mlp.", num_linears, 2 * cin, hid, cout)
@@ -120,17 +123,12 @@ def state_dict_shapes(params: dict) -> Shapes:
     elif t == "ScoreNetworkX_GMH":
         F, H = params["max_feat_num"], params["nhid"]
         for l, dims in enumerate(gmh_layer_dims(params)):
-            s += _attn_layer_shapes(l, *dims, params["num_linears"])
+            s += _attn_layer_shapes(l, *dims, params["num_linears"], params.get("conv", "GCN"))
         fdim = F + params["depth"] * H
         s += _mlp_shapes("final.", 3, fdim, 2 * fdim, F)
     elif t in ("ScoreNetworkA", "ScoreNetworkA_CC", "ScoreNetworkA_Base_CC"):
-        for l, (cin, cout, fin, ad, fo) in enumerate(attn_layer_dims(params)):
-            for c in range(cin):
-                for g, o in (("q", ad), ("k", ad), ("v", fo)):
-                    s += [(f"layers.{l}.attn.{c}.gnn_{g}.weight", (fin, o)), (f"layers.{l}.attn.{c}.gnn_{g}.bias", (o,))]
-            hid = 2 * max(cin, cout)
-            s += _mlp_shapes(f"layers.{l}.mlp.", params["num_linears"], 2 * cin, hid, cout)
-            s += _mlp_shapes(f"layers.{l}.multi_channel.", 2, cin * fo, hid, fo)
+        for l, dims in enumerate(attn_layer_dims(params)):
+            s += _attn_layer_shapes(l, *dims, params["num_linears"], params.get("conv", "GCN"))
         fdim = params["c_hid"] * (params["num_layers"] - 1) + params["c_final"] + params["c_init"]
         if t == "ScoreNetworkA_CC":
             _, K = rank2_dim(params["max_node_num"], params["d_min"], params["d_max"])
@@ -187,7 +185,7 @@ def complete_params(px: Optional[dict], pa: Optional[dict], pf: Optional[dict], 
 def _check_supported(p: dict):
     if p.get("use_bn", False):
         raise NotImplementedError("use_bn=True is not supported by the HIP path yet")
-    if p.get("conv", "GCN") != "GCN":
+    if p.get("conv", "GCN") not in ("GCN", "MLP"):
         raise NotImplementedError(f"Convolution layer {p.get('conv')} not implemented.")
     if p.get("conv_hodge", "HCN") != "HCN":
         raise NotImplementedError(f"Convolution layer {p.get('conv_hodge')} not implemented.")
@@ -209,11 +207,11 @@ def make_config(px: dict, pa: dict, pf: Optional[dict], *, predictor="Euler", co
     c.d_min, c.d_max = (pf["d_min"], pf["d_max"]) if is_cc else (0, 0)
     c.x_depth, c.x_nhid = px["depth"], px["nhid"]
     if px["model_type"] == "ScoreNetworkX_GMH":
-        if pa["model_type"] == "ScoreNetworkA_Base_CC":
-            raise NotImplementedError("ScoreNetworkX_GMH together with ScoreNetworkA_Base_CC is not supported by the HIP path")
         c.x_gmh = 1
         c.x_num_linears, c.x_c_init, c.x_c_hid, c.x_c_final = px["num_linears"], px["c_init"], px["c_hid"], px["c_final"]
         c.x_adim, c.x_num_heads = px["adim"], px.get("num_heads", 4)
+        c.x_conv_mlp = int(px.get("conv", "GCN") == "MLP")
+    c.a_conv_mlp = int(pa.get("conv", "GCN") == "MLP")
     c.a_num_layers, c.a_num_linears = pa["num_layers"], pa["num_linears"]
     c.a_c_init, c.a_c_hid, c.a_c_final = pa["c_init"], pa["c_hid"], pa["c_final"]
     c.a_nhid, c.a_adim, c.a_num_heads = pa["nhid"], pa["adim"], pa.get("num_heads", 4)
@@ -287,9 +285,9 @@ def pack_weights(px: dict, sdx: Optional[Dict], pa: dict, sda: Optional[Dict], p
         for l, (cin, cout, fin, ad, fo) in enumerate(gmh_layer_dims(px)):
             for c in range(cin):
                 for g in ("q", "k", "v"):
-                    for wb in ("weight", "bias"):
-                        k = f"layers.{l}.attn.{c}.gnn_{g}.{wb}"
-                        chunks.append(get(sdx, k, shapes_x[k]).ravel())
+                    for k, shp in shapes_x.items():
+                        if k.startswith(f"layers.{l}.attn.{c}.gnn_{g}."):
+                            chunks.append(get(sdx, k, shp).ravel())
             for pre in (f"layers.{l}.mlp.", f"layers.{l}.multi_channel."):
                 for k, shp in shapes_x.items():
                     if k.startswith(pre):
@@ -305,9 +303,9 @@ def pack_weights(px: dict, sdx: Optional[Dict], pa: dict, sda: Optional[Dict], p
     for l, (cin, cout, fin, ad, fo) in enumerate(attn_layer_dims(pa)):
         for c in range(cin):
             for g in ("q", "k", "v"):
-                for wb in ("weight", "bias"):
-                    k = f"layers.{l}.attn.{c}.gnn_{g}.{wb}"
-                    chunks.append(get(sda, k, shapes_a[k]).ravel())
+                for k, shp in shapes_a.items():
+                    if k.startswith(f"layers.{l}.attn.{c}.gnn_{g}."):
+                        chunks.append(get(sda, k, shp).ravel())
         for pre in (f"layers.{l}.mlp.", f"layers.{l}.multi_channel."):
             for k, shp in shapes_a.items():
                 if k.startswith(pre):

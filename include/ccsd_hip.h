@@ -92,6 +92,9 @@ typedef struct {
                                  * that ceil(batch / #CUs) workgroups are co-resident per CU; any batch stays correct */
     /* ScoreNetworkX_GMH (ScoreNetwork_X.py:156-341) when x_gmh=1: x_depth AttentionLayers (x_nhid wide) instead of GCN layers */
     int32_t x_gmh, x_num_linears, x_c_init, x_c_hid, x_c_final, x_adim, x_num_heads;
+    /* conv="MLP" (attention.py:168-178): Q and K of every Attention are 2-layer tanh MLPs of x (no adjacency) instead of
+     * DenseGCNConv; V stays a DenseGCNConv.  a_: the A-network's AttentionLayers, x_: ScoreNetworkX_GMH's */
+    int32_t a_conv_mlp, x_conv_mlp;
 } ccsd_config_t;
 
 typedef struct ccsd_plan ccsd_plan_t;

@@ -102,18 +102,22 @@ def case_kat_small_general(lib, device):
 
 
 def case_kat_gmh(lib, device):
-    """ScoreNetworkX_GMH (AttentionLayers in the X-network) against the reference constructor's outputs, through the
-    engine and through the model object; then one predictor-corrector step with it as the X-network against the oracle."""
+    """ScoreNetworkX_GMH (AttentionLayers in the X-network) and conv = "MLP" attention against the reference constructors'
+    outputs, through the engine and through the model object."""
     g = load_golden("kat_gmh_models.npz")
     meta = json.loads(str(g["meta"]))
     for tag, params in meta.items():
         flags, x, adj = (torch.from_numpy(g[f"{tag}/{k}"]).to(device) for k in ("flags", "x", "adj"))
         sd = {k[len(tag) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}/w/")}
         N, Fd = adj.shape[-1], x.shape[-1]
-        eng = PCEngine(params, sd, None, None, None, None, N=N, F=Fd, is_cc=False, device=device, lib=lib)
-        assert_close(eng.score(0, x, adj, None, flags), g[f"{tag}/out"], f"kat gmh {tag}")
+        if params["model_type"] == "ScoreNetworkA":      # conv = "MLP" in the A-network
+            eng = PCEngine(None, None, params, sd, None, None, N=N, F=Fd, is_cc=False, device=device, lib=lib)
+            assert_close(eng.score(1, x, adj, None, flags), g[f"{tag}/out"], f"kat {tag}")
+        else:
+            eng = PCEngine(params, sd, None, None, None, None, N=N, F=Fd, is_cc=False, device=device, lib=lib)
+            assert_close(eng.score(0, x, adj, None, flags), g[f"{tag}/out"], f"kat gmh {tag}")
         m = loader.load_model_from_ckpt(params, sd, device)
-        assert type(m).__name__ == "ScoreNetworkX_GMH"
+        assert type(m).__name__ == params["model_type"]
         assert_close(m(x, adj, flags, lib=lib) if not params["is_cc"] else m(x, adj, None, flags, lib=lib), g[f"{tag}/out"],
                      f"kat gmh {tag} (model object)")
 

@@ -59,7 +59,10 @@ def test_invalid_configs_are_rejected(lib):
     with pytest.raises(NotImplementedError):
         plan.make_config(dict(meta["params_x"], use_bn=True), meta["params_adj"], meta["params_rank2"])
     with pytest.raises(NotImplementedError):
-        plan.make_config(meta["params_x"], dict(meta["params_adj"], conv="MLP"), meta["params_rank2"])
+        plan.make_config(meta["params_x"], dict(meta["params_adj"], conv_hodge="MLP"), meta["params_rank2"])
+    with pytest.raises(NotImplementedError):
+        plan.make_config(meta["params_x"], dict(meta["params_adj"], conv="GAT"), meta["params_rank2"])
+    assert plan.make_config(meta["params_x"], dict(meta["params_adj"], conv="MLP"), meta["params_rank2"]).a_conv_mlp == 1
     with pytest.raises(NotImplementedError):
         plan.make_config(meta["params_x"], meta["params_adj"], meta["params_rank2"], predictor="Heun")
 

@@ -317,21 +317,26 @@ def kat_small_models():
 
 
 def kat_gmh_models():
-    """ScoreNetworkX_GMH (ScoreNetwork_X.py:156-341) has no shipped checkpoint: randomly initialised networks from the
-    reference's constructor, one small (hyper-parameters of tests/models/test_ScoreNetwork_X.py) and one at the width of
-    GDSS's ZINC250k X-network, with perturbed biases."""
+    """Variants without a shipped checkpoint, randomly initialised by the reference's constructors (biases perturbed):
+    ScoreNetworkX_GMH (ScoreNetwork_X.py:156-341) small (hyper-parameters of tests/models/test_ScoreNetwork_X.py) and at the
+    width of GDSS's ZINC250k X-network; conv = "MLP" attention (attention.py:168-178) in ScoreNetworkX_GMH and ScoreNetworkA."""
     from ccsd.src.models.ScoreNetwork_X import ScoreNetworkX_GMH
+    from ccsd.src.models.ScoreNetwork_A import ScoreNetworkA
 
     out, meta = {}, {}
     cases = {
-        "small": (dict(max_feat_num=10, depth=2, nhid=4, num_linears=2, c_init=2, c_hid=3, c_final=2, adim=4, num_heads=2,
-                       conv="GCN", use_bn=False, is_cc=False), 5, [5, 4, 3]),
-        "wide": (dict(max_feat_num=9, depth=3, nhid=16, num_linears=3, c_init=2, c_hid=8, c_final=4, adim=16, num_heads=4,
-                      conv="GCN", use_bn=False, is_cc=True), 12, [12, 9, 7, 2]),
+        "small": (ScoreNetworkX_GMH, dict(max_feat_num=10, depth=2, nhid=4, num_linears=2, c_init=2, c_hid=3, c_final=2, adim=4,
+                                          num_heads=2, conv="GCN", use_bn=False, is_cc=False), 5, [5, 4, 3]),
+        "wide": (ScoreNetworkX_GMH, dict(max_feat_num=9, depth=3, nhid=16, num_linears=3, c_init=2, c_hid=8, c_final=4, adim=16,
+                                         num_heads=4, conv="GCN", use_bn=False, is_cc=True), 12, [12, 9, 7, 2]),
+        "mlpconv_x": (ScoreNetworkX_GMH, dict(max_feat_num=6, depth=2, nhid=8, num_linears=2, c_init=2, c_hid=4, c_final=3, adim=8,
+                                              num_heads=4, conv="MLP", use_bn=False, is_cc=False), 9, [9, 7, 4]),
+        "mlpconv_a": (ScoreNetworkA, dict(max_feat_num=6, max_node_num=9, nhid=8, num_layers=3, num_linears=2, c_init=2, c_hid=4,
+                                          c_final=3, adim=8, num_heads=4, conv="MLP", use_bn=False, is_cc=False), 9, [9, 7, 4]),
     }
     torch.manual_seed(4242)
-    for tag, (p, N, counts) in cases.items():
-        m = ScoreNetworkX_GMH(**p)
+    for tag, (cls, p, N, counts) in cases.items():
+        m = cls(**p)
         for k, prm in m.named_parameters():
             if k.endswith("bias"):
                 prm.data.normal_(0, 0.2)
@@ -344,7 +349,7 @@ def kat_gmh_models():
             for k, v in m.state_dict().items():
                 out[f"{tag}/w/{k}"] = v.numpy()
             out[f"{tag}/out"] = (m(x, adj, None, flags) if p["is_cc"] else m(x, adj, flags)).numpy()
-        meta[tag] = dict(p, model_type="ScoreNetworkX_GMH")
+        meta[tag] = dict(p, model_type=cls.__name__)
     out["meta"] = json.dumps(meta)
     np.savez_compressed(os.path.join(GOLD, "kat_gmh_models.npz"), **out)
     print("kat_gmh", {k: v.shape for k, v in out.items() if k.endswith("/out")})
