@@ -211,8 +211,16 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
 #define PC(expr) do { rtError_t _e = (expr); if (_e != RT_OK) { ccsd_plan_destroy(pl); return set_err(CCSD_ERR_RUNTIME, std::string(#expr) + ": " + rt_error_string(_e)); } } while (0)
     PC(rt_malloc((void**)&pl->d, sizeof(PlanD)));
     PC(rt_h2d(pl->d, &pl->h, sizeof(PlanD)));
-    PC(rt_malloc((void**)&pl->w, n_weights * sizeof(float)));
-    PC(rt_h2d(pl->w, weights, n_weights * sizeof(float)));
+    {
+        const size_t wtotal = pl->h.f_blk >= 0 ? (size_t)pl->h.f_blk + CCSD_FBLK_FLOATS : n_weights;
+        PC(rt_malloc((void**)&pl->w, wtotal * sizeof(float)));
+        PC(rt_h2d(pl->w, weights, n_weights * sizeof(float)));
+        if (pl->h.f_blk >= 0) {
+            std::vector<float> blk(CCSD_FBLK_FLOATS);
+            ccsd_pack_fnet_blocks(&pl->h, weights, blk.data());
+            PC(rt_h2d(pl->w + pl->h.f_blk, blk.data(), blk.size() * sizeof(float)));
+        }
+    }
     {
         std::vector<float> packed(pl->npacked + 4, 0.f);
         ccsd_pack_mlp(pl->h.x_fin, weights, packed.data());

@@ -908,6 +908,29 @@ struct RankEpi {
 template <bool AFFINE, int FW = CCSD_FW>
 CCSD_DEV float fnet_element(const PlanD& p, const float* __restrict__ w, float f, float hf, float m) {
     if (AFFINE) return m * fmaf(p.f_alpha, f, fmaf(p.f_beta, hf, p.f_gamma));
+    if (p.f_blk >= 0) {
+        // every layer <= 8 wide, single-Linear head: zero-padded blocks behind the weight blob (ccsd_pack_fnet_blocks), read
+        // with wide scalar loads; each layer's output stays in its own registers and the head is accumulated segment by
+        // segment in concat order (no dynamic register indexing, padded lanes contribute exact zeros)
+        const float* fb = w + p.f_blk;
+        const float* hd = fb + CCSD_FBLK_HEAD;
+        float prev[8] = {f, p.f_cnum == 2 ? hf : 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc = fmaf(prev[i], hd[i], acc);
+#pragma unroll
+        for (int l = 0; l < CCSD_MAXFL; ++l)
+            if (l < p.f_L) {
+                float o8[8];
+                small_mlp_lds<8>(fb + l * CCSD_MAXLIN * CCSD_HWBLK, p.fl[l].n, prev, o8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    prev[i] = m * o8[i];                             // mask_rank2 after every layer (hodge_layers.py:90)
+                    acc = fmaf(prev[i], hd[(l + 1) * 8 + i], acc);
+                }
+            }
+        return m * (acc + hd[(CCSD_MAXFL + 1) * 8]);
+    }
     // general path: channels [F, HF] -> L x (MLP, mask) -> concat -> final MLP -> mask
     float ch[FW];
 #pragma unroll

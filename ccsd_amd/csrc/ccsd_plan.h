@@ -90,6 +90,7 @@ struct PlanD {
     int chan_global;            // 1: the channel stack [a_fdim][N*N] lives in the HBM workspace (large graphs), not in LDS
     // ---- variants off the headline path, kept behind the fields every launch reads (scalar-cache footprint)
     int chan_rows;               // rows of the channel stack: max(a_fdim, g_nch)
+    int f_blk;                   // ScoreNetworkF's general path from zero-padded 8x8 blocks behind the weight blob (-1: none)
     int hb_L;                     // ScoreNetworkA_Base_CC: HodgeBaselineLayers (0 otherwise)
     HodgeBaseD hb[CCSD_MAXHL];
     int o_hbg, o_hbd, hb_rows;    // k_xa LDS: hidden rows of layer 0 [cin][E][hid]; diagonals of layer 1's blocks [cin][E]; rows per chunk
@@ -332,6 +333,14 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
         p->f_affine = (c->f_num_linears == 1 && c->f_num_layers_mlp == 1) ? 1 : 0;
     }
     const size_t nweights = (size_t)pb.cur;
+    // ScoreNetworkF, general (non-affine) path with every layer width <= 8 and a single-Linear head: zero-padded [8][8] + [8]
+    // blocks (CCSD_HWBLK floats per Linear) and the head's weights in 8-wide segments, appended to the device copy of the blob
+    p->f_blk = -1;
+    if (c->is_cc && !p->f_affine && p->f_fin.n == 1 && p->f_cnum <= 8) {
+        bool ok = true;
+        for (int l = 0; l < p->f_L; ++l) ok = ok && p->fl[l].in <= 8 && p->fl[l].out <= 8 && (p->fl[l].n == 1 || p->fl[l].hid <= 8);
+        if (ok) p->f_blk = (int)((nweights + 15) & ~(size_t)15);
+    }
 
     // ---- k_xa LDS carve-up
     const int NN = N * N;
@@ -473,6 +482,31 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     if (best_total < 0 || (size_t)best_total * 4 > 160 * 1024)
         pb.fail(CCSD_ERR_UNSUPPORTED, "graph-network working set exceeds the 160 KB LDS of a CU");
     return nweights;
+}
+
+// ScoreNetworkF block layout behind the weight blob (PlanD::f_blk): Linear q of layer l at (l * CCSD_MAXLIN + q) * 72
+// ([8][8] weights, row = output, + [8] biases); then the head: (CCSD_MAXFL + 1) segments of 8 weights (segment 0: the cnum
+// input channels, segment l + 1: the outputs of layer l) + 8 floats whose first is the bias.
+#define CCSD_FBLK_HEAD (CCSD_MAXFL * CCSD_MAXLIN * 72)
+#define CCSD_FBLK_FLOATS (CCSD_FBLK_HEAD + (CCSD_MAXFL + 1) * 8 + 8)
+static inline void ccsd_pack_fnet_blocks(const PlanD* p, const float* w, float* dst) {
+    for (int i = 0; i < CCSD_FBLK_FLOATS; ++i) dst[i] = 0.f;
+    int co0 = p->f_cnum;
+    for (int i = 0; i < p->f_cnum; ++i) dst[CCSD_FBLK_HEAD + i] = w[p->f_fin.w[0] + i];
+    for (int l = 0; l < p->f_L; ++l) {
+        const MlpD& m = p->fl[l];
+        for (int q = 0; q < m.n; ++q) {
+            float* blk = dst + (l * CCSD_MAXLIN + q) * 72;
+            const int ni = mlp_in(m, q), no = mlp_out(m, q);
+            for (int o = 0; o < no; ++o) {
+                for (int i = 0; i < ni; ++i) blk[o * 8 + i] = w[m.w[q] + o * ni + i];
+                blk[64 + o] = w[m.b[q] + o];
+            }
+        }
+        for (int i = 0; i < m.out; ++i) dst[CCSD_FBLK_HEAD + (l + 1) * 8 + i] = w[p->f_fin.w[0] + co0 + i];
+        co0 += m.out;
+    }
+    dst[CCSD_FBLK_HEAD + (CCSD_MAXFL + 1) * 8] = w[p->f_fin.b[0]];
 }
 
 // Fold ScoreNetworkF into  score = mask * (alpha*F + beta*(H F) + gamma)  when every MLP in it is a
