@@ -98,3 +98,16 @@ def test_ccsd_sample_enzymes_s4_ema_yaml(tmp_path):
     sd = c.sampler.models[1].state_dict()
     k = next(iter(ema))
     assert torch.equal(sd[k].cpu(), ema[k]) and not torch.equal(ema[k], c.sampler.ckpt_dict["adj_state_dict"][k])
+
+
+def test_ccsd_sample_qm9_base_cc_yaml(tmp_path):
+    """The shipped sample_qm9_Base_CC configuration (ScoreNetworkA_Base_CC checkpoint) through the same harness."""
+    from tests.emu_util import emu_library
+
+    cfg = dict(QM9_CC_YAML, ckpt="ccsd_qm9_Base_CC")
+    out, c = run_harness(tmp_path, emu_library(), None, "sample_qm9_Base_CC", cfg, max_steps=2)
+    assert type(c.sampler).__name__ == "Sampler_mol_CC"
+    assert type(c.sampler.models[1]).__name__ == "ScoreNetworkA_Base_CC"
+    assert out["adj"].shape == (8, 9, 9) and out["rank2"].shape == (8, 36, 466)
+    assert torch.isfinite(out["adj"]).all() and torch.isfinite(out["rank2"]).all()
+    assert set(out["adj_int"].unique().tolist()) <= {0, 1, 2, 3}
