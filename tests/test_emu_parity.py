@@ -89,3 +89,9 @@ def test_alternative_kernel_paths_qm9(lib, env, monkeypatch):
     pc.case_forward_vs_reference_golden("ccsd_qm9_CC", lib, DEV)
     pc.case_pc_sampler_identical_seed("ccsd_qm9_CC", "ccsd_qm9_CC", "k10", lib, DEV)
     pc.case_philox_properties(lib, DEV)
+
+
+def test_one_step_vs_oracle_edge_batches(lib):
+    """Single-complex batch; a batch holding an empty graph, a 1-node and a 2-node graph (no rank-2 cell fits)."""
+    pc.case_one_step_vs_oracle_large("ccsd_qm9_CC", lib, DEV, 1, [7], "Reverse", "Langevin", 0.2, 0.7)
+    pc.case_one_step_vs_oracle_large("ccsd_qm9_CC", lib, DEV, 5, [9, 0, 1, 2, 3], "Euler", "Langevin", 0.2, 0.7, seed=8)

@@ -86,6 +86,20 @@ def test_one_step_vs_oracle_community_small_cc_b4(lib):
     pc.case_one_step_vs_oracle_large("ccsd_community_small_CC", lib, DEV, 4, [20, 12, 16, 18], "Euler", "Langevin", 0.05, 0.7)
 
 
+def test_one_step_vs_oracle_edge_batches(lib):
+    """Single-complex batch; a batch holding an empty graph (all flags 0), a 1-node and a 2-node graph (no rank-2 cell fits:
+    d_min = 3)."""
+    pc.case_one_step_vs_oracle_large("ccsd_qm9_CC", lib, DEV, 1, [7], "Reverse", "Langevin", 0.2, 0.7)
+    pc.case_one_step_vs_oracle_large("ccsd_qm9_CC", lib, DEV, 5, [9, 0, 1, 2, 3], "Euler", "Langevin", 0.2, 0.7, seed=8)
+
+
+def test_one_step_vs_oracle_base_cc(lib):
+    """ScoreNetworkA_Base_CC checkpoints on ragged batches: qm9 (fused rank-2 kernel, block-weight ScoreNetworkF path) and
+    community_small (tiled kernels, row-chunked HodgeBaselineLayer, 20-wide ScoreNetworkF head)."""
+    pc.case_one_step_vs_oracle_large("ccsd_qm9_Base_CC", lib, DEV, 32, [9, 8, 9, 7, 6, 9, 5, 4], "Reverse", "Langevin", 0.2, 0.7)
+    pc.case_one_step_vs_oracle_large("ccsd_community_small_Base_CC", lib, DEV, 3, [20, 13, 17], "Euler", "Langevin", 0.05, 0.7)
+
+
 def test_full_size_qm9_philox_properties(lib):
     """BASELINE size (B=1024) for a few steps: size-independent properties of the state."""
     import numpy as np
