@@ -740,10 +740,12 @@ __global__ __launch_bounds__(256) void k_gemm_p(const float* __restrict__ rank2,
                                                 const unsigned long long* __restrict__ cells) {
     __shared__ float As[T_BK * T_LD];
     __shared__ float Bs[T_BK * T_LD];
+    __shared__ float s_mv[CCSD_MAXLIN * CCSD_HWBLK];   // mlp_value as zero-padded 8x8 blocks (LDS broadcast reads)
     const int m0 = blockIdx.y * T_BM, n0 = blockIdx.x * T_BN;
     const float* Wc = W + wcat_off;
     TileAcc acc;
     tile_zero(acc);
+    if (layer == 1) { stage_mlp_blocks(mval, W, s_mv); __syncthreads(); }
     for (int k0 = 0; k0 < K; k0 += T_BK) {
         for (int idx = threadIdx.x; idx < T_BM * T_BK; idx += blockDim.x) {
             const int r = idx / T_BK, kk = idx % T_BK, k = k0 + kk, row = m0 + r;
@@ -756,7 +758,7 @@ __global__ __launch_bounds__(256) void k_gemm_p(const float* __restrict__ rank2,
                     float in[CCSD_SMALLW], out[CCSD_SMALLW];
 #pragma unroll
                     for (int c = 0; c < CCSD_SMALLW; ++c) in[c] = c < cin ? acoef[((size_t)b * cin + c) * E + e] * v : 0.f;
-                    small_mlp<CCSD_SMALLW>(mval, W, in, out);
+                    small_mlp_lds<CCSD_SMALLW>(s_mv, mval.n, in, out);
                     v = edge_on(off, edges, e) * out[0] * cell_on(off, cells, k);
                 }
             }
