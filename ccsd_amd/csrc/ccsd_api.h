@@ -226,6 +226,19 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
         ccsd_pack_mlp(pl->h.x_fin, weights, packed.data());
         for (int l = 0; l < pl->h.a_L; ++l) ccsd_pack_mlp(pl->h.al[l].mlp, weights, packed.data());
         if (pl->h.x_gmh) for (int l = 0; l < pl->h.x_depth; ++l) ccsd_pack_mlp(pl->h.gl[l].mlp, weights, packed.data());
+        if (pl->h.hb_L) ccsd_pack_mlp(pl->h.hb[0].mh, weights, packed.data());
+        for (int l = 0; l < pl->h.hb_L; ++l) {   // transposed copies of the BaselineBlocks' weights
+            const HodgeBaseD& h = pl->h.hb[l];
+            for (int c = 0; c < h.cin; ++c) {
+                const float* blk = weights + h.blk_base + (size_t)c * h.blk_stride;    // W1[hid][E] b1[hid] W2[E][hid] b2[E]
+                const float* w2 = blk + h.hid * E + h.hid;
+                for (int e = 0; e < E; ++e)
+                    for (int hh = 0; hh < h.hid; ++hh) {
+                        packed[(size_t)h.w2t + ((size_t)c * h.hid + hh) * E + e] = w2[e * h.hid + hh];
+                        packed[(size_t)h.w1t + ((size_t)c * E + e) * h.hid + hh] = blk[hh * E + e];
+                    }
+            }
+        }
         ccsd_pack_mlp(pl->h.a_fin, weights, packed.data());
         for (int l = 0; l < pl->h.h_L; ++l) {   // Wcat^T of the hodge projections for k_r2
             const HodgeLayerD& h = pl->h.hl[l];

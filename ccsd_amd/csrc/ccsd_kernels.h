@@ -217,6 +217,60 @@ CCSD_DEV void stage_mlp_blocks(const MlpD& m, const float* __restrict__ w, float
         blk[t] = v;
     }
 }
+// sum_i wg[i (* ws)] * xs[i], i < n (n >= 1), accumulated in index order; wg in global memory, xs in LDS.  The weight loads go out
+// eight at a time ahead of the FMAs: one L2 round trip per 8 terms instead of one per term (a counted loop with a global load
+// feeding each FMA serialises on the load latency).
+template <bool STRIDED>   // STRIDED: term i of wg sits at wg[i * ws] (a transposed copy read along its other index)
+CCSD_DEV float dot_gl(const float* __restrict__ wg, int ws, const float* xs, int n) {
+    float acc = 0.f;
+    for (int i0 = 0; i0 < n; i0 += 8) {
+        float wv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wv[j] = wg[(i0 + j < n ? i0 + j : n - 1) * (STRIDED ? ws : 1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xv = xs[i0 + j < n ? i0 + j : n - 1];
+            if (i0 + j < n) acc = fmaf(xv, wv[j], acc);
+        }
+    }
+    return acc;
+}
+
+// The same with W x W blocks (block q = [W][W] weights, row = output, + [W] biases), for MLPs up to W wide.
+template <int W>
+CCSD_DEV void stage_mlp_blocks_w(const MlpD& m, const float* __restrict__ w, float* blk) {
+    constexpr int BS = W * W + W;
+    for (int t = threadIdx.x; t < m.n * BS; t += blockDim.x) {
+        const int q = t / BS, r = t % BS;
+        const int ni = mlp_in(m, q), no = mlp_out(m, q);
+        float v = 0.f;
+        if (r < W * W) { const int o = r / W, i = r % W; if (o < no && i < ni) v = w[m.w[q] + o * ni + i]; }
+        else { const int o = r - W * W; if (o < no) v = w[m.b[q] + o]; }
+        blk[t] = v;
+    }
+}
+template <int W>
+CCSD_DEV void small_mlp_ldsw(const float* blk, int nlin, const float* in, float* out) {
+    constexpr int BS = W * W + W;
+    float a[W], t[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) a[i] = in[i];
+    for (int l = 0; l < nlin; ++l) {
+        const float* wb = blk + l * BS;
+        const bool act = l < nlin - 1;
+#pragma unroll
+        for (int o = 0; o < W; ++o) {
+            float acc = wb[W * W + o];
+#pragma unroll
+            for (int i = 0; i < W; ++i) acc = fmaf(a[i], wb[o * W + i], acc);
+            t[o] = act ? elu1(acc) : acc;
+        }
+#pragma unroll
+        for (int i = 0; i < W; ++i) a[i] = t[i];
+    }
+#pragma unroll
+    for (int i = 0; i < W; ++i) out[i] = a[i];
+}
 template <int W>   // W = 4 when every width of the MLP is <= 4 (the shipped hodge branches), else CCSD_SMALLW
 CCSD_DEV void small_mlp_lds(const float* blk, int nlin, const float* in, float* out) {
     float a[W], t[W];
@@ -2236,6 +2290,11 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
             float* s_g = sm + p.o_hbg;            // [cin0][E][hid0]: hidden rows of the first layer's BaselineBlocks
             const HodgeBaseD& b0 = p.hb[0];
             const int hd0 = b0.hid;
+            // mlp_hodge of both layers as zero-padded 16 x 16 blocks in LDS (broadcast reads instead of per-weight scalar loads)
+            constexpr int HBS = CCSD_FW * CCSD_FW + CCSD_FW;
+            float* s_mh = sm + p.o_hbw;
+            stage_mlp_blocks_w<CCSD_FW>(b0.mh, w, s_mh);
+            if (p.hb_L > 1) stage_mlp_blocks_w<CCSD_FW>(p.hb[1].mh, w, s_mh + CCSD_MAXLIN * HBS);
             const FastDiv dh0(hd0), dEh0(E * hd0);
             // adj_to_hodgedual: row e of input channel c is a_c[e] * onehot(e)  =>  hidden = elu(W1[:, e] * a_c[e] + b1)
             for (int t = tid; t < p.a_cinit * E; t += nth) {
@@ -2252,14 +2311,14 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                 s_g[t] = elu1(fmaf(blk[h * E + e], a, blk[hd0 * E + h]));
             }
             __syncthreads();
+            stamp(xa.dbg, 16);
             // tanh(mlp_layer(H_c))[e][e2] from the hidden row of e (BaselineBlock.forward, hodge_layers.py:264)
             auto blockv = [&](int c, int e, int e2) {
                 const float* blk = w + b0.blk_base + c * b0.blk_stride;
-                const float* w2 = blk + hd0 * E + hd0 + e2 * hd0;
+                const float* w2t = wp + b0.w2t + c * hd0 * E + e2;       // W2^T [hid][E]: lanes along e2 read consecutive floats
                 const float* g = s_g + (c * E + e) * hd0;
-                float acc = 0.f;
-                for (int h = 0; h < hd0; ++h) acc = fmaf(g[h], w2[h], acc);
-                return tanh_f(acc + blk[hd0 * E + hd0 + E * hd0 + e2]);
+                const float bias = blk[hd0 * E + hd0 + E * hd0 + e2];
+                return tanh_f(dot_gl<true>(w2t, E, g, hd0) + bias);
             };
             // mlp_hodge over the symmetrised channels -> mask_hodge_adjs -> tanh -> + transpose, element (e, e2) of layer 0
             auto layer0 = [&](int e, int e2, float* out) {
@@ -2269,7 +2328,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
 #pragma unroll
                 for (int c = 0; c < CCSD_FW; ++c)
                     if (c < b0.cin) in[c] = e == e2 ? blockv(c, e, e) : (blockv(c, e, e2) + blockv(c, e2, e)) * 0.5f;
-                small_mlp<CCSD_FW>(b0.mh, w, in, out);
+                small_mlp_ldsw<CCSD_FW>(s_mh, b0.mh.n, in, out);
                 const float fh = s_flags[edge_i(e)] * s_flags[edge_j(e)] * s_flags[edge_i(e2)] * s_flags[edge_j(e2)];
 #pragma unroll
                 for (int o = 0; o < CCSD_FW; ++o) { const float tv = tanh_f(out[o] * fh); out[o] = tv + tv; }
@@ -2288,10 +2347,35 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                 const int hd1 = b1.hid, R = p.hb_rows;
                 float* s_row = s_R;                           // [cout0][R][E]: rows r0 .. r0 + R of layer 0's output
                 float* s_g2 = s_R + b0.cout * R * E;          // [R][cin1][hid1]: hidden rows of the second layer's blocks
+                float* s_S = s_g2 + R * b1.cin * b1.hid;      // [cin0][R * E]: symmetrised block outputs = mlp_hodge's input rows
+                const FastDiv dRE(R * E);
                 float* s_d2 = sm + p.o_hbd;                   // [cin1][E]: diagonal of tanh(mlp_layer(H1_c))
                 const FastDiv dch1(b1.cin * hd1);
                 for (int r0 = 0; r0 < E; r0 += R) {
                     const int nr = (E - r0) < R ? (E - r0) : R;
+                    if (r0 == 0) stamp(xa.dbg, 17);
+                    if (b0.mh.chain) {
+                        // (channel, pair) tasks fill mlp_hodge's input, then the MLP runs per 16-pair tile on MFMA
+                        for (int t = tid; t < b0.cin * R * E; t += nth) {
+                            int c, r, er, e2;
+                            dRE.divmod(t, c, r);
+                            dE.divmod(r, er, e2);
+                            const int e = r0 + er;
+                            if (er < nr) s_S[t] = e == e2 ? blockv(c, e, e) : (blockv(c, e, e2) + blockv(c, e2, e)) * 0.5f;
+                        }
+                        __syncthreads();
+                        if (r0 == 0) stamp(xa.dbg, 18);
+                        mlp_chain<1, 1, 1>(b0.mh, wp, s_S, R * E, s_S, b0.mh.in, nr * E, [](int r) { return r; },
+                                           [&](int r, int o, float v) {
+                                               int er, e2;
+                                               dE.divmod(r, er, e2);
+                                               const int e = r0 + er;
+                                               const float fh = s_flags[edge_i(e)] * s_flags[edge_j(e)] * s_flags[edge_i(e2)] * s_flags[edge_j(e2)];
+                                               const float tv = tanh_f(v * fh);
+                                               s_row[(o * R + er) * E + e2] = tv + tv;
+                                               if (e == e2) s_hd[(p.a_cinit + o) * E + e] = tv + tv;
+                                           });
+                    } else
                     for (int t = tid; t < nr * E; t += nth) {
                         int er, e2;
                         dE.divmod(t, er, e2);
@@ -2306,16 +2390,16 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                             }
                     }
                     __syncthreads();
+                    if (r0 == 0) stamp(xa.dbg, 19);
                     for (int t = tid; t < nr * b1.cin * hd1; t += nth) {
                         int er, r, c, h;
                         dch1.divmod(t, er, r);
                         c = r / hd1; h = r - c * hd1;
                         const float* blk = w + b1.blk_base + c * b1.blk_stride;
-                        const float* w1 = blk + h * E;
+                        const float* w1t = wp + b1.w1t + c * E * hd1 + h;      // W1^T [E][hid]: lanes along h read consecutive floats
                         const float* row = s_row + (c * R + er) * E;
-                        float acc = 0.f;
-                        for (int e2 = 0; e2 < E; ++e2) acc = fmaf(row[e2], w1[e2], acc);
-                        s_g2[t] = elu1(acc + blk[hd1 * E + h]);
+                        const float bias = blk[hd1 * E + h];
+                        s_g2[t] = elu1(dot_gl<true>(w1t, hd1, row, E) + bias);
                     }
                     __syncthreads();
                     for (int t = tid; t < nr * b1.cin; t += nth) {
@@ -2323,17 +2407,18 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                         const float* blk = w + b1.blk_base + c * b1.blk_stride;
                         const float* w2 = blk + hd1 * E + hd1 + e * hd1;
                         const float* g = s_g2 + t * hd1;
-                        float acc = 0.f;
-                        for (int h = 0; h < hd1; ++h) acc = fmaf(g[h], w2[h], acc);
-                        s_d2[c * E + e] = tanh_f(acc + blk[hd1 * E + hd1 + E * hd1 + e]);
+                        const float bias = blk[hd1 * E + hd1 + E * hd1 + e];
+                        s_d2[c * E + e] = tanh_f(dot_gl<false>(w2, 1, g, hd1) + bias);
                     }
                     __syncthreads();
+                    if (r0 == 0) stamp(xa.dbg, 20);
                 }
+                stamp(xa.dbg, 21);
                 for (int e = tid; e < E; e += nth) {
                     float in[CCSD_FW], out[CCSD_FW];
 #pragma unroll
                     for (int c = 0; c < CCSD_FW; ++c) in[c] = c < b1.cin ? s_d2[(c < b1.cin ? c : 0) * E + e] : 0.f;
-                    small_mlp<CCSD_FW>(b1.mh, w, in, out);
+                    small_mlp_ldsw<CCSD_FW>(s_mh + CCSD_MAXLIN * HBS, b1.mh.n, in, out);
                     const float fh = s_flags[edge_i(e)] * s_flags[edge_j(e)];
 #pragma unroll
                     for (int o = 0; o < CCSD_FW; ++o)

@@ -55,6 +55,7 @@ struct HodgeLayerD {
 struct HodgeBaseD {
     int cin, cout, hid;
     int blk_base, blk_stride;
+    int w2t, w1t;            // packed buffer: per channel W2^T [hid][E] / W1^T [E][hid] (coalesced reads along e / along hid)
     MlpD mh;
 };
 
@@ -93,6 +94,7 @@ struct PlanD {
     int f_blk;                   // ScoreNetworkF's general path from zero-padded 8x8 blocks behind the weight blob (-1: none)
     int hb_L;                     // ScoreNetworkA_Base_CC: HodgeBaselineLayers (0 otherwise)
     HodgeBaseD hb[CCSD_MAXHL];
+    int o_hbw;                    // k_xa LDS: mlp_hodge weight blocks of both layers (2 * CCSD_MAXLIN * (16*16+16) floats)
     int o_hbg, o_hbd, hb_rows;    // k_xa LDS: hidden rows of layer 0 [cin][E][hid]; diagonals of layer 1's blocks [cin][E]; rows per chunk
     // ScoreNetworkX_GMH (x_gmh = 1): x_depth AttentionLayers gl[] on g_cinit adjacency powers, g_nch channels in all
     int x_gmh, g_cinit, g_nch;
@@ -270,8 +272,11 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             if (h.hid < 1) { pb.fail(CCSD_ERR_INVALID, "HodgeBaselineLayer hidden width < 1"); return 0; }
             h.blk_stride = 2 * h.hid * E + h.hid + E;
             h.blk_base = pb.take((int64_t)h.cin * h.blk_stride);
+            h.w2t = pb.pcur; pb.pcur += h.cin * h.hid * E;
+            h.w1t = pb.pcur; pb.pcur += h.cin * h.hid * E;
             const int hid = 2 * (h.cin > h.cout ? h.cin : h.cout);
             h.mh = pb.mlp(c->h_num_linears, h.cin, hid, h.cout);
+            if (first) pb.chainify(h.mh, CCSD_CHAIN_EDGE);       // the dense first layer evaluates it per (e, e') pair on MFMA
             if (h.cin > CCSD_FW || (c->h_num_linears > 1 && hid > CCSD_FW) || h.cout > CCSD_FW) {
                 pb.fail(CCSD_ERR_UNSUPPORTED, "HodgeBaselineLayer mlp_hodge wider than 16"); return 0; }
             hch += h.cout;
@@ -446,8 +451,10 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
                 int g = p->hb[0].cin * E * p->hb[0].hid;
                 p->o_hbg = (g <= o - p->o_att) ? p->o_att : carve(g);
                 p->o_hbd = carve(p->hb_L > 1 ? p->hb[1].cin * E : 4);
+                p->o_hbw = carve(2 * CCSD_MAXLIN * (CCSD_FW * CCSD_FW + CCSD_FW));
                 p->o_hd = carve(p->a_nch_hodge * E);
-                if (p->hb_L > 1) hb_rmin = p->hb[0].cout * (E + p->hb[1].hid);     // one row of layer 0's output + its hidden row
+                // per row of the chunk: the symmetrised block outputs (mlp_hodge's input), layer 0's output, the next layer's hidden row
+                if (p->hb_L > 1) hb_rmin = p->hb[0].cin * E + p->hb[0].cout * (E + p->hb[1].hid);
             }
             if (xphase_end > o) o = xphase_end;
             p->o_wst = carve(wst);

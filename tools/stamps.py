@@ -6,7 +6,8 @@ import bench
 from ccsd_amd import loader
 from ccsd_amd.engine import PCEngine
 
-meta, parts = bench.load_qm9()
+from tests.helpers import load_ckpt_np
+meta, parts = load_ckpt_np(os.environ.get("STAMPS_CKPT", "ccsd_qm9_CC"))   # STAMPS_CKPT=ccsd_qm9_Base_CC: the ablation checkpoint
 cfg = meta["config"]
 sdes = [loader.load_sde(cfg["sde"][p]) for p in ("x", "adj", "rank2")]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
@@ -42,3 +43,7 @@ hs = [12, 16, 17, 18, 19, 20, 13]
 print("hodge: fill/hq0, dense pairs, deg, MFMA proj, diag att, scatter:", [int(np.median(x[:, hs[i + 1]] - x[:, hs[i]])) for i in range(6)])
 print("final MLP: chain (wave 0)", int(np.median(x[:, 11] - x[:, 13])), " wait barrier", int(np.median(x[:, 15] - x[:, 11])), " epilogue", int(np.median(x[:, 14] - x[:, 15])))
 print("k_r2 first-start to last-end cycles:", span, " k_xa:", x[:, 14].max() - x[:, 0].min())
+if os.environ.get("STAMPS_CKPT", "").endswith("Base_CC"):
+    hb = [12, 16, 17, 18, 19, 20, 21, 13]
+    print("baseline hodge: stage+hidden0, (to chunk 0), fill S, mlp_hodge chain, hidden rows + diag of layer 1, remaining chunks, head+scatter:",
+          [int(np.median(x[:, hb[i + 1]] - x[:, hb[i]])) for i in range(7)], " rows per chunk", "see plan")
