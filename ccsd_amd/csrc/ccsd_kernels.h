@@ -506,7 +506,9 @@ CCSD_DEV void mlp_chain(const MlpD& m, const float* __restrict__ wp, const float
 // xT: LDS, feature-major [k][ldn].  A: [N][N] (LDS or the HBM channel stack).  wf(k, col) / bf(col): weight / bias.
 // NTN = ceil(N / 16) node tiles (compile time).
 // ---------------------------------------------------------------------------------------------
-template <int NTN, class WF, class BF, class OUT>
+// BATCH: load the weights of four k-steps ahead of their MFMAs (large graphs; off in the small-graph instantiations, whose
+// code is then exactly the plain loop).
+template <int NTN, bool BATCH, class WF, class BF, class OUT>
 CCSD_DEV void gcn_tile(const float* xT, int ldn, int fin, int N, const float* A, const float* dinv, int col0, int ncols,
                        WF wf, BF bf, OUT out) {
 #ifdef CCSD_EMU
@@ -537,15 +539,40 @@ CCSD_DEV void gcn_tile(const float* xT, int ldn, int fin, int N, const float* A,
 #pragma unroll
     for (int tn = 0; tn < NTN; ++tn) xw[tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int ks = (fin + 3) >> 2;
-    for (int s0 = 0; s0 < ks; ++s0) {
-        const int k = 4 * s0 + kq, kc = k < fin ? k : fin - 1;
-        const float bw = wf(kc, colc);
-        const float bv = (k < fin && cok) ? bw : 0.f;
+    if (NTN == 1 || !BATCH) {       // small graphs (fin of a few k-steps): the plain loop is as fast and lighter on registers
+        for (int s0 = 0; s0 < ks; ++s0) {
+            const int k = 4 * s0 + kq, kc = k < fin ? k : fin - 1;
+            const float bw = wf(kc, colc);
+            const float bv = (k < fin && cok) ? bw : 0.f;
 #pragma unroll
-        for (int tn = 0; tn < NTN; ++tn) {
-            const int j = 16 * tn + l15;
-            const float av = xT[kc * ldn + (j < N ? j : N - 1)];
-            xw[tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(j < N ? av : 0.f, bv, xw[tn], 0, 0, 0);
+            for (int tn = 0; tn < NTN; ++tn) {
+                const int j = 16 * tn + l15;
+                const float av = xT[kc * ldn + (j < N ? j : N - 1)];
+                xw[tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(j < N ? av : 0.f, bv, xw[tn], 0, 0, 0);
+            }
+        }
+    } else
+    // the weights of four k-steps are loaded back to back ahead of their MFMAs: one L2 round trip per four steps instead of one
+    // per step (the loads are the critical path of a task)
+    for (int s00 = 0; s00 < ks; s00 += 4) {
+        float bw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = 4 * (s00 + u) + kq;
+            bw[u] = wf(k < fin ? k : fin - 1, colc);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (s00 + u < ks) {
+                const int k = 4 * (s00 + u) + kq, kc = k < fin ? k : fin - 1;
+                const float bv = (k < fin && cok) ? bw[u] : 0.f;
+#pragma unroll
+                for (int tn = 0; tn < NTN; ++tn) {
+                    const int j = 16 * tn + l15;
+                    const float av = xT[kc * ldn + (j < N ? j : N - 1)];
+                    xw[tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(j < N ? av : 0.f, bv, xw[tn], 0, 0, 0);
+                }
+            }
         }
     }
 #pragma unroll
@@ -578,13 +605,13 @@ CCSD_DEV void gcn_tile(const float* xT, int ldn, int fin, int N, const float* A,
     }
 #endif
 }
-template <class WF, class BF, class OUT>
+template <bool BATCH, class WF, class BF, class OUT>
 CCSD_DEV void gcn_tile_n(const float* xT, int ldn, int fin, int N, const float* A, const float* dinv, int col0, int ncols,
                          WF wf, BF bf, OUT out) {
-    if (N <= 16) gcn_tile<1>(xT, ldn, fin, N, A, dinv, col0, ncols, wf, bf, out);
-    else if (N <= 32) gcn_tile<2>(xT, ldn, fin, N, A, dinv, col0, ncols, wf, bf, out);
-    else if (N <= 48) gcn_tile<3>(xT, ldn, fin, N, A, dinv, col0, ncols, wf, bf, out);
-    else gcn_tile<4>(xT, ldn, fin, N, A, dinv, col0, ncols, wf, bf, out);
+    if (N <= 16) gcn_tile<1, BATCH>(xT, ldn, fin, N, A, dinv, col0, ncols, wf, bf, out);
+    else if (N <= 32) gcn_tile<2, BATCH>(xT, ldn, fin, N, A, dinv, col0, ncols, wf, bf, out);
+    else if (N <= 48) gcn_tile<3, BATCH>(xT, ldn, fin, N, A, dinv, col0, ncols, wf, bf, out);
+    else gcn_tile<4, BATCH>(xT, ldn, fin, N, A, dinv, col0, ncols, wf, bf, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1948,7 +1975,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
             float* dst = s_xcat + (F + l * H) * ldn;
             // tanh(DenseGCNConv(x, adj)) (ScoreNetwork_X.py:118-121): 16-column tiles over the waves
             for (int ct = wave_id; ct < (H + 15) >> 4; ct += n_waves)
-                gcn_tile_n(src, ldn, fin, N, s_adj, s_dinv, 16 * ct, H,
+                gcn_tile_n<GCH>(src, ldn, fin, N, s_adj, s_dinv, 16 * ct, H,
                            [&](int k, int col) { return W[k * H + col]; }, [&](int col) { return B[col]; },
                            [&](int i, int col, float v) { dst[col * ldn + i] = tanh_f(v); });
             __syncthreads();

@@ -11,10 +11,11 @@ meta, parts = load_ckpt_np(os.environ.get("STAMPS_CKPT", "ccsd_qm9_CC"))   # STA
 cfg = meta["config"]
 sdes = [loader.load_sde(cfg["sde"][p]) for p in ("x", "adj", "rank2")]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+Nn, Ff = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
 eng = PCEngine(meta["params_x"], parts["x"], meta["params_adj"], parts["adj"], meta["params_rank2"], parts["rank2"],
-               N=9, F=4, is_cc=True, d_min=3, d_max=9, sdes=sdes, predictor="Reverse", corrector="Langevin", snr=0.2,
-               scale_eps=0.7, n_steps=1, denoise=True, eps=1e-4, device="cuda:0")
-flags = bench.qm9_flags(B).cuda()
+               N=Nn, F=Ff, is_cc=True, d_min=cfg["data"]["d_min"], d_max=cfg["data"]["d_max"], sdes=sdes, predictor="Reverse",
+               corrector="Langevin", snr=0.2, scale_eps=0.7, n_steps=1, denoise=True, eps=1e-4, device="cuda:0", batch_hint=B)
+flags = (bench.qm9_flags(B) if Nn == 9 else bench.hist_flags(B, Nn, {Nn: 3, Nn - 2: 2, Nn - 5: 1})).cuda()
 st, sc, rs = eng.alloc_state(B), eng.alloc_state(B), eng.alloc_state(B)
 eng.init_state(flags, st, None, 1, 0)
 eng.run(flags, st, sc, rs, 1, 0, 0, 3)
