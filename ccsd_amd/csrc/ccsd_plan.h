@@ -410,7 +410,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             p->o_flags = carve(N);
             p->o_x = carve(N * F);
             p->o_adj = carve(NN);
-            p->o_an = carve(cg * N > N ? cg * N : N);                       // D^-1/2 per channel of the group
+            p->o_an = carve(gch ? cinmax * N : cg * N > N ? cg * N : N);    // D^-1/2 per channel of the group (HBM stack: of the layer)
             p->o_edge = carve(E);
             const int phase0 = o;
             p->o_xcat = carve(p->x_fdim * p->ldn);                          // X-network phase ...
