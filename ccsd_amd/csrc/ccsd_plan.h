@@ -460,7 +460,8 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             p->o_wst = carve(wst);
             p->wst_floats = wst;
             // shared region R: GCN scratch of a channel group | hidden activations of the MLPs | dense hodge layer
-            int rmin = 2 * cg * N * colmax;
+            // [channel][node][Q | K | V] of a group (the GCN's x W intermediate lives in registers)
+            int rmin = cg * N * colmax;
             if (N * c->x_nhid > rmin) rmin = N * c->x_nhid;
             if (h1m_floats > rmin) rmin = h1m_floats;
             if (NN > rmin) rmin = NN;                                       // raw output of the chained final MLP
