@@ -266,7 +266,9 @@ def main():
     if not args.no_kernel_events:
         for kname in knames:                               # HIP events around those kernels' launches, on their stream
             eng.profile_kernel(kname)
-        eng.profile_stride(args.event_stride)              # every n-th launch: dense bracketing costs ~6 % of the step
+        # every n-th launch: dense bracketing costs ~6 % of the step.  Short runs bracket more densely so that the roofline
+        # object always has samples.
+        eng.profile_stride(args.event_stride if args.steps >= 200 else 3 if args.steps >= 20 else 1)
     sync()
     t0 = time.perf_counter()
     run_steps(0, args.steps)
