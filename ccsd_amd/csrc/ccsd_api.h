@@ -56,6 +56,9 @@ struct ccsd_plan {
     // fused rank-2 kernel (k_r2): eligibility and LDS geometry
     int fused_r2 = 0, r2_ldk = 0, r2_ldh = 0;
     size_t r2_lds = 0;
+    // diagnostic knobs, read from the environment ONCE at plan creation (never on the launch path):
+    // CCSD_OLD_GEMM_P, CCSD_XA_THREADS, CCSD_NO_FUSED_APPLY (CCSD_NO_FUSED_R2 / CCSD_XA_PASS / CCSD_XA_GCH / CCSD_NO_CHAIN shape the plan itself)
+    int opt_old_gemm_p = 0, opt_xa_threads = 256, opt_no_fused_apply = 0;
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     unsigned prof_mask = 0;
     size_t prof_used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -165,6 +168,9 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     *out = nullptr;
     ccsd_plan* pl = new ccsd_plan();
     pl->cfg = *cfg;
+    pl->opt_old_gemm_p = getenv("CCSD_OLD_GEMM_P") != nullptr;
+    pl->opt_no_fused_apply = getenv("CCSD_NO_FUSED_APPLY") != nullptr;
+    if (const char* xt = getenv("CCSD_XA_THREADS")) { const int v = atoi(xt); if (v >= 64 && v <= 512 && v % 64 == 0) pl->opt_xa_threads = v; }
     PlanBuilder pb;
     pl->nweights = ccsd_build_plan(cfg, &pl->h, pb);
     if (pb.status != CCSD_OK) { delete pl; return set_err(pb.status, pb.err); }
@@ -372,7 +378,7 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
         prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_P, stream);
 #ifndef CCSD_EMU
         const int nt = (h.wc + 15) / 16, Kp = (p.K + 31) & ~31;
-        if (nt <= 4 && getenv("CCSD_OLD_GEMM_P") == nullptr) {     // narrow projections: no 64-column padding
+        if (nt <= 4 && !pl->opt_old_gemm_p) {     // narrow projections: no 64-column padding
             const dim3 g0((rows + T_BM - 1) / T_BM);
             const float* WT = (const float*)pl->wp + h.wcatT;
             switch (nt) {
@@ -405,7 +411,7 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
 }
 static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Workspace& w, void* stream) {
     xa.P0 = w.P0; xa.P1 = w.P1; xa.chan_ws = w.chan; xa.dbg = pl->dbg ? pl->dbg + 32 : nullptr;
-    static const int xa_threads = getenv("CCSD_XA_THREADS") ? atoi(getenv("CCSD_XA_THREADS")) : 256;   // diagnostic: 64..512
+    const int xa_threads = pl->opt_xa_threads;   // 256 unless CCSD_XA_THREADS was set when the plan was created (diagnostic: 64..512)
     prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
     xa.wp = pl->wp; xa.hpairs = pl->hpairs;
     const dim3 xblk(CCSD_NTHREADS == 1 ? 1 : xa_threads);
@@ -750,7 +756,7 @@ extern "C" int ccsd_sampler_run(ccsd_plan_t* pl, int32_t B, const float* flags, 
             if ((st = s4_apply(pl, B, step, &a, flags, nullptr, nullptr, nullptr, seed, sample_offset, w.sums, &b,
                                want_mean ? result : nullptr, w, stream))) return st;
             ccsd_state_t t = a; a = b; b = t;
-        } else if (lang && pl->fused_r2 && getenv("CCSD_NO_FUSED_APPLY") == nullptr) {
+        } else if (lang && pl->fused_r2 && !pl->opt_no_fused_apply) {
             // a -> [norms pass] ; [apply fused into the predictor kernels] -> b ; swap roles
             if ((st = corrector_norms(pl, B, step, 0, &a, &a, flags, nullptr, seed, sample_offset, w.sums, w, stream))) return st;
             if ((st = predictor(pl, B, step, &a, flags, nullptr, seed, sample_offset, &b, want_mean ? result : nullptr, w, stream, w.sums))) return st;

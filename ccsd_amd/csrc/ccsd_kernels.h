@@ -1702,10 +1702,15 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     stamp(ra.dbg, 7);
     // No workgroup barrier here: phase 2 only READS the rank-2 block (its results go straight to HBM), so a wave may start
     // it as soon as H is complete -- the waves with the lighter phase-1 tasks do not wait for the projection tasks.
+    // Every wave of the workgroup is resident and runs its phase-1 tasks unconditionally, so the count is always reached:
+    // the wait has no give-up path into phase 2 (an incomplete H would mean silently wrong scores).  The guard only turns a
+    // broken invariant (never observed; ~10 s of polling) into a loud kernel abort instead of an endless spin.
     if (nHtasks > 0) {
-        int spins = 0;
-        while (__hip_atomic_load(&s_hdone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < nHtasks && ++spins < (1 << 22))
-            __builtin_amdgcn_s_sleep(4);
+        unsigned spins = 0;
+        while (__hip_atomic_load(&s_hdone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < nHtasks) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins == (1u << 27)) __builtin_trap();
+        }
     }
 #endif
 

@@ -91,11 +91,9 @@ def load_sde(config_sde) -> SDE:
 def load_model_from_ckpt(params: Dict[str, Any], state_dict: Dict[str, Any], device):
     model = load_model(params)
     model.load_state_dict(state_dict)
-    if isinstance(device, list) and len(device) > 1:
-        # the reference wraps the module in DataParallel here (loader.py:649-650); this build shards
-        # the batch over one process per GPU instead (bench.py / ccsd_amd.distributed), so a device
-        # list just selects its first entry for this process.
-        pass
+    # The reference wraps the module in DataParallel when `device` lists several GPUs (loader.py:649-650).  This build
+    # shards the batch over one process per GPU instead (ccsd_amd/distributed.py: load_sampling_fn_sharded), so within a
+    # process a device list just selects its first entry.
     return model.to(_device_id(device))
 
 

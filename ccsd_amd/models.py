@@ -224,6 +224,89 @@ class ScoreNetworkF(_ScoreNetwork):
                          use_hodge_mask=use_hodge_mask, use_bn=use_bn, is_cc=is_cc)
 
 
+def _shape(sd, key):
+    v = sd.get(key)
+    if v is None:
+        v = sd.get("module." + key)
+    return None if v is None else tuple(v.shape)
+
+
+def _mlp_dims(sd, prefix):
+    """(number of linears, output width) of a reference MLP from its state_dict keys (layers.py:205-218)."""
+    s1 = _shape(sd, prefix + "linear.weight")
+    if s1 is not None:
+        return 1, s1[0]
+    n = 0
+    while _shape(sd, f"{prefix}linears.{n}.weight") is not None:
+        n += 1
+    if n == 0:
+        raise ValueError(f"no MLP under {prefix}")
+    return n, _shape(sd, f"{prefix}linears.{n - 1}.weight")[0]
+
+
+_ATTRS = {
+    # model_type -> constructor keyword -> attribute the reference module stores it under
+    "ScoreNetworkX": dict(max_feat_num="nfeat", depth="depth", nhid="nhid", use_bn="use_bn", is_cc="is_cc"),
+    "ScoreNetworkA": {k: k for k in ("max_feat_num", "max_node_num", "nhid", "num_layers", "num_linears", "c_init", "c_hid",
+                                     "c_final", "adim", "num_heads", "conv", "use_bn", "is_cc")},
+    "ScoreNetworkA_CC": {k: k for k in ("max_feat_num", "max_node_num", "d_min", "d_max", "nhid", "nhid_h", "num_layers",
+                                        "num_layers_h", "num_linears", "num_linears_h", "c_init", "c_hid", "c_hid_h", "c_final",
+                                        "c_final_h", "adim", "adim_h", "num_heads", "num_heads_h", "conv", "conv_hodge", "use_bn",
+                                        "is_cc")},
+    "ScoreNetworkA_Base_CC": {k: k for k in ("max_feat_num", "max_node_num", "d_min", "d_max", "nhid", "nhid_h", "num_layers",
+                                             "num_layers_h", "num_linears", "num_linears_h", "c_init", "c_hid", "c_hid_h",
+                                             "c_final", "c_final_h", "adim", "hidden_h", "num_heads", "conv", "use_bn", "is_cc")},
+    "ScoreNetworkF": {k: k for k in ("num_layers_mlp", "num_layers", "num_linears", "nhid", "c_hid", "c_final", "cnum",
+                                     "max_node_num", "d_min", "d_max", "use_hodge_mask", "use_bn", "is_cc")},
+}
+
+
+def params_from_module(model) -> Dict[str, Any]:
+    """Constructor keywords (+ model_type) of a score network: this package's containers carry them as `.params`; for the
+    reference's own nn.Modules (ccsd/src/models/*.py, possibly inside DataParallel) they are read back from the attributes
+    the constructors store (ScoreNetwork_X.py:47-51, ScoreNetwork_A.py:390-402, ScoreNetwork_A_CC.py:83-106,
+    ScoreNetwork_A_Base_CC.py:82-103, ScoreNetwork_F.py:64-76) and, where a constructor keeps none (ScoreNetworkX_GMH,
+    ScoreNetwork_X.py:198-201), from the shapes in state_dict().  This is the pair loader.load_model_from_ckpt
+    (loader.py:619-657) builds a model from, so the seam accepts whatever that function returned."""
+    m = getattr(model, "module", model)
+    if hasattr(m, "params") and isinstance(getattr(m, "params"), dict):
+        return dict(m.params)
+    t = type(m).__name__
+    if t in _ATTRS:
+        missing = [a for a in _ATTRS[t].values() if not hasattr(m, a)]
+        if missing:
+            raise TypeError(f"{t} object lacks the attributes {missing}: cannot recover its hyper-parameters")
+        p = {k: getattr(m, a) for k, a in _ATTRS[t].items()}
+        for k, v in p.items():
+            if isinstance(v, bool) or isinstance(v, str):
+                continue
+            p[k] = int(v)
+        p["model_type"] = t
+        return p
+    if t == "ScoreNetworkX_GMH":
+        sd = m.state_dict()
+        depth, c_init = int(m.depth), int(m.c_init)
+        conv = "MLP" if _shape(sd, "layers.0.attn.0.gnn_q.linears.0.weight") is not None else "GCN"
+        fin0, nhid = _shape(sd, "layers.0.attn.0.gnn_v.weight")
+        num_linears, c_hid0 = _mlp_dims(sd, "layers.0.mlp.")
+        _, c_last = _mlp_dims(sd, f"layers.{depth - 1}.mlp.")
+        if depth > 1:
+            adim = (_shape(sd, "layers.1.attn.0.gnn_q.linears.1.weight")[0] if conv == "MLP"
+                    else _shape(sd, "layers.1.attn.0.gnn_q.weight")[1])
+        else:
+            adim = nhid
+        heads = 4
+        try:
+            heads = int(m.layers[0].attn[0].num_heads)
+        except Exception:
+            pass
+        return dict(model_type=t, max_feat_num=int(fin0), depth=depth, nhid=int(nhid), num_linears=int(num_linears), c_init=c_init,
+                    c_hid=int(c_hid0), c_final=int(c_last if depth > 1 else c_hid0), adim=int(adim), num_heads=heads, conv=conv,
+                    use_bn=bool(getattr(m, "use_bn", False)), is_cc=bool(getattr(m, "is_cc", False)))
+    raise ValueError(
+        f"Model Name <{t}> is unknown. Please select from [ScoreNetworkX, ScoreNetworkX_GMH, ScoreNetworkA, ScoreNetworkA_CC, ScoreNetworkA_Base_CC, ScoreNetworkF]")
+
+
 MODEL_TYPES = {c.model_type: c for c in (ScoreNetworkX, ScoreNetworkX_GMH, ScoreNetworkA, ScoreNetworkA_CC, ScoreNetworkA_Base_CC, ScoreNetworkF)}
 
 

@@ -15,6 +15,17 @@ Extra keyword-only knobs (not in the reference):
              code consumes it -- SURVEY.md section 7).  With keep_traj=False an empty list is returned.
   group      torch.distributed process group: all-reduce the six Langevin norm sums across ranks so that
              a sharded batch reproduces the single-process step size exactly.
+  seed, sample_offset, call_stride
+             Philox stream: the draws of sample b of a call are keyed by (seed, global sample index), with
+             global index = sample_offset + calls_so_far * call_stride + b.  The closure counts its calls, so the
+             chunks of the harness's divide_batch loop and its sampling rounds (sampler.py:1195-1211, 511-527: one
+             closure, called repeatedly) get disjoint sample indices -- every call draws fresh priors and noise.
+             call_stride defaults to B (B * world size when `group` is given: rank r passes sample_offset = r * B).
+             `pc_sampler.calls` can be read or reset by the caller.
+
+The models may be this package's weight containers (ccsd_amd.models) or the reference's own nn.Modules
+(possibly wrapped in DataParallel): hyper-parameters and weights are read through models.params_from_module
+and state_dict() (loader.py:619-657 builds them from the same pair).
 """
 from __future__ import annotations
 
@@ -63,7 +74,8 @@ def get_pc_sampler(sde_x: SDE, sde_adj: SDE, shape_x: Sequence[int], shape_adj: 
                    device: str = "cuda", is_cc: bool = False, sde_rank2: Optional[SDE] = None,
                    shape_rank2: Optional[Sequence[int]] = None, d_min: Optional[int] = None, d_max: Optional[int] = None,
                    *, rng: str = "philox", keep_traj: bool = False, seed: Optional[int] = None, group=None,
-                   sample_offset: int = 0, max_steps: Optional[int] = None, lib: Optional[_lib.Library] = None) -> Callable:
+                   sample_offset: int = 0, call_stride: Optional[int] = None, max_steps: Optional[int] = None,
+                   lib: Optional[_lib.Library] = None) -> Callable:
     s4 = predictor == "S4"          # reached through S4_solver only (get_predictor rejects the name, as the reference does)
     if not s4:
         get_predictor(predictor)
@@ -79,12 +91,14 @@ def get_pc_sampler(sde_x: SDE, sde_adj: SDE, shape_x: Sequence[int], shape_adj: 
             raise NotImplementedError("Discrete not supported")   # losses.py:69,161
         key = tuple(id(m) for m in models)
         if key not in cache:
+            from .models import params_from_module
+
             ms = [_unwrap(m) for m in models]
             for m in ms:
                 m.eval()
             args = []
             for m in ms:
-                args += [m.params, m.state_dict()]
+                args += [params_from_module(m), m.state_dict()]
             if not is_cc:
                 args += [None, None]
             cache.clear()
@@ -109,6 +123,17 @@ def get_pc_sampler(sde_x: SDE, sde_adj: SDE, shape_x: Sequence[int], shape_adj: 
         if flags.shape != (B, N):
             raise ValueError(f"init_flags must have shape {(B, N)}, got {tuple(flags.shape)}")
         the_seed = int(seed if seed is not None else torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        # global index of this call's first sample in the Philox stream: calls never share draws
+        stride = call_stride
+        if stride is None:
+            stride = B
+            if group is not None:
+                import torch.distributed as dist
+
+                if dist.is_available() and dist.is_initialized():
+                    stride = B * dist.get_world_size(group)
+        offset = int(sample_offset) + pc_sampler.calls * int(stride)
+        pc_sampler.calls += 1
         shapes = eng.shapes(B)
         nt = 3 if is_cc else 2
         state, scratch, result = eng.alloc_state(B), eng.alloc_state(B), eng.alloc_state(B)
@@ -117,15 +142,23 @@ def get_pc_sampler(sde_x: SDE, sde_adj: SDE, shape_x: Sequence[int], shape_adj: 
         diff_traj: List[List[torch.Tensor]] = []
         with torch.no_grad():
             if rng == "philox":
-                eng.init_state(flags, state, None, the_seed, sample_offset)
+                eng.init_state(flags, state, None, the_seed, offset)
                 traj = None
                 if keep_traj:
                     per = sum(s[1] * s[2] for s in shapes[:nt])
                     traj = torch.empty(diff_steps, per, device=dev)
-                if group is None:
-                    eng.run(flags, state, scratch, result, the_seed, sample_offset, 0, last, traj)
+                # the single C call covers n_steps == 1; more inner Langevin steps (solver.py:1131-1137) and the exact
+                # multi-GPU mode are driven step by step (same kernels, Philox noise generated in them)
+                stepwise = group is not None or (corrector == "Langevin" and n_steps != 1 and not s4)
+                if last == 0:
+                    for dst, src in zip(result, state):
+                        if dst is not None:
+                            dst.copy_(src)
+                elif not stepwise:
+                    eng.run(flags, state, scratch, result, the_seed, offset, 0, last, traj)
                 else:
-                    _stepwise(eng, flags, state, scratch, result, None, the_seed, sample_offset, last, diff_traj, keep_traj, group)
+                    traj = None
+                    _stepwise(eng, flags, state, scratch, result, None, the_seed, offset, last, diff_traj, keep_traj, group)
                 if traj is not None:
                     o = 0
                     for i in range(last):
@@ -144,8 +177,10 @@ def get_pc_sampler(sde_x: SDE, sde_adj: SDE, shape_x: Sequence[int], shape_adj: 
                     prior.append(sde_rank2.prior_sampling(shape_rank2).to(dev))
                 eng.init_state(flags, state, prior)
                 noise_fn = lambda k: draw(shapes[k], dev)
-                _stepwise(eng, flags, state, scratch, result, noise_fn, the_seed, sample_offset, last, diff_traj, keep_traj, group)
-        if rng != "philox" or group is not None:
+                _stepwise(eng, flags, state, scratch, result, noise_fn, the_seed, offset, last, diff_traj, keep_traj, group)
+        if last == 0:
+            out = state
+        elif rng != "philox" or stepwise:
             out = result if denoise else state
         else:
             out = result
@@ -206,4 +241,5 @@ def get_pc_sampler(sde_x: SDE, sde_adj: SDE, shape_x: Sequence[int], shape_adj: 
                 if dst is not None:
                     dst.copy_(src)
 
+    pc_sampler.calls = 0
     return pc_sampler

@@ -135,13 +135,14 @@ def sampler_from_golden(g, ckpt, case, lib, device, rng="torch_cpu", shape_overr
     sdes = []
     for p in names:
         c = dict(cfg["sde"][p])
+        c.update(sm.get("sde_override", {}).get(p, {}))        # subVP cases: no shipped checkpoint was trained with it
         if num_scales is not None:
             c["num_scales"] = num_scales
         sdes.append(loader.load_sde(c))
     models = [loader.load_model_from_ckpt(meta[f"params_{p}"], parts[p], device) for p in names]
     kw = dict(sde_x=sdes[0], sde_adj=sdes[1], shape_x=(B, N, Fd), shape_adj=(B, N, N), predictor=sm["predictor"],
               corrector=sm["corrector"], snr=sm["snr"], scale_eps=sm["scale_eps"], n_steps=sm["n_steps"],
-              probability_flow=False, continuous=True, denoise=True, eps=1e-4, device=device, rng=rng,
+              probability_flow=bool(sm.get("probability_flow", False)), continuous=True, denoise=True, eps=1e-4, device=device, rng=rng,
               max_steps=max_steps, lib=lib)
     if is_cc:
         d_min, d_max = cfg["data"]["d_min"], cfg["data"]["d_max"]
@@ -210,6 +211,60 @@ def case_philox_properties(lib, device, B=6, steps=3):
     rs = fn(*models, flags)
     for va, vs, p in zip(ra[:3], rs[:3], ["x", "adj", "rank2"]):
         assert torch.equal(va, vs), f"stepwise != fused loop for {p}"
+
+
+def case_philox_calls_are_independent(lib, device):
+    """One closure called repeatedly (the harness's divide_batch chunks and sampling rounds, sampler.py:1195-1211): every call
+    must draw from its own part of the Philox stream.  Checks: consecutive calls are uncorrelated; call k equals a fresh
+    closure started at sample_offset = k * B; two half-batch calls draw the priors of one full-batch call."""
+    g = load_golden("g5_ccsd_qm9_CC.npz")
+    flags = torch.from_numpy(g["flags"]).to(device)
+    flags = torch.ones_like(flags)                     # equal flags in every slot: only the noise distinguishes the samples
+    B = flags.shape[0]
+    fn, models, _, _ = sampler_from_golden(g, "ccsd_qm9_CC", "n1000_first2", lib, device, rng="philox", seed=11)
+    r0 = fn(*models, flags)
+    r1 = fn(*models, flags)
+    assert fn.calls == 2
+    for a, b, p in zip(r0[:3], r1[:3], ["x", "adj", "rank2"]):
+        a, b = a.cpu().flatten().double(), b.cpu().flatten().double()
+        corr = ((a - a.mean()) * (b - b.mean())).mean() / (a.std() * b.std())
+        assert abs(corr.item()) < (0.05 if p == "rank2" else 0.25), f"calls 0 and 1 share noise in {p}: corr {corr.item():.3f}"
+    fn2, models2, _, _ = sampler_from_golden(g, "ccsd_qm9_CC", "n1000_first2", lib, device, rng="philox", seed=11, sample_offset=B)
+    r2 = fn2(*models2, flags)
+    for a, b, p in zip(r1[:3], r2[:3], ["x", "adj", "rank2"]):
+        assert torch.equal(a, b), f"call 1 != fresh closure at sample_offset=B for {p}"
+    # priors (max_steps = 0 returns the masked prior): two calls of a B/2 closure == one call of a B closure
+    full, mf, _, _ = sampler_from_golden(g, "ccsd_qm9_CC", "n1000_first0", lib, device, rng="philox", seed=11)
+    half, mh, _, _ = sampler_from_golden(g, "ccsd_qm9_CC", "n1000_first0", lib, device, rng="philox", seed=11, shape_override=B // 2)
+    pf = full(*mf, flags)
+    ph = [half(*mh, flags[: B // 2]), half(*mh, flags[B // 2:])]
+    for k, p in enumerate(["x", "adj", "rank2"]):
+        assert torch.equal(pf[k], torch.cat([ph[0][k], ph[1][k]], 0)), f"divide_batch chunks do not tile the prior stream for {p}"
+
+
+def case_philox_langevin_nsteps2(lib, device):
+    """Production noise (in-kernel Philox) with two inner Langevin steps (sampler.n_steps: 2, solver.py:1131-1137): runs
+    through the step-wise driver; deterministic, masked, symmetric, and not the n_steps = 1 trajectory."""
+    g = load_golden("g5_ccsd_qm9_CC_langevin2.npz")
+    assert json.loads(str(g["sampler"]))["n_steps"] == 2
+    flags = torch.from_numpy(g["flags"]).to(device)
+    runs = []
+    for _ in range(2):
+        fn, models, _, names = sampler_from_golden(g, "ccsd_qm9_CC", "k4", lib, device, rng="philox", seed=31)
+        runs.append(fn(*models, flags))
+    ra, rb = runs
+    assert int(ra[3]) == 4 * (2 + 1)                                  # nfe = diff_steps * (n_steps + 1), solver.py:1173
+    for va, vb, p in zip(ra[:3], rb[:3], names):
+        assert torch.isfinite(va).all() and torch.equal(va, vb), f"philox n_steps=2 run not deterministic / finite for {p}"
+    x, adj, rank2 = (t.cpu() for t in ra[:3])
+    fl = flags.cpu()
+    assert torch.equal(x, O.mask_x(x, fl)) and torch.equal(adj, O.mask_adjs(adj, fl))
+    assert torch.equal(rank2, O.mask_rank2(rank2, 9, 3, 9, fl))
+    assert torch.allclose(adj, adj.transpose(-1, -2), atol=1e-5)
+    g1 = load_golden("g5_ccsd_qm9_CC.npz")                             # same checkpoint, n_steps = 1
+    fn1, m1, _, _ = sampler_from_golden(g1, "ccsd_qm9_CC", "k4", lib, device, rng="philox", seed=31, shape_override=flags.shape[0])
+    r1 = fn1(*m1, flags)
+    assert not torch.equal(r1[2], ra[2])
 
 
 class _FakeGroup:

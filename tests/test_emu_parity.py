@@ -59,6 +59,12 @@ def test_kat_small_general_paths(lib):
     ("s4_ccsd_qm9_CC", "ccsd_qm9_CC", "k6"),
     ("s4_gdss_community_small", "gdss_community_small", "k5"),
     ("s4_ccsd_enzymes_small_CC", "ccsd_enzymes_small_CC", "n1000_first2"),
+    # subVPSDE (Euler / Reverse), probability_flow + Reverse (CC and graph-only), subVP(x) + VE mixed with n_steps = 2
+    ("ccsd_qm9_CC_subvp_euler", "ccsd_qm9_CC", "k6"),
+    ("ccsd_qm9_CC_subvp_reverse", "ccsd_qm9_CC", "k6"),
+    ("ccsd_qm9_CC_pflow", "ccsd_qm9_CC", "k6"),
+    ("gdss_community_small_pflow", "gdss_community_small", "k5"),
+    ("ccsd_qm9_CC_subvp_mixed", "ccsd_qm9_CC", "k4"),
 ])
 def test_pc_sampler_identical_seed(lib, gname, ckpt, case):
     pc.case_pc_sampler_identical_seed(gname, ckpt, case, lib, DEV)
@@ -66,6 +72,14 @@ def test_pc_sampler_identical_seed(lib, gname, ckpt, case):
 
 def test_philox_properties(lib):
     pc.case_philox_properties(lib, DEV)
+
+
+def test_philox_calls_are_independent(lib):
+    pc.case_philox_calls_are_independent(lib, DEV)
+
+
+def test_philox_langevin_nsteps2(lib):
+    pc.case_philox_langevin_nsteps2(lib, DEV)
 
 
 def test_philox_prior_statistics(lib):

@@ -170,6 +170,12 @@ G5 = [
     ("s4_ccsd_enzymes_small_CC", "ccsd_enzymes_small_CC", ["k4", "k20", "n1000_first2"]),
     ("s4_ccsd_qm9_CC", "ccsd_qm9_CC", ["k6"]),
     ("s4_gdss_community_small", "gdss_community_small", ["k5"]),
+    # subVPSDE (Euler; Reverse through the base-class discretize), probability_flow + Reverse, subVP on x only with n_steps = 2
+    ("ccsd_qm9_CC_subvp_euler", "ccsd_qm9_CC", ["k6"]),
+    ("ccsd_qm9_CC_subvp_reverse", "ccsd_qm9_CC", ["k6"]),
+    ("ccsd_qm9_CC_pflow", "ccsd_qm9_CC", ["k6"]),
+    ("gdss_community_small_pflow", "gdss_community_small", ["k5"]),
+    ("ccsd_qm9_CC_subvp_mixed", "ccsd_qm9_CC", ["k4"]),
 ]
 
 
@@ -189,12 +195,13 @@ def oracle_sampler_from_golden(g, ckpt, case, noise=None):
     sdes = []
     for p in parts:
         c = dict(cfg["sde"][p])
+        c.update(sm.get("sde_override", {}).get(p, {}))
         if num_scales is not None:
             c["num_scales"] = num_scales
         sdes.append(O.load_sde(c))
     kw = dict(sde_x=sdes[0], sde_adj=sdes[1], shape_x=(B, N, Fd), shape_adj=(B, N, N), predictor=sm["predictor"],
               corrector=sm["corrector"], snr=sm["snr"], scale_eps=sm["scale_eps"], n_steps=sm["n_steps"],
-              probability_flow=False, continuous=True, denoise=True, eps=1e-4, n_diff_steps=max_steps, noise=noise)
+              probability_flow=bool(sm.get("probability_flow", False)), continuous=True, denoise=True, eps=1e-4, n_diff_steps=max_steps, noise=noise)
     if is_cc:
         d_min, d_max = cfg["data"]["d_min"], cfg["data"]["d_max"]
         kw.update(is_cc=True, sde_rank2=sdes[2], shape_rank2=(B, *O.get_rank2_dim(N, d_min, d_max)), d_min=d_min, d_max=d_max)

@@ -91,6 +91,11 @@ def export_checkpoint(name):
 
 
 def build_models(ck, is_cc):
+    # ScoreNetworkF.__init__ does `default_mask(rows).unsqueeze_(0)` on the lru-cached tensor (ScoreNetwork_F.py:135-141,
+    # cc_utils.py:932-942): every construction in one process adds a leading dimension to the shared mask and the third
+    # one makes pow_tensor_cc's bmm fail.  A fresh cache per construction gives each model the (1, E, E) mask of a
+    # first construction.
+    ref_cc.default_mask.cache_clear()
     ms = [ref_loader.load_model_from_ckpt(ck["params_x"], ck["x_state_dict"], "cpu"),
           ref_loader.load_model_from_ckpt(ck["params_adj"], ck["adj_state_dict"], "cpu")]
     if is_cc:
@@ -215,9 +220,23 @@ def g6_masks():
     np.savez_compressed(os.path.join(GOLD, "g6_masks_utils.npz"), **out)
 
 
-def g5_pc_runs(name, ck, is_cc, B, counts, sampler_cfg, cases, seed):
+def g5_pc_runs(name, ck, is_cc, B, counts, sampler_cfg, cases, seed, min_dist=0.0):
+    """Wrapper: when `min_dist` is given, the seed is advanced (by 100) until every case's final adjacency stays at least
+    that far from every quantisation threshold, so that the bit-exact integer comparison has a margin."""
+    for attempt in range(20):
+        d = _g5_pc_runs(name, ck, is_cc, B, counts, sampler_cfg, cases, seed + 100 * attempt)
+        if d >= min_dist:
+            return
+        print("g5", name, "seed", seed + 100 * attempt, "too close to a threshold:", d)
+    raise RuntimeError("no seed with the requested threshold margin")
+
+
+def _g5_pc_runs(name, ck, is_cc, B, counts, sampler_cfg, cases, seed):
     """G4/G5: end-to-end sampler runs; inputs are regenerated from the seed by the consumer
-    (prior + every in-loop draw come from torch's global CPU generator in reference order)."""
+    (prior + every in-loop draw come from torch's global CPU generator in reference order).
+    sampler_cfg may carry `probability_flow` (default False) and `sde_override` = {part: sde dict} replacing the
+    checkpoint's SDE for that part (subVP has no shipped checkpoint: the weights are just weights, the SDE
+    arithmetic is what the case pins)."""
     cfg = ck["model_config"]
     N, Fd = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
     d_min, d_max = (cfg["data"]["d_min"], cfg["data"]["d_max"]) if is_cc else (None, None)
@@ -229,12 +248,14 @@ def g5_pc_runs(name, ck, is_cc, B, counts, sampler_cfg, cases, seed):
         sdes = []
         for p in ["x", "adj"] + (["rank2"] if is_cc else []):
             c = dict(cfg["sde"][p])
+            c.update(sampler_cfg.get("sde_override", {}).get(p, {}))
             if num_scales is not None:
                 c["num_scales"] = num_scales
             sdes.append(ref_loader.load_sde(refshim.EasyDict(c)))
         kw = dict(sde_x=sdes[0], sde_adj=sdes[1], shape_x=(B, N, Fd), shape_adj=(B, N, N),
                   predictor=sampler_cfg["predictor"], corrector=sampler_cfg["corrector"], snr=sampler_cfg["snr"],
-                  scale_eps=sampler_cfg["scale_eps"], n_steps=sampler_cfg["n_steps"], probability_flow=False,
+                  scale_eps=sampler_cfg["scale_eps"], n_steps=sampler_cfg["n_steps"],
+                  probability_flow=bool(sampler_cfg.get("probability_flow", False)),
                   continuous=True, denoise=True, eps=1e-4, device="cpu")
         if is_cc:
             E, K = ref_cc.get_rank2_dim(N, d_min, d_max)
@@ -267,6 +288,7 @@ def g5_pc_runs(name, ck, is_cc, B, counts, sampler_cfg, cases, seed):
         out[f"{case}/min_thr_dist"] = np.array((res[1][..., None] - thr).abs().min().item())
         print("g5", name, case, "adj absmax", float(res[1].abs().max()), "min thr dist", float(out[f"{case}/min_thr_dist"]))
     np.savez_compressed(os.path.join(GOLD, f"g5_{name}.npz"), **out)
+    return min(float(out[f"{case}/min_thr_dist"]) for case in cases)
 
 
 def kat_small_models():
@@ -416,6 +438,27 @@ def main():
         g5_pc_runs("s4_ccsd_qm9_CC", cks["ccsd_qm9_CC"], True, 4, [9, 8, 7, 5], s4, {"k6": (6, None)}, seed=7)
         g5_pc_runs("s4_gdss_community_small", cks["gdss_community_small"], False, 4, [20, 18, 14, 12], s4,
                    {"k5": (5, None)}, seed=9)
+    if not only or "sdevar" in only:
+        # subVPSDE (sde.py:672-786; Euler and, through the base-class discretize sde.py:93-111, Reverse) and
+        # probability_flow=True with the Reverse predictor (sde.py:329-340).  No shipped config selects them.
+        sub = dict(type="subVP", beta_min=0.1, beta_max=1.0)
+        subv = {"x": sub, "adj": sub, "rank2": sub}
+        g5_pc_runs("ccsd_qm9_CC_subvp_euler", cks["ccsd_qm9_CC"], True, 3, [9, 7, 5],
+                   dict(predictor="Euler", corrector="Langevin", snr=0.2, scale_eps=0.7, n_steps=1, sde_override=subv),
+                   {"k6": (6, None)}, seed=21, min_dist=5e-3)
+        g5_pc_runs("ccsd_qm9_CC_subvp_reverse", cks["ccsd_qm9_CC"], True, 3, [9, 7, 5],
+                   dict(predictor="Reverse", corrector="Langevin", snr=0.2, scale_eps=0.7, n_steps=1, sde_override=subv),
+                   {"k6": (6, None)}, seed=22, min_dist=5e-3)
+        g5_pc_runs("ccsd_qm9_CC_pflow", cks["ccsd_qm9_CC"], True, 3, [9, 8, 6],
+                   dict(predictor="Reverse", corrector="Langevin", snr=0.2, scale_eps=0.7, n_steps=1, probability_flow=True),
+                   {"k6": (6, None)}, seed=23, min_dist=5e-3)
+        g5_pc_runs("gdss_community_small_pflow", cks["gdss_community_small"], False, 3, [20, 16, 12],
+                   dict(predictor="Reverse", corrector="None", snr=0.05, scale_eps=0.7, n_steps=1, probability_flow=True),
+                   {"k5": (5, None)}, seed=24, min_dist=5e-3)
+        # mixed: subVP on x only, the checkpoint's VE on adj / rank2, Reverse + Langevin with two inner steps
+        g5_pc_runs("ccsd_qm9_CC_subvp_mixed", cks["ccsd_qm9_CC"], True, 2, [9, 6],
+                   dict(predictor="Reverse", corrector="Langevin", snr=0.2, scale_eps=0.7, n_steps=2, sde_override={"x": sub}),
+                   {"k4": (4, None)}, seed=25, min_dist=5e-3)
     if not only or "gmh" in only:
         kat_gmh_models()
     if not only or "base" in only:
