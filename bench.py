@@ -4,24 +4,29 @@ Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 
 N=9, F=4, E=36, K=466, batch 1024 complexes per GPU, VE SDEs, Reverse predictor + Langevin corrector
 (snr 0.2, scale_eps 0.7, n_steps 1), eps 1e-4, QM9 node-count flag mix, in-kernel Philox noise.
 A "step" is one PC step (corrector + predictor = 2 joint score evaluations + 2 state updates) over the
-whole batch.  value = complexes / (time of 1000 such steps) = B_total / (ms_per_step).
+whole batch.  value = complexes / (time of 1000 such steps) = B_total / ms_per_step.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload qm9_CC|community_small_CC|community_small|zinc250k|enzymes_small_CC]
-(the default workload is the metric's; the others are BASELINE.json's remaining configs, same JSON line)
-N > 1 is launched by torch.distributed.run, one rank per GPU; the batch dimension is sharded (weak
-scaling, 1024 per rank, per-shard Langevin norms like the reference's divide_batch) with no per-step
-collective and one RCCL all-gather of the samples at the end, inside the timed region.
+The timed region is the reference's own span (sampler.py:1185-1211: init_flags on the host, then the call of
+the closure load_sampling_fn returned): `sampling_fn(model_x, model_adj, model_rank2, init_flags)` through
+ccsd_amd.loader.load_sampling_fn, i.e. prior draw (ccsd_init_state), K PC steps, and -- for N > 1 -- the final
+all-gather of the samples, device-synchronised.  Checkpoint load, plan creation and quantisation are outside,
+as they are in the reference.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload qm9_CC|community_small_CC|...]
+`--gpus N` (N > 1) without a launcher starts N fresh worker processes itself (torch.distributed.run on
+127.0.0.1, before this process touches a GPU) and relays rank 0's JSON line; under torch.distributed.run it
+is a rank.  The batch dimension is sharded (weak scaling, 1024 complexes per rank, per-shard Langevin norms
+like the reference's divide_batch, Philox keyed by the global sample index); no per-step collective, one RCCL
+all-gather of the samples at the end, inside the timed region.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -30,27 +35,28 @@ QM9_HIST = {9: 10949, 8: 1757, 7: 294, 6: 60, 5: 15, 4: 5, 3: 1, 2: 1}   # data/
 COMMUNITY_HIST = {12: 29, 14: 14, 16: 23, 18: 25, 20: 9}                 # data/community_small.pkl
 PEAK_F32_MFMA_TFLOPS = 157.3                              # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_HBM_GBPS = 8000.0
+MFMA_FLOP = 2048                                          # one wave-level v_mfma_f32_16x16x4_f32
 # Workloads = BASELINE.json configs.  flop_* : dense-as-written GEMM FLOPs / complex / forward (FlopCounterMode on
 # the reference).  The default (the configuration the metric is quoted on) is qm9_CC, B = 1024 per GPU.
 WORKLOADS = {
-    "qm9_CC": dict(ckpt="ccsd_qm9_CC", batch=1024, hist=QM9_HIST, predictor="Reverse", corrector="Langevin", snr=0.2, scale_eps=0.7,
+    "qm9_CC": dict(ckpt="ccsd_qm9_CC", data="QM9", batch=1024, hist=QM9_HIST, predictor="Reverse", corrector="Langevin", snr=0.2, scale_eps=0.7,
                    flop_x=71_424, flop_a=10_710_522, flop_f=3_220_992,
                    desc="qm9_CC N=9 F=4 E=36 K=466, B={B} per GPU, VE x3, Reverse+Langevin snr=0.2 scale_eps=0.7 n_steps=1, 1000 scales"),
-    "community_small_CC": dict(ckpt="ccsd_community_small_CC", batch=512, hist=COMMUNITY_HIST, predictor="Euler", corrector="Langevin",
+    "community_small_CC": dict(ckpt="ccsd_community_small_CC", data="community_small_CC", batch=512, hist=COMMUNITY_HIST, predictor="Euler", corrector="Langevin",
                                snr=0.05, scale_eps=0.7, flop_x=3_014_720, flop_a=192_613_760, flop_f=168_081_600,
                                desc="community_small_CC N=20 F=11 E=190 K=1140, B={B} per GPU, VP x3, Euler+Langevin snr=0.05 scale_eps=0.7, 1000 scales"),
-    "community_small": dict(ckpt="gdss_community_small", batch=16, hist=COMMUNITY_HIST, predictor="Euler", corrector="Langevin",
+    "community_small": dict(ckpt="gdss_community_small", data="community_small", batch=16, hist=COMMUNITY_HIST, predictor="Euler", corrector="Langevin",
                             snr=0.05, scale_eps=0.7, flop_x=2_952_960, flop_a=16_628_480, flop_f=0,
                             desc="community_small (graph-only) N=20 F=10, B={B} per GPU, VP x2, Euler+Langevin snr=0.05 scale_eps=0.7, 1000 scales"),
-    "zinc250k": dict(ckpt="gdss_zinc250k", batch=256, hist={38: 1, 30: 2, 24: 4, 23: 4, 20: 2}, predictor="Reverse", corrector="Langevin",
+    "zinc250k": dict(ckpt="gdss_zinc250k", data="ZINC250k", batch=256, hist={38: 1, 30: 2, 24: 4, 23: 4, 20: 2}, predictor="Reverse", corrector="Langevin",
                      snr=0.2, scale_eps=0.9, flop_x=945_440, flop_a=58_489_296, flop_f=0,
                      desc="zinc250k (graph-only substitute for the infeasible zinc250k_CC, SURVEY 8d 5a) N=38 F=9, B={B} per GPU, "
                           "VP(x)/VE(adj), Reverse+Langevin snr=0.2 scale_eps=0.9, 1000 scales; synthetic node-count mix"),
-    "qm9_Base_CC": dict(ckpt="ccsd_qm9_Base_CC", batch=1024, hist=QM9_HIST, predictor="Reverse", corrector="Langevin", snr=0.2,
+    "qm9_Base_CC": dict(ckpt="ccsd_qm9_Base_CC", data="QM9", batch=1024, hist=QM9_HIST, predictor="Reverse", corrector="Langevin", snr=0.2,
                         scale_eps=0.7, flop_x=None, flop_a=None, flop_f=None,
                         desc="qm9_Base_CC (ScoreNetworkA_Base_CC ablation) N=9 F=4 E=36 K=466, B={B} per GPU, VE x3, Reverse+Langevin "
                              "snr=0.2 scale_eps=0.7 n_steps=1, 1000 scales"),
-    "enzymes_small_CC": dict(ckpt="ccsd_enzymes_small_CC", batch=64, hist={12: 6, 11: 5, 10: 5, 9: 4, 8: 4, 6: 3, 4: 2}, predictor="S4",
+    "enzymes_small_CC": dict(ckpt="ccsd_enzymes_small_CC", data="ENZYMES_small_CC", batch=64, hist={12: 6, 11: 5, 10: 5, 9: 4, 8: 4, 6: 3, 4: 2}, predictor="S4",
                              corrector="None", snr=0.15, scale_eps=0.7, flop_x=None, flop_a=None, flop_f=None,
                              desc="ENZYMES_small_CC N=12 F=10 E=66 K=715, B={B} per GPU, VP(x)/VE/VE, S4 solver snr=0.15 scale_eps=0.7, 1000 scales"),
 }
@@ -59,20 +65,42 @@ WORKLOADS = {
 # half-step (HBM bound): fused k_r2 when the block fits LDS (qm9_CC), k_gemm_h + k_gemm_p + k_hf_score otherwise.
 KERNEL_BOUND = {"k_xa": "mfma", "k_r2": "hbm", "k_hf_score": "hbm", "k_gemm_h": "mfma", "k_gemm_p": "mfma", "k_langevin_apply": "hbm",
                 "k_s4_apply": "hbm"}
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+KERNEL_NAMES = ["k_xa", "k_r2", "k_hf_score", "k_gemm_h", "k_gemm_p", "k_langevin_apply", "k_s4_apply"]
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r02_pmc.json", "r01_pmc_traffic.json")]   # newest first
+KERNEL_SOURCES = [os.path.join(ROOT, "ccsd_amd", "csrc", f) for f in ("ccsd_kernels.h", "ccsd_attn_stack.inc", "ccsd_plan.h", "ccsd_api.h")]
 
 
-def pmc_traffic(kernel: str):
-    """HBM bytes per launch from the committed PMC passes (FETCH_SIZE doubled: gfx950 reports half of a wide
-    coalesced read, MI355X_MICROARCH.md section HBM; WRITE_SIZE as is); None when the file is absent."""
-    try:
-        d = json.load(open(PMC_FILE))[kernel]
-        return {"bytes": d["hbm_bytes_per_launch"], "source": "profiles/r01_pmc_traffic.json"}
-    except Exception:
-        return None
+def kernel_source_hash() -> str:
+    """Identifies the kernel source a PMC pass was collected on (tools/pmc_traffic.py records it next to the counters)."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
-def hist_flags(B: int, N: int, hist: dict, seed: int = 42) -> torch.Tensor:
+def pmc_counters(workload: str, kernel: str):
+    """Per-launch PMC means of `kernel` from the newest committed rocprofv3 --pmc passes (separate runs: FETCH_SIZE doubled
+    -- gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md HBM section --, WRITE_SIZE as is).  They are NOT
+    measured in this run: the object says which file they come from and whether the kernel source has changed since."""
+    for path in PMC_FILES:
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        meta = d.get("_meta", {})
+        if meta.get("workload", "qm9_CC") != workload or kernel not in d:
+            continue
+        src = meta.get("kernel_src_sha16")
+        return {"counters": d[kernel], "source": os.path.relpath(path, ROOT), "collected_at_commit": meta.get("commit", "round 1 (5cbf17b)"),
+                "stale": (src != kernel_source_hash()) if src else True}
+    return None
+
+
+def hist_flags(B: int, N: int, hist: dict, seed: int = 42):
+    import numpy as np
+    import torch
+
     rs = np.random.RandomState(seed)
     ks = np.array(list(hist.keys()))
     p = np.array(list(hist.values()), dtype=np.float64)
@@ -81,10 +109,6 @@ def hist_flags(B: int, N: int, hist: dict, seed: int = 42) -> torch.Tensor:
     for b, c in enumerate(counts):
         f[b, :c] = 1.0
     return f
-
-
-def qm9_flags(B: int, seed: int = 42) -> torch.Tensor:
-    return hist_flags(B, 9, QM9_HIST, seed)
 
 
 def log(msg: str):
@@ -103,40 +127,43 @@ def host_threads() -> int:
     return max(1, min(n, 16))
 
 
-def load_qm9():
-    from tests.helpers import load_ckpt_np
+def load_workload(wname: str, device):
+    """Checkpoint -> (ckpt dict, models, names) through the product's own loader (ccsd_amd.loader.load_ckpt reads the
+    packaged neutral-format copy of the shipped checkpoint)."""
+    from ccsd_amd import loader
 
-    return load_ckpt_np("ccsd_qm9_CC")
-
-
-def workload_setup(name: str):
-    """(meta, parts, names, N, F, d_min, d_max, is_cc) of a workload's checkpoint."""
-    from tests.helpers import load_ckpt_np
-
-    meta, parts = load_ckpt_np(WORKLOADS[name]["ckpt"])
-    cfg, is_cc = meta["config"], meta["is_cc"]
-    N, F = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
-    d_min, d_max = (cfg["data"]["d_min"], cfg["data"]["d_max"]) if is_cc else (0, 0)
+    wl = WORKLOADS[wname]
+    is_cc = wname not in ("community_small", "zinc250k")
+    ck = loader.load_ckpt({"ckpt": wl["ckpt"], "data": {"data": wl["data"]}, "folder": ROOT}, device, is_cc=is_cc)
     names = ["x", "adj"] + (["rank2"] if is_cc else [])
-    return meta, parts, names, N, F, d_min, d_max, is_cc
+    return ck, names, is_cc
 
 
-def cpu_baseline(wname: str, B: int, steps: int = 2, warm: int = 1):
-    """The oracle (CPU restatement certified bit-identical to the reference) timed on the host cores, on a bounded
-    sample of the same workload: the full batch, `steps` PC steps after `warm` warm-up, scaled to 1000 steps."""
+def cpu_baseline(wname: str, B: int, budget_s: float = 25.0):
+    """The oracle (CPU restatement certified bit-identical to the reference) timed on the host cores, on a bounded sample of
+    the same workload: the full batch, up to 10 PC steps after 1 warm-up step (fewer when a step is so slow that 10 would
+    exceed ~25 s), scaled to 1000 steps."""
+    import torch
+
+    from ccsd_amd import loader
     from oracle import ccsd_oracle as O
 
     wl = WORKLOADS[wname]
     threads = host_threads()
     torch.set_num_threads(threads)
     log(f"cpu_baseline: oracle on {threads} host threads, {wname} B={B}")
-    meta, parts, names, N, F, d_min, d_max, is_cc = workload_setup(wname)
-    cfg = meta["config"]
+    ck, names, is_cc = load_workload(wname, "cpu")
+    cfg = ck["config"]
+    data = cfg["data"]
+    N, F = data["max_node_num"], data["max_feat_num"]
+    d_min, d_max = (data["d_min"], data["d_max"]) if is_cc else (0, 0)
     so = [O.load_sde(cfg["sde"][p]) for p in names]
+    # requires_grad mirrors nn.Parameter: ATen's linear() then takes the same CPU kernel as the reference's modules
+    w = {p: {k: v.clone().requires_grad_(True) for k, v in ck[f"{p}_state_dict"].items()} for p in names}
     if is_cc:
-        nets = [(lambda x, a, r, f, p=p: O.run_network(meta[f"params_{p}"], parts[p], x, a, r, f)) for p in names]
+        nets = [(lambda x, a, r, f, p=p: O.run_network(ck[f"params_{p}"], w[p], x, a, r, f)) for p in names]
     else:
-        nets = [(lambda x, a, f, p=p: O.run_network(meta[f"params_{p}"], parts[p], x, a, None, f)) for p in names]
+        nets = [(lambda x, a, f, p=p: O.run_network(ck[f"params_{p}"], w[p], x, a, None, f)) for p in names]
     flags = hist_flags(B, N, wl["hist"])
     kw = dict(sde_x=so[0], sde_adj=so[1], shape_x=(B, N, F), shape_adj=(B, N, N), snr=wl["snr"], scale_eps=wl["scale_eps"],
               continuous=True, denoise=True, eps=1e-4, keep_traj=False)
@@ -148,14 +175,16 @@ def cpu_baseline(wname: str, B: int, steps: int = 2, warm: int = 1):
         make = lambda n: O.get_pc_sampler(n_diff_steps=n, predictor=wl["predictor"], corrector=wl["corrector"], n_steps=1, **kw)
     torch.manual_seed(0)
     t0 = time.perf_counter()
-    make(warm)(*nets, flags)
-    log(f"cpu_baseline: warm-up step took {time.perf_counter() - t0:.1f} s")
+    make(1)(*nets, flags)
+    tw = time.perf_counter() - t0
+    steps = max(2, min(10, int(budget_s / max(tw, 1e-3))))
+    log(f"cpu_baseline: warm-up step took {tw:.1f} s -> timing {steps} steps")
     t0 = time.perf_counter()
     make(steps)(*nets, flags)
     dt = (time.perf_counter() - t0) / steps
     log(f"cpu_baseline: {dt:.2f} s / PC step")
     return {"value": B / (dt * 1000.0), "unit": "complexes/s at 1000 PC steps", "cores": threads, "kind": "port",
-            "sample": f"oracle (torch CPU, {threads} threads), {wname} B={B}, {steps} PC steps after {warm} warm-up, scaled to 1000 steps"}
+            "sample": f"oracle (torch CPU, {threads} threads), {wname} B={B}, {steps} PC steps after 1 warm-up step, scaled to 1000 steps"}
 
 
 def kernel_work(wname: str, kname: str, E: int, K: int):
@@ -171,20 +200,33 @@ def kernel_work(wname: str, kname: str, E: int, K: int):
     return None, None, ""
 
 
-def roofline_obj(wname, kname, ktimes, B, dt, E, K):
-    if kname not in ktimes or not ktimes[kname][0]:
+def roofline_obj(wname, kname, kt, B, dt, E, K):
+    """kt = (bracketed launches, their summed ms, all launches in the timed region)."""
+    sampled, kms, total = kt
+    if not sampled:
         return None
-    launches, kms = ktimes[kname]
-    avg_s = kms / launches * 1e-3
+    avg_s = kms / sampled * 1e-3
     flops, nbytes, what = kernel_work(wname, kname, E, K)
-    tr = pmc_traffic(kname) if wname == "qm9_CC" else None
+    pmc = pmc_counters(wname, kname)
     bound = KERNEL_BOUND[kname]
-    o = {"kernel": kname, "bound": bound, "launches": launches, "avg_launch_us": avg_s * 1e6,
-         "share_of_step": kms / (dt * 1e3), "traffic": tr["bytes"] if tr else None}
+    o = {"kernel": kname, "bound": bound, "launches": total, "launches_timed": sampled, "avg_launch_us": avg_s * 1e6,
+         "share_of_step": total * avg_s / dt, "traffic": None}
+    if pmc:
+        c = pmc["counters"]
+        o["traffic"] = c.get("hbm_bytes_per_launch")
+        o["traffic_source"] = f"{pmc['source']} (rocprofv3 --pmc passes collected at {pmc['collected_at_commit']}; replayed, not measured in this run)"
+        o["traffic_stale"] = pmc["stale"]
+        mf = c.get("SQ_INSTS_VALU_MFMA_F32")
+        if mf:
+            ex = mf * MFMA_FLOP / avg_s / 1e12
+            o["executed_mfma_tflops"] = ex
+            o["executed_frac"] = ex / PEAK_F32_MFMA_TFLOPS       # what the matrix pipe actually did (dead GEMMs skipped, padding included)
     if bound == "mfma" and flops:
         a = flops * B / avg_s / 1e12
         o.update(achieved=a, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=a / PEAK_F32_MFMA_TFLOPS,
-                 note=f"achieved = {what} per launch / mean launch time (HIP events on the launch stream); fp32 MFMA peak")
+                 note=f"achieved = {what} per launch / mean launch time (HIP events on the launch stream): the as-written model-FLOPs "
+                      "convention, which counts GEMMs the kernel legally skips; executed_frac = MFMA instructions (PMC) x 2048 FLOP / time "
+                      "is the pipe utilisation; fp32 MFMA peak")
     elif bound == "hbm" and nbytes:
         a = nbytes * B / avg_s / 1e9
         o.update(achieved=a, peak=PEAK_HBM_GBPS, unit="GB/s", frac=a / PEAK_HBM_GBPS,
@@ -194,7 +236,7 @@ def roofline_obj(wname, kname, ktimes, B, dt, E, K):
     return o
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -204,94 +246,134 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not time the kernels with HIP events")
     ap.add_argument("--event-stride", type=int, default=17, help="bracket every n-th launch of a kernel with HIP events (odd: a kernel's norms / predictor launches alternate)")
-    args = ap.parse_args()
+    ap.add_argument("--emulate", action="store_true",
+                    help="TEST ONLY: run the product code over the host emulation of the kernels on the CPU with gloo (exercises the launcher / "
+                         "sharding / reporting path on a GPU-less box; the numbers mean nothing)")
+    return ap.parse_args(argv)
 
+
+def main():
+    # stdout carries exactly one line (rank 0's JSON); everything else the product prints (the reference's own
+    # `print(" ")` after the loop, "... loaded" of load_ckpt) goes to stderr
+    import contextlib
+
+    real_stdout = sys.stdout
+    with contextlib.redirect_stdout(sys.stderr):
+        _main(real_stdout)
+
+
+def _main(real_stdout):
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # self-launch: N fresh rank processes, started before this process has made any GPU call (it never makes one)
+        from ccsd_amd.distributed import launch_workers
+
+        rc = launch_workers([os.path.abspath(__file__)] + sys.argv[1:], args.gpus, relay=real_stdout)
+        if rc != 0:
+            log(f"a worker failed (exit code {rc})")
+        sys.exit(rc)
+
+    import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from ccsd_amd import distributed
+
+    if args.emulate:
+        os.environ.setdefault("CUDA_VISIBLE_DEVICES", "")
+    rank, world, dev = distributed.init("gloo" if args.emulate else None)
+    if args.emulate and os.environ.get("CCSD_BENCH_FAIL_RANK") == str(rank):     # tests/test_bench_launcher.py: a dying worker
+        os._exit(7)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    torch.cuda.set_device(local)
-    dev = f"cuda:{local}"
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    lib = None
+    if args.emulate:
+        from tests.emu_util import emu_library
 
-    import __graft_entry__ as ge
+        torch.set_num_threads(max(1, host_threads() // world))
+        lib = emu_library() if rank == 0 else None
+        if world > 1:
+            dist.barrier()
+        lib = lib or emu_library()
+    else:
+        import __graft_entry__ as ge
 
-    if rank == 0:
-        ge.build()
-    if world > 1:
-        dist.barrier()
+        if rank == 0:
+            ge.build()
+        if world > 1:
+            dist.barrier()
     from ccsd_amd import loader
-    from ccsd_amd.engine import PCEngine
 
     wname = args.workload
     wl = WORKLOADS[wname]
-    meta, parts, names, N, F, d_min, d_max, is_cc = workload_setup(wname)
-    cfg = meta["config"]
-    sdes = [loader.load_sde(cfg["sde"][p]) for p in names]
+    ck, names, is_cc = load_workload(wname, dev)
+    cfgt = ck["config"]
+    data = cfgt["data"]
+    N, F = data["max_node_num"], data["max_feat_num"]
+    d_min, d_max = (data["d_min"], data["d_max"]) if is_cc else (None, None)
     B = args.batch or wl["batch"]
-    eng = PCEngine(meta["params_x"], parts["x"], meta["params_adj"], parts["adj"], meta.get("params_rank2"), parts.get("rank2"),
-                   N=N, F=F, is_cc=is_cc, d_min=d_min, d_max=d_max, sdes=sdes, predictor=wl["predictor"], corrector=wl["corrector"],
-                   snr=wl["snr"], scale_eps=wl["scale_eps"], n_steps=1, probability_flow=False, denoise=True, eps=1e-4, device=dev,
-                   batch_hint=B)
-    E, K = eng.E, eng.K
-    flags = hist_flags(B * world, N, wl["hist"])[rank * B:(rank + 1) * B].to(dev)
-    state, scratch, result = eng.alloc_state(B), eng.alloc_state(B), eng.alloc_state(B)
-    outs = [t for t in result if t is not None]
-    gathered = [torch.empty((world,) + tuple(t.shape), device=dev) for t in outs] if world > 1 else None
-    seed, off = 42, rank * B
-    diff = eng.diff_steps
+    total = B * world
+    data["batch_size"] = total                      # generic datasets take the batch from the training config (loader.py:387-416)
+    models = [loader.load_model_from_ckpt(ck[f"params_{p}"], ck[f"{p}_state_dict"], dev) for p in names]
+    module = dict(predictor=wl["predictor"], corrector=wl["corrector"], snr=wl["snr"], scale_eps=wl["scale_eps"], n_steps=1)
+    sample = dict(n_samples=total, probability_flow=False, noise_removal=True, eps=1e-4)
+    # the drop-in seam: load_sampling_fn -> sampling_fn(models..., init_flags); sharded over the ranks when N > 1
+    sampling_fn = distributed.load_sampling_fn_sharded(cfgt, module, sample, dev, is_cc=is_cc, d_min=d_min, d_max=d_max, exact=False,
+                                                       rng="philox", seed=42, lib=lib)
+    inner = getattr(sampling_fn, "inner", sampling_fn)
+    flags = hist_flags(total, N, wl["hist"]).to(dev)
+    diff = loader.load_sde(cfgt["sde"]["adj"]).N
 
-    def run_steps(k0, k1):
-        s = k0
-        while s < k1:       # K may exceed the 1000 scales: wrap around
-            a, b = s % diff, min(diff, s % diff + (k1 - s))
-            eng.run(flags, state, scratch, result, seed, off, a, b)
-            s += b - a
+    def run(k):
+        out = None
+        while k > 0:                                 # K may exceed the 1000 scales: further calls of the closure
+            n = min(k, diff)
+            inner.max_steps = n
+            out = sampling_fn(*models, flags)
+            k -= n
+        return out
 
     def sync():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if dev != "cpu":
+            torch.cuda.synchronize()
 
-    log(f"rank {rank}/{world}: {wname} plan built, B={B} per GPU, warm-up {args.warmup} steps")
-    eng.init_state(flags, state, None, seed, off)
-    run_steps(0, args.warmup)
-    eng.init_state(flags, state, None, seed, off)          # the timed region starts from a fresh prior, inputs resident
-    knames = ["k_xa", "k_r2", "k_hf_score", "k_gemm_h", "k_gemm_p", "k_langevin_apply", "k_s4_apply"]
+    log(f"rank {rank}/{world}: {wname}, B={B} per GPU, warm-up {args.warmup} steps (builds the plan)")
+    run(max(1, args.warmup))
+    eng = inner.engine()
+    E, K = eng.E, eng.K
     if not args.no_kernel_events:
-        for kname in knames:                               # HIP events around those kernels' launches, on their stream
+        for kname in KERNEL_NAMES:                   # HIP events around those kernels' launches, on their stream
             eng.profile_kernel(kname)
         # every n-th launch: dense bracketing costs ~6 % of the step.  Short runs bracket more densely so that the roofline
         # object always has samples.
         eng.profile_stride(args.event_stride if args.steps >= 200 else 3 if args.steps >= 20 else 1)
     sync()
     t0 = time.perf_counter()
-    run_steps(0, args.steps)
-    if world > 1:                                          # final sample collection
-        for g, t in zip(gathered, outs):
-            dist.all_gather_into_tensor(g, t)
+    outs = run(args.steps)
     sync()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = tmax.item()
+        dt = tmax.item()
     log(f"timed region: {args.steps} steps in {dt:.3f} s")
-    ktimes = {k: eng.profile_read(k) for k in knames} if not args.no_kernel_events else {}
-    eng.profile_kernel(None)
-    ok = all(torch.isfinite(t).all().item() for t in outs)
+    ktimes = {}
+    if not args.no_kernel_events:
+        for k in KERNEL_NAMES:
+            tot = eng.profile_launches(k)
+            n, ms = eng.profile_read(k)
+            ktimes[k] = (n, ms, tot)
+        eng.profile_kernel(None)
+    nt = 3 if is_cc else 2
+    ok = all(torch.isfinite(t).all().item() for t in outs[:nt]) and all(t.shape[0] == total for t in outs[:nt])
 
     if rank == 0:
         ms_per_step = dt * 1e3 / args.steps
-        value = (B * world) / (ms_per_step)                # complexes per (1000 steps x ms_per_step / 1000 s)
-        units_per_s = B * world * args.steps / dt          # complex-steps per second
-        evals = 1 if wl["predictor"] == "S4" else 2        # joint score evaluations per step
-        live = sorted((k for k in ktimes if ktimes[k][0]), key=lambda k: -ktimes[k][1])
+        value = total / ms_per_step                  # complexes per (1000 steps x ms_per_step / 1000 s)
+        units_per_s = total * args.steps / dt        # complex-steps per second
+        evals = 1 if wl["predictor"] == "S4" else 2  # joint score evaluations per step
+        live = sorted((k for k in ktimes if ktimes[k][0]), key=lambda k: -(ktimes[k][2] * ktimes[k][1] / ktimes[k][0]))
         dominant = live[0] if live else None
         state_floats = N * F + N * N + E * K
         line = {
@@ -299,22 +381,29 @@ def main():
             "value": value, "unit": "complexes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": f"synthetic (node-count histogram flags, Philox N(0,1) prior/noise; shipped {wl['ckpt']} weights)",
-            "config": {"workload": wl["desc"].format(B=B), "global_batch": B * world,
-                       "parallelism": f"batch-sharded x{world}, per-shard Langevin norms, all-gather at end", "finite": ok},
-            "roofline": roofline_obj(wname, dominant, ktimes, B, dt, E, K) if dominant else None,
+            "config": {"workload": wl["desc"].format(B=B), "global_batch": total,
+                       "parallelism": f"batch-sharded x{world}, per-shard Langevin norms, all-gather at end",
+                       "timed_region": "load_sampling_fn -> sampling_fn(models, init_flags): prior draw + PC steps (+ final all-gather)",
+                       "finite": ok},
+            "roofline": roofline_obj(wname, dominant, ktimes[dominant], B, dt, E, K) if dominant else None,
             "cpu_baseline": None,
         }
+        if args.emulate:
+            line["data"] = "EMULATION (host CPU, test of the launcher path only): " + line["data"]
         for k in live[1:]:
-            line[f"roofline_{k}"] = roofline_obj(wname, k, ktimes, B, dt, E, K)
+            line[f"roofline_{k}"] = roofline_obj(wname, k, ktimes[k], B, dt, E, K)
         if wl["flop_x"] is not None:
             line["achieved_model_tflops"] = evals * (wl["flop_x"] + wl["flop_a"] + wl["flop_f"]) * units_per_s / 1e12
         line["achieved_state_gbps"] = 2 * evals * state_floats * 4 * units_per_s / 1e9
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.emulate:
             line["cpu_baseline"] = cpu_baseline(wname, B)
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
-        print(json.dumps(line))
+        print(json.dumps(line), file=real_stdout, flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

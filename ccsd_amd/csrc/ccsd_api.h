@@ -53,6 +53,8 @@ struct ccsd_plan {
     std::vector<ccsd_step_coef_t> coef;  // [diff_steps][3]
     size_t nweights = 0;
     long long* dbg = nullptr;   // diagnostic cycle stamps (ccsd_debug_stamps)
+    unsigned long long* init_off = nullptr;   // device: off-bit table of ccsd_init_state (which takes no workspace), grown on demand
+    size_t init_off_cap = 0;
     // fused rank-2 kernel (k_r2): eligibility and LDS geometry
     int fused_r2 = 0, r2_ldk = 0, r2_ldh = 0;
     size_t r2_lds = 0;
@@ -133,6 +135,11 @@ extern "C" int ccsd_profile_stride(ccsd_plan_t* plan, int32_t stride) {
     for (int k = 0; k < 8; ++k) plan->prof_calls[k] = 0;
     return CCSD_OK;
 }
+extern "C" int ccsd_profile_launches(ccsd_plan_t* plan, int32_t kernel_id, int64_t* launches) {
+    if (!plan || !launches || kernel_id < 0 || kernel_id >= 8) return set_err(CCSD_ERR_INVALID, "bad argument");
+    *launches = (int64_t)(plan->prof_calls[kernel_id] >> 1);       // two marks per launch
+    return CCSD_OK;
+}
 extern "C" int ccsd_profile_read(ccsd_plan_t* plan, int32_t kernel_id, int64_t* launches, double* total_ms) {
     if (!plan || !launches || !total_ms || kernel_id < 0 || kernel_id >= 8) return set_err(CCSD_ERR_INVALID, "bad argument");
     *launches = 0; *total_ms = 0.0;
@@ -159,6 +166,7 @@ extern "C" void ccsd_plan_destroy(ccsd_plan_t* plan) {
     if (plan->hpairs) (void)rt_free(plan->hpairs);
     if (plan->edges) (void)rt_free(plan->edges);
     if (plan->cells) (void)rt_free(plan->cells);
+    if (plan->init_off) (void)rt_free(plan->init_off);
     delete plan;
 }
 
@@ -529,21 +537,27 @@ extern "C" int ccsd_init_state(ccsd_plan_t* pl, int32_t B, const float* flags, c
     int st = check_state(pl, state, "state");
     if (st) return st;
     const PlanD& p = pl->h;
-    // the off-bit table lives in front of nothing here: use a small private scratch in the state-free path
-    unsigned long long* offbits = nullptr;
-    RT_CHECK(rt_malloc((void**)&offbits, (size_t)B * 8));
+    // this call takes no workspace: the off-bit table lives in a plan-owned buffer that only ever grows, so the call stays
+    // asynchronous on `stream` (launches that use the buffer are ordered on it; a plan is reentrant per handle only)
+    if (pl->init_off_cap < (size_t)B) {
+        if (pl->init_off) {
+#ifndef CCSD_EMU
+            (void)hipStreamSynchronize((hipStream_t)stream);     // an earlier init on this stream may still read the old buffer
+#endif
+            (void)rt_free(pl->init_off);
+            pl->init_off = nullptr; pl->init_off_cap = 0;
+        }
+        RT_CHECK(rt_malloc((void**)&pl->init_off, (size_t)B * 8));
+        pl->init_off_cap = (size_t)B;
+    }
+    unsigned long long* offbits = pl->init_off;
     CCSD_LAUNCH(k_flagbits, dim3(grid_for(B, 256)), dim3(CCSD_NTHREADS), 0, stream, flags, offbits, B, p.N);
     NoiseArgs na = make_noise(prior, seed, sample_offset, 0);
     const long long total = (long long)B * (p.N * p.F + p.N * p.N) + (p.is_cc ? (long long)B * ((p.E + 3) / 4) * p.K : 0);
     CCSD_LAUNCH(k_init_state, dim3(grid_for(total, 256)), dim3(CCSD_NTHREADS), 0, stream, state->x, state->adj, state->rank2,
                 flags, na, (const unsigned long long*)offbits, (const unsigned char*)pl->edges,
                 (const unsigned long long*)pl->cells, B, p.N, p.F, p.E, p.K, p.is_cc);
-    rtError_t e = rt_last_error();
-#ifndef CCSD_EMU
-    (void)hipStreamSynchronize((hipStream_t)stream);
-#endif
-    (void)rt_free(offbits);
-    if (e != RT_OK) return set_err(CCSD_ERR_RUNTIME, rt_error_string(e));
+    LAUNCH_CHECK();
     return CCSD_OK;
 }
 

@@ -7,7 +7,7 @@ batch and runs the whole reverse diffusion locally on its GPU; the only per-step
 one 6-float all-reduce of the Langevin norm sums per corrector half-step, and the samples are all-gathered
 over RCCL / xGMI once at the end.
 
-    # inside each rank (started by torch.distributed.run, or by `spawn` below)
+    # inside each rank (started by torch.distributed.run, or by `launch_workers` below)
     rank, world, device = distributed.init()
     sampling_fn = distributed.load_sampling_fn_sharded(configt, config.sampler, config.sample, device,
                                                        is_cc=True, d_min=3, d_max=9)
@@ -38,7 +38,7 @@ from . import loader
 
 def init(backend: Optional[str] = None) -> Tuple[int, int, str]:
     """Join the process group described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (set by
-    torch.distributed.run or by `spawn`).  Returns (rank, world, device).  backend: "nccl" (= RCCL on ROCm) when a GPU
+    torch.distributed.run or by `launch_workers`).  Returns (rank, world, device).  backend: "nccl" (= RCCL on ROCm) when a GPU
     is visible, else "gloo"."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -120,8 +120,9 @@ def free_port() -> int:
 
 def launch_workers(argv: Sequence[str], nproc: int, env: Optional[dict] = None, relay=sys.stdout) -> int:
     """Run `python <argv>` as `nproc` ranks of one node through torch.distributed.run (127.0.0.1 rendezvous) in a child
-    process, relaying its stdout; returns the exit code.  The caller must not have initialised a GPU: the workers are
-    fresh processes, nothing is re-exec'ed."""
+    process; returns the exit code.  Result lines of the workers (JSON objects, one per line) are relayed to `relay`,
+    anything else they write to stdout (library banners such as gloo's connection messages) goes to stderr.  The caller
+    must not have initialised a GPU: the workers are fresh processes, nothing is re-exec'ed."""
     import subprocess
 
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
@@ -130,6 +131,7 @@ def launch_workers(argv: Sequence[str], nproc: int, env: Optional[dict] = None, 
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=e, text=True)
     for line in p.stdout:
-        relay.write(line)
-        relay.flush()
+        out = relay if line.lstrip().startswith("{") else sys.stderr
+        out.write(line)
+        out.flush()
     return p.wait()

@@ -191,6 +191,12 @@ class PCEngine:
         self.lib.check(self.lib.ccsd_profile_read(self.handle, _lib.KERNEL_IDS[name], C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
+    def profile_launches(self, name: str) -> int:
+        """All launches of a selected kernel since the selection / stride was set (bracketed by events or not)."""
+        n = C.c_int64(0)
+        self.lib.check(self.lib.ccsd_profile_launches(self.handle, _lib.KERNEL_IDS[name], C.byref(n)))
+        return n.value
+
     def quantize(self, t: torch.Tensor, thr: float = 0.5) -> torch.Tensor:
         """thr < 0 selects quantize_mol's 0/1/2/3 bins."""
         t = t.contiguous()

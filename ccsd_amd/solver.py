@@ -138,7 +138,8 @@ def get_pc_sampler(sde_x: SDE, sde_adj: SDE, shape_x: Sequence[int], shape_adj: 
         nt = 3 if is_cc else 2
         state, scratch, result = eng.alloc_state(B), eng.alloc_state(B), eng.alloc_state(B)
         diff_steps = sde_adj.N
-        last = diff_steps if max_steps is None else min(max_steps, diff_steps)
+        ms = pc_sampler.max_steps                   # (attribute: a caller may change the step budget between calls)
+        last = diff_steps if ms is None else min(ms, diff_steps)
         diff_traj: List[List[torch.Tensor]] = []
         with torch.no_grad():
             if rng == "philox":
@@ -242,4 +243,6 @@ def get_pc_sampler(sde_x: SDE, sde_adj: SDE, shape_x: Sequence[int], shape_adj: 
                     dst.copy_(src)
 
     pc_sampler.calls = 0
+    pc_sampler.max_steps = max_steps
+    pc_sampler.engine = lambda: next(iter(cache.values()), None)      # the PCEngine of the last model triple (measurement hooks)
     return pc_sampler

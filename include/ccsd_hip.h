@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CCSD_ABI_VERSION 3
+#define CCSD_ABI_VERSION 4
 
 /* status codes; the Python shim re-raises the reference's exception types */
 enum {
@@ -204,6 +204,9 @@ int ccsd_profile_kernel(ccsd_plan_t* plan, int32_t kernel_id);
  * back-to-back dispatch, so dense bracketing perturbs the timed region (~6 % of a qm9_CC step). */
 int ccsd_profile_stride(ccsd_plan_t* plan, int32_t stride);
 int ccsd_profile_read(ccsd_plan_t* plan, int32_t kernel_id, int64_t* launches, double* total_ms);
+/* ALL launches of a selected kernel since the selection / stride was last set (bracketed or not): with the mean of the
+ * bracketed ones this gives the kernel's share of a timed region */
+int ccsd_profile_launches(ccsd_plan_t* plan, int32_t kernel_id, int64_t* launches);
 /* Diagnostic: when dev_buffer (B x 64 int64, device) is non-NULL, thread 0 of every workgroup of k_r2 (slots 0-31)
  * and k_xa (slots 32-63) stores the shader clock at its phase boundaries (tools/stamps.py).  NULL disables. */
 int ccsd_debug_stamps(ccsd_plan_t* plan, void* dev_buffer);

@@ -2,6 +2,7 @@
 GPU suite (tests/test_gpu_parity.py, -m gpu).  Every case drives the product code (ccsd_amd.*) through
 the C ABI; `lib`/`device` select the backend: the HIP library on cuda:0, or the host emulation of the
 same kernel source on cpu."""
+import contextlib
 import json
 
 import numpy as np
@@ -13,9 +14,15 @@ from ccsd_amd.plan import rank2_dim
 from oracle import ccsd_oracle as O
 from tests.helpers import load_ckpt_np, load_golden, make_flags, rng_matches
 
-# float tolerance of the path (BASELINE.json north_star: scores within 1e-4 relative): relative to the
-# tensor's largest magnitude, since individual entries pass through zero.
+# float tolerance of the path (BASELINE.json north_star: scores within 1e-4 relative).  Two checks per tensor:
+#  (1) max |got - ref| <= RTOL * max|ref|            -- relative to the tensor's scale, since entries pass through zero;
+#  (2) on the entries with |ref| > 1e-2 * max|ref|:  |got - ref| <= RTOL * |ref| + ATOL_SCALE * max|ref|   (allclose form).
+# (2) halves the room (1) leaves to the smaller entries.  A pure element-wise 1e-4 is not attainable in fp32 by ANY
+# implementation, the reference included: ScoreNetworkF's alpha*F + beta*HF cancels O(scale) terms down to entries at
+# 1e-2 * scale, whose relative error is then ~1e-3 (measured: up to 1.5e-3 on community_small_CC's net_rank2 while (1) sits at
+# 2e-5), see test_fp64_arbiter for the reference's own distance from the exact result.
 RTOL = 1e-4
+ATOL_SCALE = 5e-5
 
 
 def assert_close(got: torch.Tensor, want, what: str, rtol: float = RTOL):
@@ -26,6 +33,10 @@ def assert_close(got: torch.Tensor, want, what: str, rtol: float = RTOL):
     scale = max(want.abs().max().item(), 1e-6)
     err = (got - want).abs().max().item()
     assert err <= rtol * scale, f"{what}: max abs err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.2e} > {rtol})"
+    big = want.abs() > 1e-2 * scale
+    if big.any() and rtol <= RTOL:
+        excess = ((got - want).abs() - rtol * want.abs() - ATOL_SCALE * scale)[big].max().item()
+        assert excess <= 0, f"{what}: element-wise check failed on an entry with |ref| > 1e-2 scale (excess {excess:.3e}, scale {scale:.3e})"
 
 
 def masked_state(seed, B, N, Fd, is_cc, d_min, d_max, flags, scale=1.0):
@@ -156,7 +167,84 @@ def sampler_from_golden(g, ckpt, case, lib, device, rng="torch_cpu", shape_overr
 # (H = F F^T, then H F over K = 715) and the first, large-sigma S4 steps amplify fp32 summation-order differences: measured
 # growth 6e-6 -> 3e-5 -> 6e-5 -> 1.1e-4 over steps 1, 2, 3, 5, then flat (x and adj stay at 1e-6).  The CPU emulation of the
 # kernels shows the same figures, and the 1000-scale case of the same checkpoint agrees to 7e-7.
+# Arbitrated in float64 (case_fp64_arbiter / test_fp64_arbiter_*): against the same trajectory computed in float64 the
+# REFERENCE's fp32 golden is off by 2.3e-4 (k4) / 1.0e-4 (k20) on rank2 and the product by 1.5e-4 / 1.3e-4 -- the product
+# is at least as close to the exact result as the reference; their mutual difference (2.6e-4 / 1.3e-4) is the sum of two
+# rounding histories, not a defect.  The bound below = the mutual difference that arbitration allows (reference error +
+# product error, each <= 2.5e-4 here).
 TRAJ_RTOL = {("s4_ccsd_enzymes_small_CC", "k20"): 5e-4, ("s4_ccsd_enzymes_small_CC", "k4"): 5e-4}
+
+
+@contextlib.contextmanager
+def f64_arithmetic():
+    """Run the oracle's tensor arithmetic in float64 on the SAME inputs: every draw (torch.randn / randn_like) and every
+    table (torch.linspace) is produced in float32 exactly as in a normal run and then widened, so the prior, the noise, the
+    timesteps and the table indices are the reference's; only the networks and the updates gain precision."""
+    rn, rl, ls, dd = torch.randn, torch.randn_like, torch.linspace, torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    torch.randn = lambda *s, **k: rn(*s, **dict(k, dtype=torch.float32)).double()
+    torch.randn_like = lambda t, **k: rn(*t.shape, dtype=torch.float32).double()
+    torch.linspace = lambda *a, **k: ls(*a, **dict(k, dtype=torch.float32)).double()
+    try:
+        yield
+    finally:
+        torch.randn, torch.randn_like, torch.linspace = rn, rl, ls
+        torch.set_default_dtype(dd)
+
+
+def case_fp64_arbiter(gname, ckpt, case, lib, device, factor=2.0):
+    """Who is right when the product and the fp32 reference golden differ by more than RTOL?  The same trajectory is
+    computed by the oracle in float64 (f64_arithmetic) and both are measured against it.  Required: the product is within
+    max(RTOL, factor * the reference's own error) of the exact result -- it may not be (much) further from the truth than the
+    reference is.  Returns {tensor: (reference error, product error, mutual difference)} relative to the tensor's scale."""
+    g = load_golden(f"g5_{gname}.npz")
+    assert rng_matches(g)
+    meta, parts = load_ckpt_np(ckpt)
+    cfg, is_cc = meta["config"], meta["is_cc"]
+    sm = json.loads(str(g["sampler"]))
+    N, Fd = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
+    flags = torch.from_numpy(g["flags"])
+    B = flags.shape[0]
+    names = ["x", "adj"] + (["rank2"] if is_cc else [])
+    num_scales = int(case[1:]) if case.startswith("k") else None
+    max_steps = None if case.startswith("k") else int(case.split("first")[1])
+    with f64_arithmetic():
+        sdes = []
+        for p in names:
+            c = dict(cfg["sde"][p])
+            c.update(sm.get("sde_override", {}).get(p, {}))
+            if num_scales is not None:
+                c["num_scales"] = num_scales
+            sdes.append(O.load_sde(c))
+        w = {p: {k: v.detach().double() for k, v in parts[p].items()} for p in names}
+        kw = dict(sde_x=sdes[0], sde_adj=sdes[1], shape_x=(B, N, Fd), shape_adj=(B, N, N), predictor=sm["predictor"],
+                  corrector=sm["corrector"], snr=sm["snr"], scale_eps=sm["scale_eps"], n_steps=sm["n_steps"],
+                  probability_flow=bool(sm.get("probability_flow", False)), continuous=True, denoise=True, eps=1e-4,
+                  n_diff_steps=max_steps, keep_traj=False)
+        if is_cc:
+            d_min, d_max = cfg["data"]["d_min"], cfg["data"]["d_max"]
+            kw.update(is_cc=True, sde_rank2=sdes[2], shape_rank2=(B, *O.get_rank2_dim(N, d_min, d_max)), d_min=d_min, d_max=d_max)
+            nets = [(lambda x, a, r, f, p=p: O.run_network(meta[f"params_{p}"], w[p], x, a, r, f)) for p in names]
+        else:
+            nets = [(lambda x, a, f, p=p: O.run_network(meta[f"params_{p}"], w[p], x, a, None, f)) for p in names]
+        fn = (O.S4_solver if sm["predictor"] == "S4" else O.get_pc_sampler)(**kw)
+        torch.manual_seed(int(g["seed"]))
+        exact = fn(*nets, flags.double())[: len(names)]
+    pfn, models, _, _ = sampler_from_golden(g, ckpt, case, lib, device)
+    torch.manual_seed(int(g["seed"]))
+    got = pfn(*models, flags.to(device))
+    out = {}
+    for k, p in enumerate(names):
+        ex = exact[k]
+        ref = torch.from_numpy(g[f"{case}/{p}"]).double()
+        mine = got[k].detach().cpu().double()
+        scale = max(ex.abs().max().item(), 1e-6)
+        e_ref, e_mine, e_mut = ((ref - ex).abs().max().item() / scale, (mine - ex).abs().max().item() / scale,
+                                (mine - ref).abs().max().item() / scale)
+        out[p] = (e_ref, e_mine, e_mut)
+        assert e_mine <= max(RTOL, factor * e_ref), (f"{gname} {case} {p}: product is {e_mine:.2e} from the float64 trajectory, the "
+                                                     f"fp32 reference {e_ref:.2e}")
+    return out
 
 
 def case_pc_sampler_identical_seed(gname, ckpt, case, lib, device):
@@ -393,3 +481,77 @@ def case_rank2_cells(lib, device):
             assert cells_from_bits(bits[b].cpu(), N, d_min, d_max) == want
         assert counts[0].item() == 0 and counts[1].item() == K
 
+
+
+def case_harness_vs_oracle(lib, tmp_path, name, cfg_yaml, ckpt, max_steps):
+    """Sampler_*.sample() on the HIP path with every draw taken from torch's CPU generator, against the oracle driven through
+    the same seeds in the harness's own order (load_seed(sample.seed); per divide_batch chunk: init_flags on the numpy stream,
+    then priors and in-loop noise on the torch stream -- sampler.py:1157-1211): floats to 1e-4 of the tensor's scale, the
+    integer outputs (quantize_mol + relabelling, quantize, one-hots) bit for bit wherever the oracle's value is not within
+    the float tolerance of a threshold (and such entries must be rare)."""
+    import numpy as np
+
+    from ccsd_amd import loader
+    from ccsd_amd import sampler as S
+    from oracle import ccsd_oracle as O
+    from tests import test_harness as H
+    from tests.helpers import load_ckpt_np
+
+    H.write_cfg(tmp_path, name, cfg_yaml)
+    from ccsd_amd.diffusion import CCSD
+
+    c = CCSD("sample", name, folder=str(tmp_path), seed=42)
+    c.sampler = S.get_sampler_from_config(c.cfg)
+    c.sampler.extra = dict(lib=lib, max_steps=max_steps, rng="torch_cpu")
+    out = c.sampler.sample()
+    smp, div = cfg_yaml["sample"], cfg_yaml["sample"].get("divide_batch", 1)
+    # the oracle through the same sequence
+    meta, parts = load_ckpt_np(ckpt)
+    cfg = meta["config"]
+    N, F = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
+    d_min, d_max = cfg["data"]["d_min"], cfg["data"]["d_max"]
+    names = ["x", "adj", "rank2"]
+    Bc = smp["n_samples"] // div
+    so = [O.load_sde(cfg["sde"][p]) for p in names]
+    nets = [(lambda x, a, r, f, p=p: O.run_network(meta[f"params_{p}"], parts[p], x, a, r, f)) for p in names]
+    sm = cfg_yaml["sampler"]
+    ofn = O.get_pc_sampler(sde_x=so[0], sde_adj=so[1], sde_rank2=so[2], shape_x=(Bc, N, F), shape_adj=(Bc, N, N),
+                           shape_rank2=(Bc, *O.get_rank2_dim(N, d_min, d_max)), predictor=sm["predictor"], corrector=sm["corrector"],
+                           snr=sm["snr"], scale_eps=sm["scale_eps"], n_steps=sm["n_steps"], probability_flow=False, continuous=True,
+                           denoise=True, eps=smp["eps"], is_cc=True, d_min=d_min, d_max=d_max, n_diff_steps=max_steps, keep_traj=False)
+    loader.load_seed(smp["seed"])
+    want = [[], [], []]
+    flags_all = []
+    for _ in range(div):
+        fl = S.init_flags(c.sampler.node_counts, c.sampler.configt, Bc, is_cc=True)     # numpy stream, as the harness
+        flags_all.append(fl)
+        res = ofn(*nets, fl)
+        for k in range(3):
+            want[k].append(res[k])
+    want = [torch.cat(w, 0) for w in want]
+    assert torch.equal(out["flags"].cpu(), torch.cat(flags_all, 0))
+    for k, p in enumerate(names):
+        assert_close(out[p], want[k], f"harness {name} {p}")
+
+    def check_ints(got, ref_float, quant, thresholds, what):
+        ref_float = ref_float.double()
+        tol = 1e-4 * max(ref_float.abs().max().item(), 1.0)
+        safe = torch.ones_like(ref_float, dtype=torch.bool)
+        for t in thresholds:
+            safe &= (ref_float - t).abs() > tol
+        assert safe.double().mean().item() > 0.995, f"{what}: too many entries sit on a threshold"
+        assert torch.equal(got.cpu()[safe], quant[safe]), f"{what}: integer output differs away from the thresholds"
+
+    q = torch.as_tensor(O.quantize_mol(want[1].clone()))
+    relabelled = torch.where(q == 0, torch.full_like(q, 3), q - 1)                       # sampler.py:1219-1220
+    check_ints(out["adj_int"], want[1], relabelled, (0.5, 1.5, 2.5), "adj_int")
+    check_ints(out["rank2_int"].to(torch.int64), want[2], O.quantize(want[2]).to(torch.int64), (0.5,), "rank2_int")
+    xi = torch.where(want[0] > 0.5, 1, 0)
+    check_ints(out["x_onehot"][..., : xi.shape[-1]], want[0], xi, (0.5,), "x_onehot")
+    oh = torch.nn.functional.one_hot(out["adj_int"].cpu(), num_classes=4).permute(0, 3, 1, 2)
+    assert torch.equal(out["adj_onehot"].cpu(), oh)
+    # sparse rank-2 output == the dense quantised tensor's occupied columns
+    bits, counts = out["rank2_cell_bits"].cpu(), out["rank2_cell_count"].cpu()
+    occ = (out["rank2_int"].cpu() > 0).any(dim=1)
+    assert counts.tolist() == occ.sum(dim=1).tolist()
+    return out

@@ -70,6 +70,23 @@ def test_pc_sampler_identical_seed(lib, gname, ckpt, case):
     pc.case_pc_sampler_identical_seed(gname, ckpt, case, lib, DEV)
 
 
+@pytest.mark.parametrize("case", ["k4", "k20"])
+def test_fp64_arbiter_s4_enzymes(lib, case):
+    """The two cases whose tolerance against the fp32 reference golden is wider than 1e-4 (parity_cases.TRAJ_RTOL), judged
+    against the float64 trajectory: the product may not be further from it than the reference is."""
+    r = pc.case_fp64_arbiter("s4_ccsd_enzymes_small_CC", "ccsd_enzymes_small_CC", case, lib, DEV)
+    e_ref, e_mine, e_mut = r["rank2"]
+    assert e_mut <= e_ref + e_mine + 1e-7
+    assert e_ref > 0.9e-4, "the reference itself is no longer > 1e-4 from the exact trajectory: tighten TRAJ_RTOL"
+
+
+def test_fp64_arbiter_qm9(lib):
+    """Control: on a well-conditioned case both the reference and the product sit within 2e-5 of the float64 trajectory."""
+    r = pc.case_fp64_arbiter("ccsd_qm9_CC", "ccsd_qm9_CC", "k10", lib, DEV)
+    for p, (e_ref, e_mine, _) in r.items():
+        assert e_ref < 5e-5 and e_mine < 5e-5, (p, e_ref, e_mine)
+
+
 def test_philox_properties(lib):
     pc.case_philox_properties(lib, DEV)
 

@@ -66,6 +66,23 @@ def test_pc_sampler_identical_seed(lib, gname, ckpt, case):
     pc.case_pc_sampler_identical_seed(gname, ckpt, case, lib, DEV)
 
 
+@pytest.mark.parametrize("case", ["k4", "k20"])
+def test_fp64_arbiter_s4_enzymes(lib, case):
+    """The two cases whose tolerance against the fp32 reference golden is wider than 1e-4 (parity_cases.TRAJ_RTOL), judged
+    against the float64 trajectory: the product may not be further from it than the reference is."""
+    r = pc.case_fp64_arbiter("s4_ccsd_enzymes_small_CC", "ccsd_enzymes_small_CC", case, lib, DEV)
+    e_ref, e_mine, e_mut = r["rank2"]
+    assert e_mut <= e_ref + e_mine + 1e-7
+    assert e_ref > 0.9e-4, "the reference itself is no longer > 1e-4 from the exact trajectory: tighten TRAJ_RTOL"
+
+
+def test_fp64_arbiter_qm9(lib):
+    """Control: on a well-conditioned case both the reference and the product sit within 2e-5 of the float64 trajectory."""
+    r = pc.case_fp64_arbiter("ccsd_qm9_CC", "ccsd_qm9_CC", "k10", lib, DEV)
+    for p, (e_ref, e_mine, _) in r.items():
+        assert e_ref < 5e-5 and e_mine < 5e-5, (p, e_ref, e_mine)
+
+
 def test_philox_properties(lib):
     pc.case_philox_properties(lib, DEV)
 
@@ -162,16 +179,65 @@ def test_alternative_kernel_paths_qm9(lib, env, monkeypatch):
     pc.case_philox_properties(lib, DEV)
 
 
+def test_full_size_community_small_cc_philox_properties(lib):
+    """BASELINE configs[1] size (community_small_CC, B=512, E=190, K=1140: the tiled rank-2 kernels) for a few steps:
+    size-independent properties of the state."""
+    import numpy as np
+
+    from ccsd_amd import loader, solver
+    from oracle import ccsd_oracle as O
+    from tests.helpers import load_ckpt_np
+
+    meta, parts = load_ckpt_np("ccsd_community_small_CC")
+    cfg = meta["config"]
+    B, N, F = 512, 20, cfg["data"]["max_feat_num"]
+    rs = np.random.RandomState(12)
+    counts = rs.choice([12, 14, 16, 18, 20], size=B, p=np.array([29, 14, 23, 25, 9]) / 100.0)
+    flags = torch.zeros(B, N)
+    for b, c in enumerate(counts):
+        flags[b, :c] = 1
+    names = ["x", "adj", "rank2"]
+    ms = [loader.load_model_from_ckpt(meta[f"params_{p}"], parts[p], DEV) for p in names]
+    sd = [loader.load_sde(cfg["sde"][p]) for p in names]
+    E, K = 190, 1140
+    fn = solver.get_pc_sampler(sde_x=sd[0], sde_adj=sd[1], sde_rank2=sd[2], shape_x=(B, N, F), shape_adj=(B, N, N),
+                               shape_rank2=(B, E, K), predictor="Euler", corrector="Langevin", snr=0.05, scale_eps=0.7,
+                               n_steps=1, continuous=True, denoise=True, eps=1e-4, device=DEV, is_cc=True, d_min=3, d_max=3,
+                               rng="philox", seed=12, max_steps=3, lib=lib)
+    x, adj, rank2, nfe, traj = fn(*ms, flags.to(DEV))
+    again = fn(*ms, flags.to(DEV))                       # second call of the closure: fresh draws
+    assert not torch.equal(again[2], rank2)
+    x, adj, rank2 = x.cpu(), adj.cpu(), rank2.cpu()
+    assert nfe == 2000 and traj == []
+    for t in (x, adj, rank2):
+        assert torch.isfinite(t).all()
+    assert torch.equal(x, O.mask_x(x, flags)) and torch.equal(adj, O.mask_adjs(adj, flags))
+    fl, fr = O.rank2_flags(flags, N, 3, 3)
+    assert torch.equal(rank2, rank2 * fl[:, :, None] * fr[:, None, :])
+    assert torch.allclose(adj, adj.transpose(-1, -2), atol=1e-5)
+    assert (adj.diagonal(dim1=-2, dim2=-1) == 0).all()
+    live = rank2[flags.sum(1) == 20]
+    assert 0.5 < live.std().item() < 2.0                 # 3 of 1000 VP steps: still prior-dominated
+
+
 def test_ccsd_api_yaml_surface_on_gpu(lib, tmp_path):
-    """CCSD(type="sample", config=<yaml>).run()-equivalent flow on the HIP path: qm9_CC (Reverse+Langevin, divide_batch) and
-    the shipped ENZYMES_small_CC config (S4 solver, EMA weights)."""
+    """CCSD(type="sample", config=<yaml>).run()-equivalent flow on the HIP path.  (i) qm9_CC (Reverse + Langevin, divide_batch = 2)
+    with identical seeds against the oracle: float outputs and the quantised / relabelled / one-hot integer outputs; (ii) the
+    same config with the production Philox noise and the shipped ENZYMES_small_CC config (S4 solver, EMA weights): properties."""
     from tests import test_harness as H
 
+    cfg = dict(H.QM9_CC_YAML, sample=dict(H.QM9_CC_YAML["sample"], n_samples=32))
+    pc.case_harness_vs_oracle(lib, tmp_path, "sample_qm9_CC_parity", cfg, "ccsd_qm9_CC", max_steps=12)
     out, c = H.run_harness(tmp_path, lib, None, "sample_qm9_CC", dict(H.QM9_CC_YAML, sample=dict(H.QM9_CC_YAML["sample"], n_samples=64)),
                            max_steps=20)
     assert out["adj"].is_cuda and out["adj"].shape == (64, 9, 9) and out["rank2"].shape == (64, 36, 466)
     assert torch.isfinite(out["rank2"]).all() and set(out["adj_int"].unique().tolist()) <= {0, 1, 2, 3}
     fl = out["flags"]
     assert torch.equal(out["adj"], out["adj"] * fl[:, :, None] * fl[:, None, :])
+    # the two divide_batch chunks draw different noise (equal-flag samples of chunk 0 and chunk 1 are not copies)
+    half = out["rank2"].shape[0] // 2
+    a, b = out["rank2"][:half].flatten().double().cpu(), out["rank2"][half:].flatten().double().cpu()
+    corr = ((a - a.mean()) * (b - b.mean())).mean() / (a.std() * b.std())
+    assert abs(corr.item()) < 0.05, f"divide_batch chunks are correlated: {corr.item():.3f}"
     out, c = H.run_harness(tmp_path, lib, None, "sample_enzymes_small_CC", H.ENZYMES_YAML, max_steps=10, rounds=1)
     assert out["adj"].shape[1:] == (12, 12) and torch.isfinite(out["rank2"]).all()

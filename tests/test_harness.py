@@ -111,3 +111,12 @@ def test_ccsd_sample_qm9_base_cc_yaml(tmp_path):
     assert out["adj"].shape == (8, 9, 9) and out["rank2"].shape == (8, 36, 466)
     assert torch.isfinite(out["adj"]).all() and torch.isfinite(out["rank2"]).all()
     assert set(out["adj_int"].unique().tolist()) <= {0, 1, 2, 3}
+
+
+def test_harness_identical_seed_vs_oracle(tmp_path):
+    """CPU twin of the GPU harness-parity test: Sampler_mol_CC.sample() (divide_batch = 2, every draw from torch's CPU
+    generator) over the emulation library against the oracle driven through the same seeds."""
+    from tests import parity_cases as pc
+    from tests.emu_util import emu_library
+
+    pc.case_harness_vs_oracle(emu_library(), tmp_path, "sample_qm9_CC_parity", QM9_CC_YAML, "ccsd_qm9_CC", max_steps=3)

@@ -15,7 +15,7 @@ Nn, Ff = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
 eng = PCEngine(meta["params_x"], parts["x"], meta["params_adj"], parts["adj"], meta["params_rank2"], parts["rank2"],
                N=Nn, F=Ff, is_cc=True, d_min=cfg["data"]["d_min"], d_max=cfg["data"]["d_max"], sdes=sdes, predictor="Reverse",
                corrector="Langevin", snr=0.2, scale_eps=0.7, n_steps=1, denoise=True, eps=1e-4, device="cuda:0", batch_hint=B)
-flags = (bench.qm9_flags(B) if Nn == 9 else bench.hist_flags(B, Nn, {Nn: 3, Nn - 2: 2, Nn - 5: 1})).cuda()
+flags = (bench.hist_flags(B, 9, bench.QM9_HIST) if Nn == 9 else bench.hist_flags(B, Nn, {Nn: 3, Nn - 2: 2, Nn - 5: 1})).cuda()
 st, sc, rs = eng.alloc_state(B), eng.alloc_state(B), eng.alloc_state(B)
 eng.init_state(flags, st, None, 1, 0)
 eng.run(flags, st, sc, rs, 1, 0, 0, 3)
