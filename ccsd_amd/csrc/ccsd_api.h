@@ -101,6 +101,38 @@ static void prof_mark(ccsd_plan* pl, int kid, void* stream) {
         if (_e != RT_OK) return set_err(CCSD_ERR_RUNTIME, std::string("kernel launch: ") + rt_error_string(_e)); \
     } while (0)
 
+// Instantiation of the fused rank-2 kernel for a plan: (MT, RS) from E -- MT = ceil(E / 16) row tiles, RS = plain MFMA steps
+// covering E mod 16 behind the full 16-wide blocks of phase 2's contraction index (0: last block taken whole) --, AFFINE
+// ScoreNetworkF, general hodge mlp_value.  RS only shapes the affine phase 2; the non-affine kernels are instantiated with RS = 0.
+static inline void r2_shape(const ccsd_plan* pl, int* MT, int* RS, bool* aff, bool* gen1) {
+    const int E = pl->h.E, rem = E & 15;
+    *MT = (E + 15) / 16;
+    *aff = pl->h.f_affine != 0;
+    *gen1 = pl->h.h_L > 1 && pl->h.hl[0].mval.n > 1;
+    *RS = (!*aff || rem == 0 || rem > 12) ? 0 : (rem + 3) / 4;
+}
+// X(MT, RS, AFFINE, GEN1) is expanded for the plan's combination
+#define R2_CASE(MT_, RS_, X) \
+    if (mt_ == MT_ && rs_ == RS_) { \
+        if (aff_ && !gen1_) { X(MT_, RS_, true, false); } else if (aff_) { X(MT_, RS_, true, true); } \
+        else if (!gen1_) { X(MT_, 0, false, false); } else { X(MT_, 0, false, true); } \
+    }
+#define R2_DISPATCH(pl_, X) \
+    do { \
+        int mt_, rs_; bool aff_, gen1_; \
+        r2_shape(pl_, &mt_, &rs_, &aff_, &gen1_); \
+        /* E = N (N - 1) / 2 <= 64, i.e. E in {1, 3, 6, 10, 15, 21, 28, 36, 45, 55}: the (MT, RS) pairs that occur */ \
+        R2_CASE(1, 0, X) else R2_CASE(1, 1, X) else R2_CASE(1, 2, X) else R2_CASE(1, 3, X) \
+        else R2_CASE(2, 2, X) else R2_CASE(2, 3, X) else R2_CASE(3, 0, X) else R2_CASE(3, 1, X) else R2_CASE(4, 2, X) \
+    } while (0)
+static inline const void* r2_kernel(const ccsd_plan* pl) {
+    const void* fn = nullptr;
+#define R2_PTR(MT_, RS_, A_, G_) fn = (const void*)k_r2<MT_, RS_, A_, G_>
+    R2_DISPATCH(pl, R2_PTR);
+#undef R2_PTR
+    return fn;
+}
+
 extern "C" const char* ccsd_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" void ccsd_rank2_dims(const ccsd_config_t* cfg, int32_t* E, int64_t* K) {
@@ -280,10 +312,10 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
         const PlanD& p = pl->h;
         const int Kp4 = (K + 31) & ~31, Ep4 = (E + 3) & ~3;   // K zero-padded to whole 8-step MFMA batches
         int ldk = Kp4; while ((ldk & 31) != 8 && (ldk & 31) != 24) ldk += 4;   // conflict-free ds_read_b128 fragment reads (16 rows x 4 k-quads)
-        int ldh = Ep4 | 1;                                                 // odd stride; H fragments are read once per wave
+        int ldh = Ep4;                                                     // 16-byte aligned rows: phase 2 re-reads H's fragments per column tile as ds_read_b128
         const size_t fl = (size_t)E * ldk + (size_t)E * ldh + 64 * 2 + (size_t)p.a_cinit * E + 3 * N * N + 64 + (Kp4 + 3) / 4 + 4;
         const bool wc_ok = fnet_width(p) <= CCSD_FW;        // the fused kernel's per-element MLPs are padded to <= 16
-        if (fl * 4 + 64 <= 160 * 1024 && wc_ok) {
+        if (fl * 4 + 64 <= 160 * 1024 && wc_ok && r2_kernel(pl) != nullptr) {
             pl->fused_r2 = 1; pl->r2_ldk = ldk; pl->r2_ldh = ldh; pl->r2_lds = fl * 4;
         }
     }
@@ -291,13 +323,7 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     if ((size_t)pl->h.xa_lds_floats * 4 > 64 * 1024)
         PC(rt_set_max_dyn_smem(xa_kernel(pl->h), (size_t)pl->h.xa_lds_floats * 4));
     if (pl->fused_r2 && pl->r2_lds > 64 * 1024) {
-        const int MT = (E + 15) / 16;
-        const bool aff = pl->h.f_affine != 0, gen1 = pl->h.h_L > 1 && pl->h.hl[0].mval.n > 1;
-#define R2_FN(MT_) (aff ? (gen1 ? (const void*)k_r2<MT_, true, true> : (const void*)k_r2<MT_, true, false>) \
-                        : (gen1 ? (const void*)k_r2<MT_, false, true> : (const void*)k_r2<MT_, false, false>))
-        const void* fn = MT == 1 ? R2_FN(1) : MT == 2 ? R2_FN(2) : MT == 3 ? R2_FN(3) : R2_FN(4);
-#undef R2_FN
-        PC(rt_set_max_dyn_smem(fn, pl->r2_lds));
+        PC(rt_set_max_dyn_smem(r2_kernel(pl), pl->r2_lds));
     }
 #endif
 #undef PC
@@ -468,23 +494,11 @@ static int launch_r2(const ccsd_plan* pl, int B, const float* rank2, const float
     ra.ldk = pl->r2_ldk; ra.ldh = pl->r2_ldh; ra.dbg = pl->dbg; ra.wp = pl->wp;
     prof_mark(const_cast<ccsd_plan*>(pl), KID_R2, stream);
     const dim3 blk(CCSD_NTHREADS == 1 ? 1 : 512);
-    const bool aff = pl->h.f_affine != 0, gen1 = pl->h.h_L > 1 && pl->h.hl[0].mval.n > 1;
-#define R2_ARGS (const PlanD*)pl->d, (const float*)pl->w, (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, ra, ep, na
-#define R2_GO(MT_) \
-    do { \
-        if (aff && !gen1) CCSD_LAUNCH((k_r2<MT_, true, false>), dim3(B), blk, pl->r2_lds, stream, R2_ARGS); \
-        else if (aff) CCSD_LAUNCH((k_r2<MT_, true, true>), dim3(B), blk, pl->r2_lds, stream, R2_ARGS); \
-        else if (!gen1) CCSD_LAUNCH((k_r2<MT_, false, false>), dim3(B), blk, pl->r2_lds, stream, R2_ARGS); \
-        else CCSD_LAUNCH((k_r2<MT_, false, true>), dim3(B), blk, pl->r2_lds, stream, R2_ARGS); \
-    } while (0)
-    switch ((pl->h.E + 15) / 16) {
-        case 1: R2_GO(1); break;
-        case 2: R2_GO(2); break;
-        case 3: R2_GO(3); break;
-        default: R2_GO(4); break;
-    }
+#define R2_GO(MT_, RS_, A_, G_) \
+    CCSD_LAUNCH((k_r2<MT_, RS_, A_, G_>), dim3(B), blk, pl->r2_lds, stream, (const PlanD*)pl->d, (const float*)pl->w, \
+                (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, ra, ep, na)
+    R2_DISPATCH(pl, R2_GO);
 #undef R2_GO
-#undef R2_ARGS
     prof_mark(const_cast<ccsd_plan*>(pl), KID_R2, stream);
     LAUNCH_CHECK();
     return CCSD_OK;

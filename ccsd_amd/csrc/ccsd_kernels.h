@@ -17,6 +17,7 @@
 // Reference file:line citations sit next to each restated formula.
 #pragma once
 #include "ccsd_plan.h"
+#include <type_traits>
 
 // ---------------------------------------------------------------------------------------------
 // small device helpers
@@ -90,9 +91,9 @@ CCSD_DEV void philox4(unsigned int c0, unsigned int c1, unsigned int c2, unsigne
     for (int r = 0; r < 10; ++r) {
         const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
         const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
-        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0;
-        const unsigned int n1 = (unsigned int)p1;
+        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0;       // (gfx950 has no three-operand xor: two v_xor_b32)
         const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1;
+        const unsigned int n1 = (unsigned int)p1;
         const unsigned int n3 = (unsigned int)p0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -1316,9 +1317,11 @@ struct R2Args {
     CorrFuse cf;
 };
 
-// MT = ceil(E / 16) row tiles (1..4); AFFINE: ScoreNetworkF folds to alpha F + beta HF + gamma; GEN1: general
-// (non-affine) mlp_value in the hodge branch.  Compile-time so that the common variant carries no general-path code.
-template <int MT, bool AFFINE, bool GEN1>
+// MT = ceil(E / 16) row tiles (1..4); RS (affine phase 2 only): plain MFMA steps covering E mod 16 behind the MT - 1 full
+// 16-wide blocks of the contraction index (0: the last block is taken whole, zero padded -- E mod 16 == 0 or > 12);
+// AFFINE: ScoreNetworkF folds to alpha F + beta HF + gamma; GEN1: general (non-affine) mlp_value in the hodge branch.
+// Compile-time so that the common variant carries no general-path code.
+template <int MT, int RS, bool AFFINE, bool GEN1>
 __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, const float* __restrict__ w,
                                             const unsigned char* __restrict__ edges,
                                             const unsigned long long* __restrict__ cells, R2Args ra, RankEpi ep,
@@ -1517,188 +1520,174 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
             ra.P1[((size_t)b * E + m) * wc1 + n] = lin1 ? sFl[m] * fmaf(sRow[m], acc, w[h0.mval.b[0]] * un) : acc;
         }
     }
-#else
-    {
-        // Tile tasks over the full K, two tiles that share their A rows per wave.  The MFMA k slot kq of step j of a
-        // 16-wide k block is assigned to k = 16*blk + 4*kq + j, so a lane's A (and, for H, B) values of four steps are
-        // ONE aligned ds_read_b128 of F, and its weight values one float4 of the transposed copy Wcat^T[col][Kp].
-        // Rows / columns beyond E / wc read clamped (valid) addresses and are never stored; k >= K meets the zero
-        // padding of F.  Lists: per row tile i  [H(i, j >= i) ..., P_0(i, .)...]  and  [P_1(i, .)...] (A = F o fr).
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        const int wave = tid >> 6, nw = nth >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
-        const int nblk = Kp4 >> 4;
-        const float* WT0 = ra.wp + h0.wcatT;
-        const float* WT1 = ra.wp + h1.wcatT;
-        const bool hmask = p.f_hmask != 0;
-        const float mval_b0 = lin1 ? w[h0.mval.b[0]] : 0.f;       // fetched before the k loops
-        int npairs = 0;
-        for (int i = 0; i < MT; ++i) npairs += (((p.f_cnum == 2 ? MT - i : 0) + nt0) + 1) / 2 + (nt1 + 1) / 2;
-        for (int i = 0; i < MT; ++i) nHtasks += ((p.f_cnum == 2 ? MT - i : 0) + 1) / 2;    // pairs that hold an H tile
-        for (int pr = wave; pr < npairs; pr += nw) {
-            // decode pair -> (row tile, list, first entry)
-            int i = 0, kind = 0, first = 0, rem = pr;
-            for (;; ++i) {
-                const int na = ((p.f_cnum == 2 ? MT - i : 0) + nt0 + 1) / 2, nb = (nt1 + 1) / 2;
-                if (rem < na) { kind = 0; first = 2 * rem; break; }
-                rem -= na;
-                if (rem < nb) { kind = 1; first = 2 * rem; break; }
-                rem -= nb;
-            }
-            const int nh = p.f_cnum == 2 ? MT - i : 0;            // H tiles of this row tile
-            const int nlist = kind == 0 ? nh + nt0 : nt1;
-            const int ra_ = 16 * i + l15;
-            const float* pa = sF + (ra_ < E ? ra_ : E - 1) * ldk + 4 * kq;
-            int offB[2];                                          // H tiles: B rows of F in LDS
-            const float* wtp[2];                                  // P tiles: column of Wcat^T in global memory
-            int tcol[2], ttype[2];                                // 0 = H, 1 = P_0, 2 = P_1, -1 = none
-            bool blds[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int idx = first + q;
-                const bool live = idx < nlist;
-                const int id = live ? idx : first;
-                offB[q] = 0; wtp[q] = WT0;
-                if (kind == 0 && id < nh) {
-                    tcol[q] = i + id; ttype[q] = live ? 0 : -1; blds[q] = true;
-                    const int rb_ = 16 * tcol[q] + l15;
-                    offB[q] = (rb_ < E ? rb_ : E - 1) * ldk + 4 * kq;
-                } else {
-                    const int c = kind == 0 ? id - nh : id, wcn = kind == 0 ? wc0 : wc1;
-                    tcol[q] = c; ttype[q] = live ? (kind == 0 ? 1 : 2) : -1; blds[q] = false;
-                    const int n = 16 * c + l15;
-                    wtp[q] = (kind == 0 ? WT0 : WT1) + (size_t)(n < wcn ? n : wcn - 1) * Kp4 + 4 * kq;
-                }
-            }
-            f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-            float upart[2] = {0.f, 0.f};
-            // the k loop, specialised on where each tile's B operand lives (LDS / global) and on the masked-A kind
-            auto kloop = [&](auto L0, auto L1, auto K1) {
-                constexpr bool l0 = decltype(L0)::v, l1 = decltype(L1)::v, k1 = decltype(K1)::v;
-                auto ld0 = [&](int blk) -> float4 {
-                    if (l0) return *reinterpret_cast<const float4*>(sF + offB[0] + 16 * blk);
-                    return *reinterpret_cast<const float4*>(wtp[0] + 16 * blk);
-                };
-                auto ld1 = [&](int blk) -> float4 {
-                    if (l1) return *reinterpret_cast<const float4*>(sF + offB[1] + 16 * blk);
-                    return *reinterpret_cast<const float4*>(wtp[1] + 16 * blk);
-                };
-                // operands of four 16-wide k blocks are kept in flight (the weights come from L2: ~500+ cycles); a slot is
-                // refilled only after the MFMAs that read it have been issued, so the load lands in the same registers
-                constexpr int D = 4;
-                float4 ab[D], bb0[D], bb1[D];
-                unsigned int fb[D];                                   // cell-mask bytes of the block (masked-A kind only)
-#pragma unroll
-                for (int u = 0; u < D; ++u) {
-                    const int bl = u < nblk ? u : nblk - 1;
-                    ab[u] = *reinterpret_cast<const float4*>(pa + 16 * bl);
-                    bb0[u] = ld0(bl); bb1[u] = ld1(bl);
-                    fb[u] = k1 ? *reinterpret_cast<const unsigned int*>(sFrb + 16 * bl + 4 * kq) : 0u;
-                }
-                auto block = [&](int u, int blk, bool refill) {
-                    float4 a4 = ab[u];
-                    const float4 b40 = bb0[u], b41 = bb1[u];
-                    if (k1) {
-                        const unsigned int f4 = fb[u];
-                        const float fr0 = (float)(f4 & 0xffu), fr1 = (float)((f4 >> 8) & 0xffu), fr2 = (float)((f4 >> 16) & 0xffu),
-                                    fr3 = (float)(f4 >> 24);
-                        if (GEN1) {   // general mlp_value: rank2' element-wise on the fly (hodge_attention.py:322-323)
-                            const int r = 16 * i + l15, e = r < E ? r : E - 1;
-                            float fv[4] = {a4.x, a4.y, a4.z, a4.w};
-                            const float frv[4] = {fr0, fr1, fr2, fr3};
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                float iin[CCSD_SMALLW], out[CCSD_SMALLW];
-#pragma unroll
-                                for (int c = 0; c < CCSD_SMALLW; ++c) iin[c] = c < h0.cin ? sAco[c * E + e] * fv[j] : 0.f;
-                                small_mlp<CCSD_SMALLW>(h0.mval, w, iin, out);
-                                fv[j] = sFl[e] * out[0] * frv[j];
-                            }
-                            a4 = make_float4(fv[0], fv[1], fv[2], fv[3]);
-                        } else {
-                            a4.x *= fr0; a4.y *= fr1; a4.z *= fr2; a4.w *= fr3;
-                            upart[0] = fmaf(fr0, b40.x, fmaf(fr1, b40.y, fmaf(fr2, b40.z, fmaf(fr3, b40.w, upart[0]))));
-                            upart[1] = fmaf(fr0, b41.x, fmaf(fr1, b41.y, fmaf(fr2, b41.z, fmaf(fr3, b41.w, upart[1]))));
-                        }
-                    }
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b40.x, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b41.x, acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b40.y, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b41.y, acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b40.z, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b41.z, acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b40.w, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b41.w, acc[1], 0, 0, 0);
-                    if (refill) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        const int bl = blk + D < nblk ? blk + D : nblk - 1;   // clamped: a harmless reload at the tail
-                        ab[u] = *reinterpret_cast<const float4*>(pa + 16 * bl);
-                        bb0[u] = ld0(bl); bb1[u] = ld1(bl);
-                        if (k1) fb[u] = *reinterpret_cast<const unsigned int*>(sFrb + 16 * bl + 4 * kq);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                };
-                int blk0 = 0;
-                for (; blk0 + D <= nblk; blk0 += D) {      // branch-free body: the waits at the loop head stay counted
-#pragma unroll
-                    for (int u = 0; u < D; ++u) block(u, blk0 + u, true);
-                }
-#pragma unroll
-                for (int u = 0; u < D - 1; ++u)
-                    if (blk0 + u < nblk) block(u, blk0 + u, false);
+#endif
+#ifndef CCSD_EMU
+    // Tile tasks: one 16x16 output tile over the full K per task.  Task list: the H tiles (upper triangle, row-major), the
+    // P_0 tiles (row tile major), the P_1 tiles.  The MFMA k slot kq of step j of a 16-wide k block is assigned to
+    // k = 16*blk + 4*kq + j, so a lane's A (and, for H, B) values of four steps are ONE aligned ds_read_b128 of F, and its
+    // weight values one float4 of the transposed copy Wcat^T[col][Kp].  Rows / columns beyond E / wc read clamped (valid)
+    // addresses and are never stored; k >= K meets the zero padding of F.  Even and odd k blocks accumulate into two
+    // independent MFMA chains (a dependent f32 16x16x4 MFMA waits 40 cycles, an independent one issues after 32).  Operands of
+    // four k blocks are kept in flight (the weights come from L2: ~500+ cycles); a slot is refilled only after the MFMAs that
+    // read it have been issued, so the load lands in the same registers.  No atomics: results are bitwise reproducible.
+    typedef float r2_f32x4 __attribute__((ext_vector_type(4)));
+    const int nblk = Kp4 >> 4;
+    const float* WT0 = ra.wp + h0.wcatT;
+    const float* WT1 = ra.wp + h1.wcatT;
+    const bool hmask = p.f_hmask != 0;
+    const float mval_b0 = lin1 ? w[h0.mval.b[0]] : 0.f;       // fetched before the k loops
+    auto run_tile = [&](int t) {
+        const int lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+        int type, i, c;                                       // 0: H(i, c >= i); 1: P_0(i, c); 2: P_1(i, c)
+        if (t < nH) {
+            type = 0; i = 0;
+            int rem = t;
+            while (rem >= MT - i) { rem -= MT - i; ++i; }
+            c = i + rem;
+        } else if (t < nH + MT * nt0) {
+            type = 1; i = (t - nH) / nt0; c = (t - nH) % nt0;
+        } else {
+            type = 2; i = (t - nH - MT * nt0) / nt1; c = (t - nH - MT * nt0) % nt1;
+        }
+        const int ra_ = 16 * i + l15;
+        const float* pa = sF + (ra_ < E ? ra_ : E - 1) * ldk + 4 * kq;
+        int offB = 0;                                         // H tiles: B rows of F in LDS
+        const float* wtp = WT0;                               // P tiles: column of Wcat^T in global memory
+        if (type == 0) {
+            const int rb_ = 16 * c + l15;
+            offB = (rb_ < E ? rb_ : E - 1) * ldk + 4 * kq;
+        } else {
+            const int wcn = type == 1 ? wc0 : wc1, n = 16 * c + l15;
+            wtp = (type == 1 ? WT0 : WT1) + (size_t)(n < wcn ? n : wcn - 1) * Kp4 + 4 * kq;
+        }
+        r2_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        float upart = 0.f;
+        // the k loop, specialised on where the B operand lives (LDS / global) and on the masked-A kind
+        auto kloop = [&](auto LB, auto K1) {
+            constexpr bool lb = decltype(LB)::v, k1 = decltype(K1)::v;
+            auto ldB = [&](int blk) -> float4 {
+                if (lb) return *reinterpret_cast<const float4*>(sF + offB + 16 * blk);
+                return *reinterpret_cast<const float4*>(wtp + 16 * blk);
             };
-            if (kind == 1) kloop(BoolTag<false>{}, BoolTag<false>{}, BoolTag<true>{});
-            else if (blds[0] && blds[1]) kloop(BoolTag<true>{}, BoolTag<true>{}, BoolTag<false>{});
-            else if (blds[0]) kloop(BoolTag<true>{}, BoolTag<false>{}, BoolTag<false>{});
-            else kloop(BoolTag<false>{}, BoolTag<false>{}, BoolTag<false>{});
+            constexpr int D = 4;
+            float4 ab[D], bb[D];
+            unsigned int fb[D];                                   // cell-mask bytes of the block (masked-A kind only)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                if (ttype[q] < 0) continue;
-                const int n = 16 * tcol[q] + l15;
-                const int mb = 16 * i + 4 * kq;
-                if (ttype[q] == 0) {
-                    if (n < E) {
+            for (int u = 0; u < D; ++u) {
+                const int bl = u < nblk ? u : nblk - 1;
+                ab[u] = *reinterpret_cast<const float4*>(pa + 16 * bl);
+                bb[u] = ldB(bl);
+                fb[u] = k1 ? *reinterpret_cast<const unsigned int*>(sFrb + 16 * bl + 4 * kq) : 0u;
+            }
+            auto block = [&](int u, int blk, bool refill) {
+                float4 a4 = ab[u];
+                const float4 b4 = bb[u];
+                if (k1) {
+                    const unsigned int f4 = fb[u];
+                    const float fr0 = (float)(f4 & 0xffu), fr1 = (float)((f4 >> 8) & 0xffu), fr2 = (float)((f4 >> 16) & 0xffu),
+                                fr3 = (float)(f4 >> 24);
+                    if (GEN1) {   // general mlp_value: rank2' element-wise on the fly (hodge_attention.py:322-323)
+                        const int r = 16 * i + l15, e = r < E ? r : E - 1;
+                        float fv[4] = {a4.x, a4.y, a4.z, a4.w};
+                        const float frv[4] = {fr0, fr1, fr2, fr3};
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int m = mb + r;
-                            if (m < E) {
-                                const float hv = (hmask && m == n) ? 0.f : acc[q][r];   // hodge_mask zeroes the diagonal (cc_utils.py:964-969)
-                                sH[m * ldh + n] = hv;
-                                sH[n * ldh + m] = hv;
-                            }
+                        for (int j = 0; j < 4; ++j) {
+                            float iin[CCSD_SMALLW], out[CCSD_SMALLW];
+#pragma unroll
+                            for (int cc = 0; cc < CCSD_SMALLW; ++cc) iin[cc] = cc < h0.cin ? sAco[cc * E + e] * fv[j] : 0.f;
+                            small_mlp<CCSD_SMALLW>(h0.mval, w, iin, out);
+                            fv[j] = sFl[e] * out[0] * frv[j];
                         }
+                        a4 = make_float4(fv[0], fv[1], fv[2], fv[3]);
+                    } else {
+                        a4.x *= fr0; a4.y *= fr1; a4.z *= fr2; a4.w *= fr3;
+                        upart = fmaf(fr0, b4.x, fmaf(fr1, b4.y, fmaf(fr2, b4.z, fmaf(fr3, b4.w, upart))));
                     }
-                } else if (ttype[q] == 1) {
-                    if (n < wc0) {
-                        float* dst = ra.P0 + ((size_t)b * E + mb) * wc0 + n;
+                }
+                r2_f32x4& acc = (u & 1) ? acc1 : acc0;            // block parity == slot parity (D even, block counter a multiple of D)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
+                if (refill) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int bl = blk + D < nblk ? blk + D : nblk - 1;   // clamped: a harmless reload at the tail
+                    ab[u] = *reinterpret_cast<const float4*>(pa + 16 * bl);
+                    bb[u] = ldB(bl);
+                    if (k1) fb[u] = *reinterpret_cast<const unsigned int*>(sFrb + 16 * bl + 4 * kq);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            int blk0 = 0;
+            for (; blk0 + D <= nblk; blk0 += D) {      // branch-free body: the waits at the loop head stay counted
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (mb + r < E) dst[(size_t)r * wc0] = acc[q][r];
-                    }
-                } else {
-                    float un = upart[q];                   // fr . Wcat_1 column: reduce the four k residue classes
-                    un += __shfl_xor(un, 16, 64);
-                    un += __shfl_xor(un, 32, 64);
-                    if (n < wc1) {
-                        // rank2'[e,k] = fl[e] fr[k] (s[e] F[e,k] + b)  ->  P_1[e,:] = fl[e] (s[e] ((F.fr) W_1)[e,:] + b (fr W_1))
-                        float* dst = ra.P1 + ((size_t)b * E + mb) * wc1 + n;
-                        const float bu = mval_b0 * un;
+                for (int u = 0; u < D; ++u) block(u, blk0 + u, true);
+            }
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int m = mb + r, mc = m < E ? m : E - 1;
-                            const float v = GEN1 ? acc[q][r] : sFl[mc] * fmaf(sRow[mc], acc[q][r], bu);
-                            if (m < E) dst[(size_t)r * wc1] = v;
-                        }
+            for (int u = 0; u < D - 1; ++u)
+                if (blk0 + u < nblk) block(u, blk0 + u, false);
+        };
+        if (type == 2) kloop(BoolTag<false>{}, BoolTag<true>{});
+        else if (type == 0) kloop(BoolTag<true>{}, BoolTag<false>{});
+        else kloop(BoolTag<false>{}, BoolTag<false>{});
+        const r2_f32x4 acc = acc0 + acc1;
+        const int n = 16 * c + l15;
+        const int mb = 16 * i + 4 * kq;
+        if (type == 0) {
+            if (n < E) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mb + r;
+                    if (m < E) {
+                        const float hv = (hmask && m == n) ? 0.f : acc[r];   // hodge_mask zeroes the diagonal (cc_utils.py:964-969)
+                        sH[m * ldh + n] = hv;
+                        sH[n * ldh + m] = hv;
                     }
                 }
             }
-            if (pr == 0) stamp(ra.dbg, 6);
-            if (kind == 0 && first < nh) {
-                // this task wrote H tiles: publish (a wave's LDS operations complete in order)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) atomicAdd(&s_hdone, 1);
+            // this task wrote an H tile: publish (a wave's LDS operations complete in order)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) atomicAdd(&s_hdone, 1);
+        } else if (type == 1) {
+            if (n < wc0) {
+                float* dst = ra.P0 + ((size_t)b * E + mb) * wc0 + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (mb + r < E) dst[(size_t)r * wc0] = acc[r];
+            }
+        } else {
+            float un = upart;                      // fr . Wcat_1 column: reduce the four k residue classes
+            un += __shfl_xor(un, 16, 64);
+            un += __shfl_xor(un, 32, 64);
+            if (n < wc1) {
+                // rank2'[e,k] = fl[e] fr[k] (s[e] F[e,k] + b)  ->  P_1[e,:] = fl[e] (s[e] ((F.fr) W_1)[e,:] + b (fr W_1))
+                float* dst = ra.P1 + ((size_t)b * E + mb) * wc1 + n;
+                const float bu = mval_b0 * un;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mb + r, mc = m < E ? m : E - 1;
+                    const float v = GEN1 ? acc[r] : sFl[mc] * fmaf(sRow[mc], acc[r], bu);
+                    if (m < E) dst[(size_t)r * wc1] = v;
+                }
             }
         }
+    };
+    // Phase 1 = the H tiles plus as many projection tiles as it takes to give every wave the same number of tasks.  The other
+    // projection tiles (they depend on nothing but F) are run by the waves BETWEEN their column tiles of phase 2 (affine
+    // path): phase 2's epilogue is pure VALU work (Philox, Box-Muller, masks, update), the projection tiles pure MFMA work, and
+    // the partner waves of a SIMD then feed different pipes instead of queueing for the same one phase after phase.
+    nHtasks = nH;
+    const int nw1 = nth >> 6, wave1 = tid >> 6;
+    int n1 = ntask;
+    if (AFFINE) {
+        n1 = ((nH + nw1 - 1) / nw1) * nw1;
+        if (n1 > ntask) n1 = ntask;
     }
+    for (int t = wave1; t < n1; t += nw1) {
+        run_tile(t);
+        if (t == 0) stamp(ra.dbg, 6);
+    }
+
     stamp(ra.dbg, 7);
     // No workgroup barrier here: phase 2 only READS the rank-2 block (its results go straight to HBM), so a wave may start
     // it as soon as H is complete -- the waves with the lighter phase-1 tasks do not wait for the projection tasks.
@@ -1766,7 +1755,169 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
             }
     }
 #else
-    {
+    if constexpr (AFFINE) {
+        // Affine ScoreNetworkF (every shipped CC checkpoint but ENZYMES): net = fl[e] fr[k] (alpha f + beta (H F) + gamma).
+        // The tile loop is specialised per epilogue mode and noise source (no per-element mode branches) and organised so that
+        // the epilogue needs no address arithmetic of its own:
+        //  * contraction index in the PERMUTED slot order for the TF full 16-wide blocks (k slot kq of step j of block t <->
+        //    e' = 16 t + 4 kq + j): the lane's B operands of block t ARE F[16 t + 4 kq + r][n], r = 0..3, i.e. the F values of its
+        //    own accumulator rows of row tile t -- the epilogue reads f from registers; the remainder of E (E mod 16 <= 12)
+        //    follows in RS plain steps (e' = 16 TF + 4 s + kq): no MFMA step is spent on padding of the contraction index;
+        //  * H's A-fragments are re-read from LDS per column tile (16-byte aligned rows: one ds_read_b128 per (row tile, block))
+        //    instead of living in 36 registers for the whole phase;
+        //  * masks: fl of the lane's four rows is one ds_read_b128 of sFl, fr one byte per column tile;
+        //  * HBM: uniform base pointer + one per-lane 32-bit element offset, advanced by uniform row / tile strides.
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const int wave = tid >> 6, nw = nth >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+        constexpr int TF = RS ? MT - 1 : MT;               // full blocks of the contraction index
+        const bool padblk = RS == 0 && (E & 15) != 0;      // the last full block reaches beyond E: its A values are zeroed
+        const int ar0 = (l15 < E ? l15 : E - 1) * ldh + 4 * kq;   // A: row l15 of row tile 0, slot group kq
+        const int arL = ((16 * (MT - 1) + l15 < E) ? 16 * (MT - 1) + l15 : E - 1) * ldh + 4 * kq;   // ... of the last row tile (clamped)
+        const int brow = 4 * kq * ldk;                     // B: row 4 kq of block 0; block t, step j: + (16 t + j) ldk
+        const unsigned vo = (unsigned)(4 * kq * K + l15);  // element offset of (row 4 kq, column l15) inside the complex's block
+        const bool cn2 = p.f_cnum == 2;
+        auto coltile = [&](auto MODE_, auto INJ_, int tn) {
+            constexpr int MODE = decltype(MODE_)::value;   // 0 score, 1 norms, 2 predictor, 3 predictor + mean output
+            constexpr bool INJ = decltype(INJ_)::value;    // host-supplied raw draws instead of Philox
+            // net' = s * net with s = sscale (score), 1 (norms), pb (predictor): folded into the three affine constants
+            const float s_ = MODE == 0 ? ep.sscale : MODE == 1 ? 1.f : ep.pb;
+            const float sa = s_ * p.f_alpha, sb = s_ * p.f_beta, sg = s_ * p.f_gamma;
+            const float pa = ep.pa, pc = ep.pc;
+            float* const outp = ep.out + (size_t)b * E * K;
+            float* const meanp = MODE == 3 ? ep.mean + (size_t)b * E * K : nullptr;
+            const float* const zrp = INJ ? na.zr + (size_t)b * E * K : nullptr;
+            {
+                const int n = 16 * tn + l15;
+                const bool nin = n < K;
+                const int nc = nin ? n : K - 1;
+                // B operands: bv[4 t + j] = F[16 t + 4 kq + j][n] (permuted blocks), bvr[s] = F[16 TF + 4 s + kq][n] (remainder)
+                float bv[TF ? 4 * TF : 1], bvr[RS ? RS : 1];
+                const float* fb = sF + brow + nc;
+#pragma unroll
+                for (int t = 0; t < TF; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = 16 * t + 4 * kq + j;
+                        bv[4 * t + j] = (t < MT - 1 || !padblk) ? fb[(16 * t + j) * ldk] : sF[(c < E ? c : E - 1) * ldk + nc];
+                    }
+#pragma unroll
+                for (int s0 = 0; s0 < RS; ++s0) {
+                    const int c = 16 * TF + 4 * s0 + kq;
+                    bvr[s0] = sF[(c < E ? c : E - 1) * ldk + nc];
+                }
+                f32x4 acc[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (cn2) {
+                    int ao = ar0, aL = arL;
+                    asm volatile("" : "+v"(ao), "+v"(aL));  // opaque per tile: the loop-invariant A loads must not be hoisted into registers
+#pragma unroll
+                    for (int t = 0; t < TF; ++t) {
+                        float4 a4[MT];
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+                            a4[i] = *reinterpret_cast<const float4*>(sH + (i < MT - 1 ? ao + 16 * i * ldh : aL) + 16 * t);
+                        if (t == MT - 1 && padblk) {       // columns 16 t + 4 kq + j >= E: whatever was read, the operand is zero
+                            const int c0 = 16 * t + 4 * kq;
+#pragma unroll
+                            for (int i = 0; i < MT; ++i) {
+                                a4[i].x = c0 < E ? a4[i].x : 0.f; a4[i].y = c0 + 1 < E ? a4[i].y : 0.f;
+                                a4[i].z = c0 + 2 < E ? a4[i].z : 0.f; a4[i].w = c0 + 3 < E ? a4[i].w : 0.f;
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) {
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].x, bv[4 * t + 0], acc[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].y, bv[4 * t + 1], acc[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].z, bv[4 * t + 2], acc[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].w, bv[4 * t + 3], acc[i], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int s0 = 0; s0 < RS; ++s0) {
+                        const int c = 16 * TF + 4 * s0 + kq;   // contraction index of this lane's slot
+                        const int cc = (c < E ? c : E - 1) - 4 * kq;
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) {
+                            const float av = sH[(i < MT - 1 ? ao + 16 * i * ldh : aL) + cc];
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(c < E ? av : 0.f, bvr[s0], acc[i], 0, 0, 0);
+                        }
+                    }
+                }
+                if (nin) {                                 // false only for the padding columns of the last column tile
+                    const float fr = (float)sFrb[n];
+                    unsigned gi = vo + 16u * (unsigned)tn;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const bool last = i == MT - 1;     // only the last row tile can reach beyond E
+                        const int e0 = 16 * i + 4 * kq;
+                        if (!last || e0 < E) {
+                            float z[4] = {0.f, 0.f, 0.f, 0.f};
+                            if (MODE != 0) {
+                                if (INJ) {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) z[r] = (!last || e0 + r < E) ? zrp[gi + (unsigned)(r * K)] : 0.f;
+                                } else {
+                                    philox_normal4(na.seed, na.draw_r, na.b_off + b, (unsigned)((4 * i + kq) * K + n), z);   // one Philox group = 4 edge rows
+                                }
+                            }
+                            const float4 fl4 = *reinterpret_cast<const float4*>(sFl + e0);   // sFl: 64 entries, zero beyond E
+                            const float flv[4] = {fl4.x, fl4.y, fl4.z, fl4.w};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int e = e0 + r;
+                                const float f = i < TF ? bv[4 * (i < TF ? i : 0) + r] : sF[(e < E ? e : E - 1) * ldk + n];
+                                const float m = flv[r] * fr;                     // flags_left * flags_right, cc_utils.py:590
+                                const float net = m * fmaf(sb, acc[i][r], fmaf(sa, f, sg));
+                                const unsigned g = gi + (unsigned)(r * K);
+                                if (!last || e < E) {
+                                    if (MODE == 0) {
+                                        outp[g] = net;
+                                    } else {
+                                        const float zz = z[r] * m;               // gen_noise_rank2, cc_utils.py:613-615
+                                        if (MODE == 1) {
+                                            outp[g] = net;
+                                            s_net = fmaf(net, net, s_net);
+                                            s_z = fmaf(zz, zz, s_z);
+                                        } else {
+                                            const float mean = fmaf(pa, f, net); // v_mean = pa v + pb net (pb folded into net)
+                                            if (MODE == 3) meanp[g] = mean;
+                                            outp[g] = fmaf(pc, zz, mean);
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        gi += 16u * (unsigned)K;
+                    }
+                }
+            }
+        };
+        typedef std::integral_constant<bool, false> NoInj;
+        typedef std::integral_constant<bool, true> Inj;
+        const bool inj = na.zr != nullptr && ep.mode != MODE_SCORE;
+        const int cmode = ep.mode == MODE_SCORE ? 0 : ep.mode == MODE_NORMS ? 1 : ep.mean == nullptr ? 2 : 3;
+        // Static schedule of a wave: its column tiles tn = wave, wave + nw, ... with its projection tiles (task n1 + wave, + nw,
+        // ...) in between -- before the first column tile for the waves of the lower half, after the second one for the upper
+        // half, so that the two waves a SIMD holds are in MFMA-bound and VALU-bound code at different times.  (Static, hence
+        // the per-thread accumulation order of the Langevin norms is fixed and runs are bitwise reproducible.)
+        int pt = n1 + wave;
+        const int pslot = wave < (nw >> 1) ? 0 : 2;
+        int cnt = 0;
+        for (int tn = wave; tn < ntn; tn += nw, ++cnt) {
+            if (cnt == pslot && pt < ntask) { run_tile(pt); pt += nw; }
+            switch (cmode * 2 + (inj ? 1 : 0)) {
+                case 0: case 1: coltile(std::integral_constant<int, 0>{}, NoInj{}, tn); break;
+                case 2: coltile(std::integral_constant<int, 1>{}, NoInj{}, tn); break;
+                case 3: coltile(std::integral_constant<int, 1>{}, Inj{}, tn); break;
+                case 4: coltile(std::integral_constant<int, 2>{}, NoInj{}, tn); break;
+                case 5: coltile(std::integral_constant<int, 2>{}, Inj{}, tn); break;
+                case 6: coltile(std::integral_constant<int, 3>{}, NoInj{}, tn); break;
+                default: coltile(std::integral_constant<int, 3>{}, Inj{}, tn); break;
+            }
+        }
+        for (; pt < ntask; pt += nw) run_tile(pt);
+    } else {
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         const int wave = tid >> 6, nw = nth >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
         constexpr int KSE = 4 * MT;                        // ceil(16*MT / 4) k-steps cover E <= 16*MT
