@@ -42,7 +42,7 @@ WORKLOADS = {
     "qm9_CC": dict(ckpt="ccsd_qm9_CC", data="QM9", batch=1024, hist=QM9_HIST, predictor="Reverse", corrector="Langevin", snr=0.2, scale_eps=0.7,
                    flop_x=71_424, flop_a=10_710_522, flop_f=3_220_992,
                    desc="qm9_CC N=9 F=4 E=36 K=466, B={B} per GPU, VE x3, Reverse+Langevin snr=0.2 scale_eps=0.7 n_steps=1, 1000 scales"),
-    "community_small_CC": dict(ckpt="ccsd_community_small_CC", data="community_small_CC", batch=512, hist=COMMUNITY_HIST, predictor="Euler", corrector="Langevin",
+    "community_small_CC": dict(ckpt="ccsd_community_small_CC", data="community_small_CC", batch=512, cpu_batch=32, wc=16, hist=COMMUNITY_HIST, predictor="Euler", corrector="Langevin",
                                snr=0.05, scale_eps=0.7, flop_x=3_014_720, flop_a=192_613_760, flop_f=168_081_600,
                                desc="community_small_CC N=20 F=11 E=190 K=1140, B={B} per GPU, VP x3, Euler+Langevin snr=0.05 scale_eps=0.7, 1000 scales"),
     "community_small": dict(ckpt="gdss_community_small", data="community_small", batch=16, hist=COMMUNITY_HIST, predictor="Euler", corrector="Langevin",
@@ -52,6 +52,11 @@ WORKLOADS = {
                      snr=0.2, scale_eps=0.9, flop_x=945_440, flop_a=58_489_296, flop_f=0,
                      desc="zinc250k (graph-only substitute for the infeasible zinc250k_CC, SURVEY 8d 5a) N=38 F=9, B={B} per GPU, "
                           "VP(x)/VE(adj), Reverse+Langevin snr=0.2 scale_eps=0.9, 1000 scales; synthetic node-count mix"),
+    "zinc250k_CC_5b": dict(ckpt="zinc250k_CC_5b", data="ZINC250k", batch=256, cpu_batch=2, hist={38: 1, 30: 2, 24: 4, 23: 4, 20: 2}, predictor="Reverse",
+                           corrector="Langevin", snr=0.2, scale_eps=0.9, flop_x=None, flop_a=None, flop_f=None, wc=8,
+                           desc="zinc250k_CC substitute 5b (SURVEY 8d: the config's N=38 and network hyper-parameters, d_min=d_max=3 instead of the "
+                                "infeasible d_max=24) N=38 F=9 E=703 K=8436, B={B} per GPU, VP(x)/VE/VE, Reverse+Langevin snr=0.2 scale_eps=0.9, "
+                                "1000 scales; reference-initialised random weights, synthetic node-count mix"),
     "qm9_Base_CC": dict(ckpt="ccsd_qm9_Base_CC", data="QM9", batch=1024, hist=QM9_HIST, predictor="Reverse", corrector="Langevin", snr=0.2,
                         scale_eps=0.7, flop_x=None, flop_a=None, flop_f=None,
                         desc="qm9_Base_CC (ScoreNetworkA_Base_CC ablation) N=9 F=4 E=36 K=466, B={B} per GPU, VE x3, Reverse+Langevin "
@@ -134,6 +139,8 @@ def load_workload(wname: str, device):
 
     wl = WORKLOADS[wname]
     is_cc = wname not in ("community_small", "zinc250k")
+    if wl["ckpt"] == "zinc250k_CC_5b":
+        pass   # packaged neutral-format file written by tools/make_golden.py::kat_zinc5b (no shipped checkpoint exists)
     ck = loader.load_ckpt({"ckpt": wl["ckpt"], "data": {"data": wl["data"]}, "folder": ROOT}, device, is_cc=is_cc)
     names = ["x", "adj"] + (["rank2"] if is_cc else [])
     return ck, names, is_cc
@@ -141,8 +148,9 @@ def load_workload(wname: str, device):
 
 def cpu_baseline(wname: str, B: int, budget_s: float = 25.0):
     """The oracle (CPU restatement certified bit-identical to the reference) timed on the host cores, on a bounded sample of
-    the same workload: the full batch, up to 10 PC steps after 1 warm-up step (fewer when a step is so slow that 10 would
-    exceed ~25 s), scaled to 1000 steps."""
+    the same workload: the full batch (the workload's `cpu_batch` complexes where a full-batch step would take minutes), up
+    to 10 PC steps after 1 warm-up step (fewer when a step is so slow that 10 would exceed ~25 s), scaled to 1000 steps."""
+    B = min(B, WORKLOADS[wname].get("cpu_batch", B))
     import torch
 
     from ccsd_amd import loader
@@ -197,6 +205,10 @@ def kernel_work(wname: str, kname: str, E: int, K: int):
         return wl["flop_f"], 2 * E * K * 4, "read + write of rank2 (E*K fp32 each)"
     if kname in ("k_langevin_apply", "k_s4_apply"):
         return None, 3 * E * K * 4, "read state + raw score, write state (rank2 dominates)"
+    if kname == "k_gemm_p" and wl.get("wc"):
+        return 2 * E * K * wl["wc"], None, "hodge projection GEMM P_0 = rank2 . Wcat (2 E K wc FLOPs)"
+    if kname == "k_gemm_h":
+        return 2 * E * E * K, None, "H = F F^T as written (2 E^2 K FLOPs; the kernel computes the upper-triangle tiles only)"
     return None, None, ""
 
 

@@ -555,3 +555,68 @@ def case_harness_vs_oracle(lib, tmp_path, name, cfg_yaml, ckpt, max_steps):
     occ = (out["rank2_int"].cpu() > 0).any(dim=1)
     assert counts.tolist() == occ.sum(dim=1).tolist()
     return out
+
+
+def zinc5b_setup():
+    """kat_zinc250k_CC_5b.npz: (golden, meta, state dicts, flags, inputs).  SURVEY 8(d) substitute 5b: N = 38, the network
+    hyper-parameters of the reference's config/zinc250k_CC.yaml, d_min = d_max = 3 (E = 703, K = 8436), weights initialised
+    by the reference's constructors."""
+    g = load_golden("kat_zinc250k_CC_5b.npz")
+    assert rng_matches(g)
+    meta = json.loads(str(g["meta"]))
+    sd = {tag: {k[len(tag) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}/w/")} for tag in ("x", "adj", "rank2")}
+    N, Fd, d_min, d_max, E, K = meta["dims"]
+    flags = torch.from_numpy(g["flags"])
+    x, adj, rank2 = masked_state(int(g["seed"]), flags.shape[0], N, Fd, True, d_min, d_max, flags)
+    return g, meta, sd, flags, (x, adj, rank2)
+
+
+def zinc5b_check_rank2(got, g, key, what):
+    got = got.detach().cpu()
+    cs = g[f"{key}_checksum"]
+    scale = float(cs[2])
+    sample = got[:, ::37, ::53]
+    err = (sample - torch.from_numpy(g[f"{key}_sample"])).abs().max().item()
+    assert err <= RTOL * scale, f"{what}: sampled entries differ by {err:.3e} (scale {scale:.3e})"
+    n = got.numel()
+    assert abs(got.double().sum().item() - cs[0]) <= 1e-5 * scale * n ** 0.5 * 10, f"{what}: sum differs"
+    assert abs(got.abs().double().sum().item() - cs[1]) <= 1e-5 * cs[1], f"{what}: sum of magnitudes differs"
+    assert abs(got.abs().max().item() - scale) <= RTOL * scale
+
+
+def case_zinc5b(lib, device):
+    """Forwards of the three networks and a 3-scale Reverse + Langevin run (every draw from torch's CPU generator) of the N = 38
+    combinatorial-complex substitute against the reference's outputs: k_xa with a 38-node graph and 10 channels, the tiled
+    rank-2 kernels at E = 703, K = 8436 (projection GEMM with K = 8436, cnum = 1 ScoreNetworkF: no Hodge Laplacian term)."""
+    g, meta, sd, flags, (x, adj, rank2) = zinc5b_setup()
+    N, Fd, d_min, d_max, E, K = meta["dims"]
+    pm = meta["params"]
+    eng = PCEngine(pm["x"], sd["x"], pm["adj"], sd["adj"], pm["rank2"], sd["rank2"], N=N, F=Fd, is_cc=True, d_min=d_min, d_max=d_max,
+                   device=device, lib=lib)
+    dv = lambda t: t.to(device)
+    assert_close(eng.score(0, dv(x), dv(adj), dv(rank2), dv(flags)), g["x/out"], "5b net_x")
+    assert_close(eng.score(1, dv(x), dv(adj), dv(rank2), dv(flags)), g["adj/out"], "5b net_adj")
+    zinc5b_check_rank2(eng.score(2, dv(x), dv(adj), dv(rank2), dv(flags)), g, "rank2/out", "5b net_rank2")
+    del eng
+    sdes = [loader.load_sde(dict(meta["sde"][p], num_scales=3)) for p in ("x", "adj", "rank2")]
+    models = [loader.load_model_from_ckpt(pm[p], sd[p], device) for p in ("x", "adj", "rank2")]
+    sm = meta["sampler"]
+    B = flags.shape[0]
+    fn = solver.get_pc_sampler(sde_x=sdes[0], sde_adj=sdes[1], sde_rank2=sdes[2], shape_x=(B, N, Fd), shape_adj=(B, N, N),
+                               shape_rank2=(B, E, K), predictor=sm["predictor"], corrector=sm["corrector"], snr=sm["snr"],
+                               scale_eps=sm["scale_eps"], n_steps=sm["n_steps"], probability_flow=False, continuous=True, denoise=True,
+                               eps=1e-4, device=device, is_cc=True, d_min=d_min, d_max=d_max, rng="torch_cpu", lib=lib)
+    torch.manual_seed(int(g["seed"]))
+    res = fn(*models, dv(flags))
+    assert_close(res[0], g["k3/x"], "5b k3 x")
+    assert_close(res[1], g["k3/adj"], "5b k3 adj")
+    zinc5b_check_rank2(res[2], g, "k3/rank2", "5b k3 rank2")
+    # quantize_mol: bit-exact wherever the reference value is not within the float tolerance of a threshold
+    ref = torch.from_numpy(g["k3/adj"]).double()
+    tol = RTOL * max(ref.abs().max().item(), 1.0)
+    safe = torch.ones_like(ref, dtype=torch.bool)
+    for t in (0.5, 1.5, 2.5):
+        safe &= (ref - t).abs() > tol
+    assert safe.double().mean().item() > 0.99
+    q = PCEngine(None, None, None, None, None, None, N=N, F=1, is_cc=False, device=device, lib=lib).quantize(res[1], -1.0).cpu()
+    assert torch.equal(q[safe], torch.from_numpy(g["k3/quantize_mol_adj"])[safe])

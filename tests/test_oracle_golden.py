@@ -229,6 +229,36 @@ def test_g5_pc_sampler_identical_seed(gname, ckpt, cases):
             assert np.array_equal(O.quantize(res[2]).numpy().astype(np.uint8), g[f"{case}/quantize_rank2"])
 
 
+def test_zinc5b_substitute_networks_and_sampler():
+    """SURVEY 8(d) substitute 5b (N = 38 CC, d_min = d_max = 3, zinc250k_CC.yaml hyper-parameters, reference-initialised
+    weights): forwards and a 3-scale sampler run."""
+    from tests import parity_cases as pc
+
+    g, meta, sd, flags, (x, adj, rank2) = pc.zinc5b_setup()
+    N, Fd, d_min, d_max, E, K = meta["dims"]
+    pm = meta["params"]
+    w = {p: {k: v.clone().requires_grad_(True) for k, v in sd[p].items()} for p in sd}
+    with torch.no_grad():
+        _close(O.run_network(pm["x"], w["x"], x, adj, rank2, flags).numpy(), g["x/out"], "5b x")
+        _close(O.run_network(pm["adj"], w["adj"], x, adj, rank2, flags).numpy(), g["adj/out"], "5b adj")
+        o = O.run_network(pm["rank2"], w["rank2"], x, adj, rank2, flags)
+        _close(o[:, ::37, ::53].numpy(), g["rank2/out_sample"], "5b rank2")
+    sdes = [O.load_sde(dict(meta["sde"][p], num_scales=3)) for p in ("x", "adj", "rank2")]
+    nets = [(lambda x_, a_, r_, f_, p=p: O.run_network(pm[p], w[p], x_, a_, r_, f_)) for p in ("x", "adj", "rank2")]
+    sm = meta["sampler"]
+    B = flags.shape[0]
+    fn = O.get_pc_sampler(sde_x=sdes[0], sde_adj=sdes[1], sde_rank2=sdes[2], shape_x=(B, N, Fd), shape_adj=(B, N, N),
+                          shape_rank2=(B, E, K), predictor=sm["predictor"], corrector=sm["corrector"], snr=sm["snr"],
+                          scale_eps=sm["scale_eps"], n_steps=1, probability_flow=False, continuous=True, denoise=True, eps=1e-4,
+                          is_cc=True, d_min=d_min, d_max=d_max, keep_traj=False)
+    torch.manual_seed(int(g["seed"]))
+    res = fn(*nets, flags)
+    _close(res[0].numpy(), g["k3/x"], "5b k3 x")
+    _close(res[1].numpy(), g["k3/adj"], "5b k3 adj")
+    _close(res[2][:, ::37, ::53].numpy(), g["k3/rank2_sample"], "5b k3 rank2")
+    assert np.array_equal(O.quantize_mol(res[1]), g["k3/quantize_mol_adj"])
+
+
 def test_registry_errors_match_reference():
     s = O.SDE("VE", 0.1, 1.0, 10)
     with pytest.raises(NotImplementedError):

@@ -377,6 +377,89 @@ def kat_gmh_models():
     print("kat_gmh", {k: v.shape for k, v in out.items() if k.endswith("/out")})
 
 
+def kat_zinc5b():
+    """SURVEY 8(d) substitute 5b for the infeasible zinc250k_CC config (d_max = 24 -> K = 2.6e11): the same N = 38 and the
+    hyper-parameters of config/zinc250k_CC.yaml:38-64 (loader.load_model_params, loader.py:461-566) with d_min = d_max = 3
+    (E = 703, K = 8436), networks built and randomly initialised by the reference's constructors (biases perturbed), B = 2.
+    rank-2 sized outputs (47 MB) are stored as a strided sample + checksums."""
+    from ccsd.src.models.ScoreNetwork_A_CC import ScoreNetworkA_CC
+    from ccsd.src.models.ScoreNetwork_F import ScoreNetworkF
+    from ccsd.src.models.ScoreNetwork_X import ScoreNetworkX
+
+    N, Fd, d_min, d_max = 38, 9, 3, 3
+    px = dict(max_feat_num=Fd, depth=2, nhid=2, use_bn=False, is_cc=True)
+    pa = dict(max_feat_num=Fd, max_node_num=N, d_min=d_min, d_max=d_max, nhid=2, nhid_h=2, num_layers=2, num_layers_h=1,
+              num_linears=2, num_linears_h=1, c_init=2, c_hid=2, c_hid_h=2, c_final=2, c_final_h=2, adim=4, adim_h=2,
+              num_heads=2, num_heads_h=2, conv="GCN", conv_hodge="HCN", use_bn=False, is_cc=True)
+    pf = dict(num_layers_mlp=1, num_layers=1, num_linears=1, nhid=2, c_hid=2, c_final=2, cnum=1, max_node_num=N, d_min=d_min,
+              d_max=d_max, use_hodge_mask=True, use_bn=False, is_cc=True)
+    ref_cc.default_mask.cache_clear()
+    torch.manual_seed(538)
+    nets = {"x": (ScoreNetworkX(**px), dict(px, model_type="ScoreNetworkX")),
+            "adj": (ScoreNetworkA_CC(**pa), dict(pa, model_type="ScoreNetworkA_CC")),
+            "rank2": (ScoreNetworkF(**pf), dict(pf, model_type="ScoreNetworkF"))}
+    for m, _ in nets.values():
+        for k, p in m.named_parameters():
+            if k.endswith("bias"):
+                p.data.normal_(0, 0.2)
+        m.eval()
+    B, seed = 2, 77
+    flags = make_flags(B, N, [38, 23])
+    out = {"flags": flags.numpy(), "seed": seed, "rng_probe": rng_probe(seed)}
+    meta = {}
+    samp = lambda t: t[:, ::37, ::53].contiguous().numpy()
+    x, adj, rank2 = masked_state(seed, B, N, Fd, True, d_min, d_max, flags, 1.0)
+    with torch.no_grad():
+        for tag, (m, p) in nets.items():
+            for k, v in m.state_dict().items():
+                out[f"{tag}/w/{k}"] = v.numpy()
+            meta[tag] = p
+            o = m(x, adj, rank2, flags)
+            if tag == "rank2":
+                out["rank2/out_sample"] = samp(o)
+                out["rank2/out_checksum"] = np.array([o.double().sum().item(), o.abs().double().sum().item(), o.abs().max().item()])
+            else:
+                out[f"{tag}/out"] = o.numpy()
+    # short sampler run with the sampler block of config/zinc250k_CC.yaml:85-90 and its SDEs (:20-35), 3 scales
+    sde_cfg = {"x": dict(type="VP", beta_min=0.1, beta_max=1.0), "adj": dict(type="VE", beta_min=0.2, beta_max=1.0),
+               "rank2": dict(type="VE", beta_min=0.1, beta_max=1.0)}
+    sm = dict(predictor="Reverse", corrector="Langevin", snr=0.2, scale_eps=0.9, n_steps=1)
+    sdes = [ref_loader.load_sde(refshim.EasyDict(dict(sde_cfg[p], num_scales=3))) for p in ("x", "adj", "rank2")]
+    E, K = ref_cc.get_rank2_dim(N, d_min, d_max)
+    fn = ref_solver.get_pc_sampler(sde_x=sdes[0], sde_adj=sdes[1], shape_x=(B, N, Fd), shape_adj=(B, N, N), predictor=sm["predictor"],
+                                   corrector=sm["corrector"], snr=sm["snr"], scale_eps=sm["scale_eps"], n_steps=1,
+                                   probability_flow=False, continuous=True, denoise=True, eps=1e-4, device="cpu", is_cc=True,
+                                   sde_rank2=sdes[2], shape_rank2=(B, E, K), d_min=d_min, d_max=d_max)
+    orig = ref_solver.trange
+    ref_solver.trange = lambda a, b, **k: range(a, b)
+    try:
+        torch.manual_seed(seed)
+        res = fn(nets["x"][0], nets["adj"][0], nets["rank2"][0], flags)
+    finally:
+        ref_solver.trange = orig
+    out["k3/x"], out["k3/adj"] = res[0].numpy(), res[1].numpy()
+    out["k3/rank2_sample"] = samp(res[2])
+    out["k3/rank2_checksum"] = np.array([res[2].double().sum().item(), res[2].abs().double().sum().item(), res[2].abs().max().item()])
+    out["k3/quantize_mol_adj"] = ref_gu.quantize_mol(res[1].clone())
+    thr = torch.tensor([0.5, 1.5, 2.5])
+    out["k3/min_thr_dist"] = np.array((res[1][..., None] - thr).abs().min().item())
+    out["meta"] = json.dumps(dict(params=meta, sde=sde_cfg, sampler=sm, dims=[N, Fd, d_min, d_max, E, K]))
+    np.savez_compressed(os.path.join(GOLD, "kat_zinc250k_CC_5b.npz"), **out)
+    # the same weights as a neutral-format checkpoint (bench.py --workload zinc250k_CC_5b): no shipped checkpoint exists for it
+    arrays = {f"{tag}/{k}": v.detach().cpu().numpy().astype(np.float32) for tag, (m, _) in nets.items() for k, v in m.state_dict().items()}
+    cfg = {"is_cc": True,
+           "data": {"data": "ZINC250k", "max_node_num": N, "max_feat_num": Fd, "d_min": d_min, "d_max": d_max, "batch_size": 1024},
+           "sde": {p: dict(v, num_scales=1000) for p, v in sde_cfg.items()}, "sampler": sm}
+    ck = {"name": "zinc250k_CC_5b", "source": "reference constructors with config/zinc250k_CC.yaml hyper-parameters, d_min = d_max = 3, "
+          "random initialisation (tools/make_golden.py::kat_zinc5b)", "is_cc": True, "config": cfg}
+    for tag, (_, prm) in nets.items():
+        ck[f"params_{tag}"] = prm
+    np.savez_compressed(os.path.join(CKPT, "zinc250k_CC_5b.npz"), **arrays)
+    with open(os.path.join(CKPT, "zinc250k_CC_5b.json"), "w") as f:
+        json.dump(ck, f, indent=1, sort_keys=True)
+    print("kat_zinc5b: E, K =", E, K, "min thr dist", float(out["k3/min_thr_dist"]), {k: v.shape for k, v in out.items() if k.endswith("out") or k.endswith("sample")})
+
+
 def reference_kat_status():
     """Run the reference's own known-answer tests for the path in this container and record the result."""
     files = ["tests/models", "tests/utils/test_graph_utils.py", "tests/utils/test_cc_utils.py",
@@ -459,6 +542,8 @@ def main():
         g5_pc_runs("ccsd_qm9_CC_subvp_mixed", cks["ccsd_qm9_CC"], True, 2, [9, 6],
                    dict(predictor="Reverse", corrector="Langevin", snr=0.2, scale_eps=0.7, n_steps=2, sde_override={"x": sub}),
                    {"k4": (4, None)}, seed=25, min_dist=5e-3)
+    if not only or "zinc5b" in only:
+        kat_zinc5b()
     if not only or "gmh" in only:
         kat_gmh_models()
     if not only or "base" in only:
