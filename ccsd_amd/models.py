@@ -50,7 +50,8 @@ class _ScoreNetwork:
         sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
         expected = dict(_plan.state_dict_shapes(self.params))
         missing = [k for k in expected if k not in sd]
-        unexpected = [k for k in sd if k not in expected]
+        # (BatchNorm1d entries of a use_bn=True checkpoint are tolerated: no such network reaches a forward, plan.reference_forward_error)
+        unexpected = [k for k in sd if k not in expected and ".batch_norms." not in k]
         if strict and (missing or unexpected):
             raise RuntimeError(f"Error(s) in loading state_dict for {self.model_type}: missing {missing}, unexpected {unexpected}")
         for k, shape in expected.items():

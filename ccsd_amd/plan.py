@@ -183,12 +183,53 @@ def complete_params(px: Optional[dict], pa: Optional[dict], pf: Optional[dict], 
 
 
 def _check_supported(p: dict):
-    if p.get("use_bn", False):
-        raise NotImplementedError("use_bn=True is not supported by the HIP path yet")
+    """Constructor-time checks (the reference's constructors raise the same, attention.py:180, hodge_attention.py:181)."""
     if p.get("conv", "GCN") not in ("GCN", "MLP"):
         raise NotImplementedError(f"Convolution layer {p.get('conv')} not implemented.")
-    if p.get("conv_hodge", "HCN") != "HCN":
+    if p.get("conv_hodge", "HCN") not in ("HCN", "MLP"):
         raise NotImplementedError(f"Convolution layer {p.get('conv_hodge')} not implemented.")
+
+
+def reference_forward_error(p: Optional[dict], N: int, B: int = 1) -> Optional[Exception]:
+    """The exception the reference's forward raises for this network (None: it runs) -- for the two switches no shipped config
+    sets and whose reference implementation only type-checks on degenerate shapes (captured from the reference itself in
+    tests/golden/reference_variant_status.json, tools/make_golden.py::reference_variant_status):
+
+    use_bn=True   MLP puts BatchNorm1d(hidden) behind every hidden Linear (layers.py:219-224, 262-275; single-Linear MLPs have
+                  none).  On the (B, N, hidden) activations of ScoreNetworkX's head, ScoreNetworkX_GMH's head and every
+                  multi_channel MLP torch normalises over dim 1 = N and raises unless N == hidden; on the 4-D activations of
+                  ScoreNetworkA*'s final MLP and of ScoreNetworkF's MLPs it raises "expected 2D or 3D input".
+    conv_hodge="MLP"  HodgeAttention applies an MLP with input width K to the E x E hodge adjacency (hodge_attention.py:100-102,
+                  235-241): a matmul shape error unless E == K.
+    The shapes that do type-check (ScoreNetworkX with N == 2 (F + depth nhid); E == K) are not built: NotImplementedError."""
+    if p is None:
+        return None
+    t = p.get("model_type")
+    bn_rt = lambda hid: RuntimeError(f"running_mean should contain {N} elements not {hid}")
+    bn_4d = ValueError("expected 2D or 3D input (got 4D input)")
+    if p.get("use_bn", False):
+        if t == "ScoreNetworkX":
+            hid = 2 * (p["max_feat_num"] + p["depth"] * p["nhid"])
+            return bn_rt(hid) if N != hid else NotImplementedError(
+                "use_bn=True on ScoreNetworkX with N == 2 (F + depth nhid): BatchNorm1d over the node index is not built")
+        if t in ("ScoreNetworkX_GMH", "ScoreNetworkA", "ScoreNetworkA_CC", "ScoreNetworkA_Base_CC"):
+            dims = gmh_layer_dims(p) if t == "ScoreNetworkX_GMH" else attn_layer_dims(p)
+            for cin, cout, *_ in dims:                       # multi_channel: MLP(2, ...) on (B, N, cin * fout)
+                if N != 2 * max(cin, cout):
+                    return bn_rt(2 * max(cin, cout))
+            if t == "ScoreNetworkX_GMH":
+                hid = 2 * (p["max_feat_num"] + p["depth"] * p["nhid"])
+                return bn_rt(hid) if N != hid else NotImplementedError("use_bn=True on ScoreNetworkX_GMH is not built")
+            return bn_4d                                     # final MLP (3 Linears) on (B, N, N, fdim)
+        if t == "ScoreNetworkF" and (p["num_linears"] > 1 or p["num_layers_mlp"] > 1):
+            return bn_4d                                     # HodgeNetworkLayer / final MLP on (B, E, K, C)
+    if t == "ScoreNetworkA_CC" and p.get("conv_hodge", "HCN") == "MLP":
+        E, K = rank2_dim(p["max_node_num"], p["d_min"], p["d_max"])
+        if E != K:
+            return RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({B * E}x{E} and {K}x{2 * p['nhid_h']})")
+        return NotImplementedError('conv_hodge="MLP" with E == K (the only shape the reference\'s MLP over the hodge adjacency '
+                                   "type-checks on) is not built")
+    return None
 
 
 def make_config(px: dict, pa: dict, pf: Optional[dict], *, predictor="Euler", corrector="None", snr=0.1, scale_eps=1.0,
@@ -196,6 +237,9 @@ def make_config(px: dict, pa: dict, pf: Optional[dict], *, predictor="Euler", co
     for p in (px, pa, pf):
         if p is not None:
             _check_supported(p)
+            err = reference_forward_error(p, pa["max_node_num"], max(1, int(batch_hint)))
+            if err is not None:
+                raise err
     if px["model_type"] not in ("ScoreNetworkX", "ScoreNetworkX_GMH"):
         raise NotImplementedError(f"{px['model_type']} is not supported by the HIP path yet")
     if pa["model_type"] not in ("ScoreNetworkA", "ScoreNetworkA_CC", "ScoreNetworkA_Base_CC"):

@@ -56,10 +56,15 @@ def test_invalid_configs_are_rejected(lib):
     assert b"abi_version" in lib.ccsd_last_error()
     cfg = plan.make_config(meta["params_x"], dict(meta["params_adj"], num_layers_h=3), meta["params_rank2"])
     assert lib.ccsd_weight_count(C.byref(cfg)) == 0           # 3 hodge layers: outside the HIP envelope
-    with pytest.raises(NotImplementedError):
+    # use_bn / conv_hodge="MLP": the reference's own forward fails on these shapes, with these exception types
+    with pytest.raises(RuntimeError, match="running_mean should contain 9 elements not 48"):
         plan.make_config(dict(meta["params_x"], use_bn=True), meta["params_adj"], meta["params_rank2"])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="mat1 and mat2 shapes cannot be multiplied"):
         plan.make_config(meta["params_x"], dict(meta["params_adj"], conv_hodge="MLP"), meta["params_rank2"])
+    with pytest.raises(NotImplementedError):
+        plan.make_config(meta["params_x"], dict(meta["params_adj"], conv_hodge="GAT"), meta["params_rank2"])
+    # ... while use_bn on a network whose MLPs are single Linears creates no BatchNorm at all (layers.py:205-224): it runs
+    assert plan.make_config(meta["params_x"], meta["params_adj"], dict(meta["params_rank2"], use_bn=True)).f_num_linears == 1
     with pytest.raises(NotImplementedError):
         plan.make_config(meta["params_x"], dict(meta["params_adj"], conv="GAT"), meta["params_rank2"])
     assert plan.make_config(meta["params_x"], dict(meta["params_adj"], conv="MLP"), meta["params_rank2"]).a_conv_mlp == 1
@@ -88,3 +93,27 @@ def test_pack_weights_errors():
     bad.pop("final.linears.0.bias")
     with pytest.raises(ValueError):
         plan.pack_weights(meta["params_x"], bad, meta["params_adj"], parts["adj"], meta["params_rank2"], parts["rank2"])
+
+
+def test_unshipped_switches_fail_like_the_reference():
+    """use_bn=True and conv_hodge="MLP": tests/golden/reference_variant_status.json holds what the REFERENCE's forward does for a
+    set of configurations (captured by tools/make_golden.py): the product raises the same exception type with the same
+    message where the reference raises, and says NotImplementedError for the two degenerate shapes on which the reference's
+    code happens to type-check (N == hidden width; E == K)."""
+    import json
+
+    st = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_variant_status.json")))
+    nodes = {"bn_x_N5_hidden22": 5, "bn_x_N8_hidden8": 8, "bn_x_gmh": 8}
+    assert len(st) >= 8
+    for tag, v in st.items():
+        p = v["params"]
+        err = plan.reference_forward_error(p, p.get("max_node_num") or nodes[tag], 2)
+        if v["result"] == "error":
+            assert type(err).__name__ == v["type"] and str(err) == v["message"], (tag, err, v)
+        else:
+            assert isinstance(err, NotImplementedError), (tag, err)
+    # the model containers construct (as the reference's modules do) and fail at the first forward / sampler build
+    from ccsd_amd import loader
+
+    m = loader.load_model(dict(st["bn_f"]["params"]))
+    assert m.params["use_bn"] is True

@@ -460,6 +460,61 @@ def kat_zinc5b():
     print("kat_zinc5b: E, K =", E, K, "min thr dist", float(out["k3/min_thr_dist"]), {k: v.shape for k, v in out.items() if k.endswith("out") or k.endswith("sample")})
 
 
+def reference_variant_status():
+    """What the reference itself does with the two config switches no shipped config sets: use_bn=True (layers.py:219-224,
+    262-275: BatchNorm1d(hidden) applied to (B, N, hidden) / (B, N, N, hidden) activations) and conv_hodge="MLP"
+    (hodge_attention.py:100-102, 168-179: an MLP with input width K applied to the E x E hodge adjacency).  Exception types
+    and messages of a forward pass are recorded; the product raises the same types for the same configurations."""
+    from ccsd.src.models.ScoreNetwork_A import ScoreNetworkA
+    from ccsd.src.models.ScoreNetwork_A_CC import ScoreNetworkA_CC
+    from ccsd.src.models.ScoreNetwork_F import ScoreNetworkF
+    from ccsd.src.models.ScoreNetwork_X import ScoreNetworkX, ScoreNetworkX_GMH
+
+    torch.manual_seed(0)
+    out = {}
+
+    def attempt(tag, params, build, args):
+        try:
+            o = build().eval()(*args)
+            out[tag] = {"params": params, "result": "ok", "shape": list(o.shape)}
+        except Exception as e:      # noqa: BLE001 -- the point is to record whatever the reference raises
+            out[tag] = {"params": params, "result": "error", "type": type(e).__name__, "message": str(e)}
+
+    B = 2
+    def inputs(N, Fd, E=None, K=None):
+        x = torch.randn(B, N, Fd); a = torch.randn(B, N, N); a = a + a.transpose(1, 2)
+        return x, a, (torch.randn(B, E, K) if E else None), torch.ones(B, N)
+
+    px = dict(max_feat_num=3, depth=2, nhid=4, use_bn=True, is_cc=False)
+    x, a, _, fl = inputs(5, 3)
+    attempt("bn_x_N5_hidden22", dict(px, model_type="ScoreNetworkX"), lambda: ScoreNetworkX(**px), (x, a, fl))
+    px8 = dict(max_feat_num=2, depth=1, nhid=2, use_bn=True, is_cc=False)        # N == 2 * fdim: the one shape that type-checks
+    x, a, _, fl = inputs(8, 2)
+    attempt("bn_x_N8_hidden8", dict(px8, model_type="ScoreNetworkX"), lambda: ScoreNetworkX(**px8), (x, a, fl))
+    pa = dict(max_feat_num=2, max_node_num=8, nhid=4, num_layers=2, num_linears=2, c_init=2, c_hid=2, c_final=2, adim=4, num_heads=2,
+              conv="GCN", use_bn=True, is_cc=False)
+    attempt("bn_a", dict(pa, model_type="ScoreNetworkA"), lambda: ScoreNetworkA(**pa), (x, a, fl))
+    pg = dict(max_feat_num=2, depth=2, nhid=4, num_linears=2, c_init=2, c_hid=2, c_final=2, adim=4, num_heads=2, conv="GCN", use_bn=True,
+              is_cc=False)
+    attempt("bn_x_gmh", dict(pg, model_type="ScoreNetworkX_GMH"), lambda: ScoreNetworkX_GMH(**pg), (x, a, fl))
+    pf = dict(num_layers_mlp=2, num_layers=1, num_linears=2, nhid=2, c_hid=2, c_final=2, cnum=2, max_node_num=5, d_min=3, d_max=4,
+              use_hodge_mask=True, use_bn=True, is_cc=True)
+    ref_cc.default_mask.cache_clear()
+    x, a, r, fl = inputs(5, 3, 10, 15)
+    attempt("bn_f", dict(pf, model_type="ScoreNetworkF"), lambda: ScoreNetworkF(**pf), (x, a, r, fl))
+    for (N, dmin, dmax) in ((5, 3, 4), (5, 3, 3), (6, 3, 3)):
+        E, K = ref_cc.get_rank2_dim(N, dmin, dmax)
+        pc_ = dict(max_feat_num=3, max_node_num=N, d_min=dmin, d_max=dmax, nhid=4, nhid_h=2, num_layers=2, num_layers_h=2, num_linears=2,
+                   num_linears_h=1, c_init=2, c_hid=2, c_hid_h=2, c_final=2, c_final_h=2, adim=4, adim_h=2, num_heads=2, num_heads_h=2,
+                   conv="GCN", conv_hodge="MLP", use_bn=False, is_cc=True)
+        x, a, r, fl = inputs(N, 3, E, K)
+        attempt(f"conv_hodge_mlp_N{N}_E{E}_K{K}", dict(pc_, model_type="ScoreNetworkA_CC"), lambda: ScoreNetworkA_CC(**pc_), (x, a, r, fl))
+    with open(os.path.join(GOLD, "reference_variant_status.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    for k, v in out.items():
+        print("variant", k, v["result"], v.get("type", ""), v.get("message", v.get("shape")))
+
+
 def reference_kat_status():
     """Run the reference's own known-answer tests for the path in this container and record the result."""
     files = ["tests/models", "tests/utils/test_graph_utils.py", "tests/utils/test_cc_utils.py",
@@ -555,6 +610,8 @@ def main():
                    {"k10": (10, None), "n1000_first3": (None, 3)}, seed=42)
     if not only or "refkat" in only:
         reference_kat_status()
+    if not only or "variants" in only:
+        reference_variant_status()
 
 
 if __name__ == "__main__":
