@@ -72,7 +72,7 @@ KERNEL_BOUND = {"k_xa": "mfma", "k_r2": "hbm", "k_hf_score": "hbm", "k_gemm_h": 
                 "k_s4_apply": "hbm"}
 KERNEL_NAMES = ["k_xa", "k_r2", "k_hf_score", "k_gemm_h", "k_gemm_p", "k_langevin_apply", "k_s4_apply"]
 PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r02_pmc.json", "r01_pmc_traffic.json")]   # newest first
-KERNEL_SOURCES = [os.path.join(ROOT, "ccsd_amd", "csrc", f) for f in ("ccsd_kernels.h", "ccsd_attn_stack.inc", "ccsd_plan.h", "ccsd_api.h")]
+KERNEL_SOURCES = [os.path.join(ROOT, "ccsd_amd", "csrc", f) for f in ("ccsd_dev.h", "ccsd_rank2_common.h", "ccsd_k_rank2.h", "ccsd_k_r2.h", "ccsd_k_xa.h", "ccsd_k_update.h", "ccsd_attn_stack.inc", "ccsd_plan.h", "ccsd_api.h")]
 
 
 def kernel_source_hash() -> str:

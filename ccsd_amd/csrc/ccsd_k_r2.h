@@ -1,0 +1,669 @@
+// ccsd_k_r2.h -- k_r2: the fused rank-2 kernel (one complex per workgroup, rank2 block LDS-resident)
+// Part of the kernel source of libccsd_hip.so (see ccsd_kernels.h for the map).
+#pragma once
+#include "ccsd_rank2_common.h"
+
+struct R2Args {
+    const float* rank2; const float* adj; const float* flags;
+    const unsigned long long* offbits;     // per-sample bitmask of switched-off nodes
+    float* P0; float* P1;
+    int want_p;            // write the hodge projections (the A-network will run on the same state)
+    int ldk, ldh;
+    long long* dbg;
+    const float* wp;       // packed buffer (Wcat^T of the hodge projections)
+    CorrFuse cf;
+};
+
+// MT = ceil(E / 16) row tiles (1..4); RS (affine phase 2 only): plain MFMA steps covering E mod 16 behind the MT - 1 full
+// 16-wide blocks of the contraction index (0: the last block is taken whole, zero padded -- E mod 16 == 0 or > 12);
+// AFFINE: ScoreNetworkF folds to alpha F + beta HF + gamma; GEN1: general (non-affine) mlp_value in the hodge branch.
+// Compile-time so that the common variant carries no general-path code.
+template <int MT, int RS, bool AFFINE, bool GEN1>
+__global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, const float* __restrict__ w,
+                                            const unsigned char* __restrict__ edges,
+                                            const unsigned long long* __restrict__ cells, R2Args ra, RankEpi ep,
+                                            NoiseArgs na) {
+    CCSD_DYN_SMEM(sm);
+    const PlanD& p = *plan;
+    const int E = p.E, K = p.K, N = p.N, NN = N * N, ldk = ra.ldk, ldh = ra.ldh;
+    const int b = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    const int Kp4 = (K + 31) & ~31, Ep4 = (E + 3) & ~3;   // K is zero-padded to whole 8-step batches in LDS
+    float* sF = sm;                        // [E][ldk]
+    float* sH = sF + E * ldk;              // [E][ldh]
+    float* sFl = sH + E * ldh;             // [64]  flags_left (edge masks)
+    float* sRow = sFl + 64;                // [64]  per-row scale of rank2' (linear mlp_value)
+    float* sAco = sRow + 64;               // [cinit][E] adjacency powers' upper triangle
+    float* sAdj = sAco + p.a_cinit * E;    // 3 x [N*N] scratch for the powers
+    float* sRed = sAdj + 3 * NN;           // [64]
+    unsigned char* sFrb = reinterpret_cast<unsigned char*>(sRed + 64);   // [Kp4] flags_right (cell masks) as bytes
+    __shared__ unsigned long long s_off;
+#ifndef CCSD_EMU
+    __shared__ int s_hdone;              // H-tile tasks finished (phase 1 -> 2 hand-over)
+#endif
+    const float* Fg = ra.rank2 + (size_t)b * E * K;
+    const FastDiv dK(K);
+
+    // ---- phase 0: rank2 block -> LDS; masks; adjacency powers
+    stamp(ra.dbg, 0);
+    if (tid == 0) {
+        s_off = ra.offbits[b];                // switched-off nodes (k_flagbits): one load instead of a serial walk over the flags
+#ifndef CCSD_EMU
+        s_hdone = 0;
+#endif
+    }
+    // With the fused Langevin apply (predictor launches of ccsd_sampler_run) the raw scores of the norms pass are loaded
+    // alongside and F + c1*net goes to LDS in the same pass (same fma as k_langevin_apply; the noise term follows below).
+    float c1f = 0.f, c2f = 0.f;
+    if (ra.cf.on) corr_coef(ra.cf, 2, &c1f, &c2f);
+    const float* Ng = ra.cf.on ? ra.cf.net_r + (size_t)b * E * K : Fg;
+    if (((E * K) & 3) == 0) {
+        // the block is 16-byte aligned and a multiple of 16 bytes: batches of four float4 loads in flight per thread
+        const float4* F4 = reinterpret_cast<const float4*>(Fg);
+        const float4* N4 = reinterpret_cast<const float4*>(Ng);
+        const int n4 = (E * K) >> 2;
+        for (int base = tid; base < n4; base += 4 * nth) {
+            float4 v[4], nv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i4 = base + u * nth; v[u] = F4[i4 < n4 ? i4 : n4 - 1]; }
+            if (ra.cf.on) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int i4 = base + u * nth; nv[u] = N4[i4 < n4 ? i4 : n4 - 1]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v[u].x = fmaf(c1f, nv[u].x, v[u].x); v[u].y = fmaf(c1f, nv[u].y, v[u].y);
+                    v[u].z = fmaf(c1f, nv[u].z, v[u].z); v[u].w = fmaf(c1f, nv[u].w, v[u].w);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i4 = base + u * nth;
+                if (i4 < n4) {
+                    int e, k;
+                    dK.divmod(4 * i4, e, k);
+                    const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        sF[e * ldk + k] = vv[q];
+                        if (++k == K) { k = 0; ++e; }
+                    }
+                }
+            }
+        }
+    } else {
+        for (int t = tid; t < E * K; t += nth) {
+            int e, k;
+            dK.divmod(t, e, k);
+            sF[e * ldk + k] = ra.cf.on ? fmaf(c1f, Ng[t], Fg[t]) : Fg[t];
+        }
+    }
+    for (int t = tid; t < E * (Kp4 - K); t += nth) { const int e = t / (Kp4 - K), k = K + t % (Kp4 - K); sF[e * ldk + k] = 0.f; }
+    const int hodge2 = (p.h_L > 1) && ra.want_p;
+    if (hodge2) {
+        float c1a = 0.f, c2a = 0.f;
+        if (ra.cf.on) corr_coef(ra.cf, 1, &c1a, &c2a);
+        for (int i = tid; i < NN; i += nth) {
+            float v = ra.adj[(size_t)b * NN + i];
+            if (ra.cf.on) {   // the A-network of the predictor sees the corrected adjacency
+                NoiseArgs nc = na;
+                nc.zadj = nullptr; nc.draw_adj = ra.cf.draw_adj;
+                const int ii = i / N, jj = i % N;
+                const float z = raw_noise_adj(nc, b, ii, jj, N) * ra.flags[(size_t)b * N + ii] * ra.flags[(size_t)b * N + jj];
+                v = fmaf(c2a, z, fmaf(c1a, ra.cf.net_adj[(size_t)b * NN + i], v));
+            }
+            sAdj[i] = v; sAdj[NN + i] = v;
+        }
+    }
+    __syncthreads();
+    const unsigned long long off = s_off;
+    for (int k = tid; k < Kp4; k += nth) sFrb[k] = (k < K && !(cells[k] & off)) ? 1 : 0;
+    for (int e = tid; e < 64; e += nth) sFl[e] = e < E ? edge_on(off, edges, e) : 0.f;
+    if (hodge2) {
+        // acoef[c][e] = (adj^(c+1))[i_e][j_e]   (pow_tensor + adj_to_hodgedual, graph_utils.py:285-292, cc_utils.py:1525-1536)
+        float* A = sAdj; float* P0_ = sAdj + NN; float* P1_ = sAdj + 2 * NN;
+        for (int c = 0; c < p.a_cinit; ++c) {
+            for (int e = tid; e < E; e += nth) sAco[c * E + e] = P0_[edges[2 * e] * N + edges[2 * e + 1]];
+            if (c + 1 < p.a_cinit) {
+                for (int i = tid; i < NN; i += nth) {
+                    const int r = i / N, cc = i % N;
+                    float acc = 0.f;
+                    for (int kk = 0; kk < N; ++kk) acc = fmaf(P0_[r * N + kk], A[kk * N + cc], acc);
+                    P1_[i] = acc;
+                }
+                __syncthreads();
+                float* t2 = P0_; P0_ = P1_; P1_ = t2;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (ra.cf.on) {
+        // fused Langevin corrector apply on the LDS-resident block, noise term: F <- (F + c1*net) + c2*z (masked)
+        const float c2 = c2f;
+        NoiseArgs nc = na;
+        nc.zr = nullptr; nc.draw_r = ra.cf.draw_r;
+        const int egn = (E + 3) >> 2;
+        for (int t = tid; t < egn * K; t += nth) {
+            int eg, k;
+            dK.divmod(t, eg, k);
+            float z[4];
+            raw_noise_r4(nc, b, eg, k, E, K, z);
+            const float fr = (float)sFrb[k];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = 4 * eg + r;
+                if (e < E) {
+                    // same expression as k_langevin_apply: fma(c2, z*fl*fr, fma(c1, net, v))
+                    const float zz = z[r] * sFl[e] * fr;
+                    sF[e * ldk + k] = fmaf(c2, zz, sF[e * ldk + k]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    stamp(ra.dbg, 1);
+    const HodgeLayerD& h0 = p.hl[0];
+    const HodgeLayerD& h1 = p.hl[1];
+    const bool doP0 = ra.want_p && p.h_L > 0, doP1 = hodge2;
+    const bool lin1 = doP1 && h0.mval.n == 1;      // rank2' affine in rank2: fold it around the GEMM
+    const int wc0 = doP0 ? h0.wc : 0, wc1 = doP1 ? h1.wc : 0;
+    if (lin1) {
+        // rank2'[e,k] = fl[e] fr[k] (sum_c w_c a_c[e] F[e,k] + b)  ->  P_1[e,:] = fl[e] (s[e] ((F.fr) W_1)[e,:] + b (fr W_1))
+        for (int e = tid; e < E; e += nth) {
+            float sc = 0.f;
+            for (int c = 0; c < h0.cin; ++c) sc = fmaf(w[h0.mval.w[0] + c], sAco[c * E + e], sc);
+            sRow[e] = sc;
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 1: H = F F^T (upper-triangle tiles, mirrored), P_0 = F Wcat_0, P_1 = rank2' Wcat_1.
+    // One 16x16 output tile over the full K per task; a wave runs two tasks interleaved (independent MFMA
+    // chains).  Operands of eight k-steps are fetched at once; the weight fragments, which come from L2,
+    // are double-buffered in registers one batch ahead.  No atomics: results are bitwise reproducible.
+    stamp(ra.dbg, 2);
+    const int ks = Kp4 >> 2;
+    int nHtasks = 0;
+    const int nH = p.f_cnum == 2 ? MT * (MT + 1) / 2 : 0;
+    const int nt0 = doP0 ? (wc0 + 15) >> 4 : 0, nt1 = doP1 ? (wc1 + 15) >> 4 : 0;
+    const int ntask = nH + MT * nt0 + MT * nt1;
+#ifdef CCSD_EMU
+    (void)ks; (void)ntask;
+    for (int m = 0; m < E; ++m) {
+        for (int n = 0; n < E; ++n) {
+            float acc = 0.f;
+            if (p.f_cnum == 2) for (int kk = 0; kk < K; ++kk) acc = fmaf(sF[m * ldk + kk], sF[n * ldk + kk], acc);
+            sH[m * ldh + n] = (p.f_hmask && m == n) ? 0.f : acc;
+        }
+        for (int n = 0; n < wc0; ++n) {
+            float acc = 0.f;
+            for (int kk = 0; kk < K; ++kk) acc = fmaf(sF[m * ldk + kk], w[h0.wcat + (size_t)kk * wc0 + n], acc);
+            ra.P0[((size_t)b * E + m) * wc0 + n] = acc;
+        }
+        for (int n = 0; n < wc1; ++n) {
+            float acc = 0.f, un = 0.f;
+            for (int kk = 0; kk < K; ++kk) {
+                const float frk = (float)sFrb[kk], wv = w[h1.wcat + (size_t)kk * wc1 + n];
+                float a;
+                if (lin1) a = sF[m * ldk + kk] * frk;
+                else {
+                    float in[CCSD_SMALLW], out[CCSD_SMALLW];
+                    for (int c = 0; c < CCSD_SMALLW; ++c) in[c] = c < h0.cin ? sAco[c * E + m] * sF[m * ldk + kk] : 0.f;
+                    small_mlp<CCSD_SMALLW>(h0.mval, w, in, out);
+                    a = sFl[m] * out[0] * frk;
+                }
+                acc = fmaf(a, wv, acc);
+                un = fmaf(frk, wv, un);
+            }
+            ra.P1[((size_t)b * E + m) * wc1 + n] = lin1 ? sFl[m] * fmaf(sRow[m], acc, w[h0.mval.b[0]] * un) : acc;
+        }
+    }
+#endif
+#ifndef CCSD_EMU
+    // Tile tasks: one 16x16 output tile over the full K per task.  Task list: the H tiles (upper triangle, row-major), the
+    // P_0 tiles (row tile major), the P_1 tiles.  The MFMA k slot kq of step j of a 16-wide k block is assigned to
+    // k = 16*blk + 4*kq + j, so a lane's A (and, for H, B) values of four steps are ONE aligned ds_read_b128 of F, and its
+    // weight values one float4 of the transposed copy Wcat^T[col][Kp].  Rows / columns beyond E / wc read clamped (valid)
+    // addresses and are never stored; k >= K meets the zero padding of F.  Even and odd k blocks accumulate into two
+    // independent MFMA chains (a dependent f32 16x16x4 MFMA waits 40 cycles, an independent one issues after 32).  Operands of
+    // four k blocks are kept in flight (the weights come from L2: ~500+ cycles); a slot is refilled only after the MFMAs that
+    // read it have been issued, so the load lands in the same registers.  No atomics: results are bitwise reproducible.
+    typedef float r2_f32x4 __attribute__((ext_vector_type(4)));
+    const int nblk = Kp4 >> 4;
+    const float* WT0 = ra.wp + h0.wcatT;
+    const float* WT1 = ra.wp + h1.wcatT;
+    const bool hmask = p.f_hmask != 0;
+    const float mval_b0 = lin1 ? w[h0.mval.b[0]] : 0.f;       // fetched before the k loops
+    auto run_tile = [&](int t) {
+        const int lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+        int type, i, c;                                       // 0: H(i, c >= i); 1: P_0(i, c); 2: P_1(i, c)
+        if (t < nH) {
+            type = 0; i = 0;
+            int rem = t;
+            while (rem >= MT - i) { rem -= MT - i; ++i; }
+            c = i + rem;
+        } else if (t < nH + MT * nt0) {
+            type = 1; i = (t - nH) / nt0; c = (t - nH) % nt0;
+        } else {
+            type = 2; i = (t - nH - MT * nt0) / nt1; c = (t - nH - MT * nt0) % nt1;
+        }
+        const int ra_ = 16 * i + l15;
+        const float* pa = sF + (ra_ < E ? ra_ : E - 1) * ldk + 4 * kq;
+        int offB = 0;                                         // H tiles: B rows of F in LDS
+        const float* wtp = WT0;                               // P tiles: column of Wcat^T in global memory
+        if (type == 0) {
+            const int rb_ = 16 * c + l15;
+            offB = (rb_ < E ? rb_ : E - 1) * ldk + 4 * kq;
+        } else {
+            const int wcn = type == 1 ? wc0 : wc1, n = 16 * c + l15;
+            wtp = (type == 1 ? WT0 : WT1) + (size_t)(n < wcn ? n : wcn - 1) * Kp4 + 4 * kq;
+        }
+        r2_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        float upart = 0.f;
+        // the k loop, specialised on where the B operand lives (LDS / global) and on the masked-A kind
+        auto kloop = [&](auto LB, auto K1) {
+            constexpr bool lb = decltype(LB)::v, k1 = decltype(K1)::v;
+            auto ldB = [&](int blk) -> float4 {
+                if (lb) return *reinterpret_cast<const float4*>(sF + offB + 16 * blk);
+                return *reinterpret_cast<const float4*>(wtp + 16 * blk);
+            };
+            constexpr int D = 4;
+            float4 ab[D], bb[D];
+            unsigned int fb[D];                                   // cell-mask bytes of the block (masked-A kind only)
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int bl = u < nblk ? u : nblk - 1;
+                ab[u] = *reinterpret_cast<const float4*>(pa + 16 * bl);
+                bb[u] = ldB(bl);
+                fb[u] = k1 ? *reinterpret_cast<const unsigned int*>(sFrb + 16 * bl + 4 * kq) : 0u;
+            }
+            auto block = [&](int u, int blk, bool refill) {
+                float4 a4 = ab[u];
+                const float4 b4 = bb[u];
+                if (k1) {
+                    const unsigned int f4 = fb[u];
+                    const float fr0 = (float)(f4 & 0xffu), fr1 = (float)((f4 >> 8) & 0xffu), fr2 = (float)((f4 >> 16) & 0xffu),
+                                fr3 = (float)(f4 >> 24);
+                    if (GEN1) {   // general mlp_value: rank2' element-wise on the fly (hodge_attention.py:322-323)
+                        const int r = 16 * i + l15, e = r < E ? r : E - 1;
+                        float fv[4] = {a4.x, a4.y, a4.z, a4.w};
+                        const float frv[4] = {fr0, fr1, fr2, fr3};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float iin[CCSD_SMALLW], out[CCSD_SMALLW];
+#pragma unroll
+                            for (int cc = 0; cc < CCSD_SMALLW; ++cc) iin[cc] = cc < h0.cin ? sAco[cc * E + e] * fv[j] : 0.f;
+                            small_mlp<CCSD_SMALLW>(h0.mval, w, iin, out);
+                            fv[j] = sFl[e] * out[0] * frv[j];
+                        }
+                        a4 = make_float4(fv[0], fv[1], fv[2], fv[3]);
+                    } else {
+                        a4.x *= fr0; a4.y *= fr1; a4.z *= fr2; a4.w *= fr3;
+                        upart = fmaf(fr0, b4.x, fmaf(fr1, b4.y, fmaf(fr2, b4.z, fmaf(fr3, b4.w, upart))));
+                    }
+                }
+                r2_f32x4& acc = (u & 1) ? acc1 : acc0;            // block parity == slot parity (D even, block counter a multiple of D)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
+                if (refill) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int bl = blk + D < nblk ? blk + D : nblk - 1;   // clamped: a harmless reload at the tail
+                    ab[u] = *reinterpret_cast<const float4*>(pa + 16 * bl);
+                    bb[u] = ldB(bl);
+                    if (k1) fb[u] = *reinterpret_cast<const unsigned int*>(sFrb + 16 * bl + 4 * kq);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            int blk0 = 0;
+            for (; blk0 + D <= nblk; blk0 += D) {      // branch-free body: the waits at the loop head stay counted
+#pragma unroll
+                for (int u = 0; u < D; ++u) block(u, blk0 + u, true);
+            }
+#pragma unroll
+            for (int u = 0; u < D - 1; ++u)
+                if (blk0 + u < nblk) block(u, blk0 + u, false);
+        };
+        if (type == 2) kloop(BoolTag<false>{}, BoolTag<true>{});
+        else if (type == 0) kloop(BoolTag<true>{}, BoolTag<false>{});
+        else kloop(BoolTag<false>{}, BoolTag<false>{});
+        const r2_f32x4 acc = acc0 + acc1;
+        const int n = 16 * c + l15;
+        const int mb = 16 * i + 4 * kq;
+        if (type == 0) {
+            if (n < E) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mb + r;
+                    if (m < E) {
+                        const float hv = (hmask && m == n) ? 0.f : acc[r];   // hodge_mask zeroes the diagonal (cc_utils.py:964-969)
+                        sH[m * ldh + n] = hv;
+                        sH[n * ldh + m] = hv;
+                    }
+                }
+            }
+            // this task wrote an H tile: publish (a wave's LDS operations complete in order)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) atomicAdd(&s_hdone, 1);
+        } else if (type == 1) {
+            if (n < wc0) {
+                float* dst = ra.P0 + ((size_t)b * E + mb) * wc0 + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (mb + r < E) dst[(size_t)r * wc0] = acc[r];
+            }
+        } else {
+            float un = upart;                      // fr . Wcat_1 column: reduce the four k residue classes
+            un += __shfl_xor(un, 16, 64);
+            un += __shfl_xor(un, 32, 64);
+            if (n < wc1) {
+                // rank2'[e,k] = fl[e] fr[k] (s[e] F[e,k] + b)  ->  P_1[e,:] = fl[e] (s[e] ((F.fr) W_1)[e,:] + b (fr W_1))
+                float* dst = ra.P1 + ((size_t)b * E + mb) * wc1 + n;
+                const float bu = mval_b0 * un;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mb + r, mc = m < E ? m : E - 1;
+                    const float v = GEN1 ? acc[r] : sFl[mc] * fmaf(sRow[mc], acc[r], bu);
+                    if (m < E) dst[(size_t)r * wc1] = v;
+                }
+            }
+        }
+    };
+    // Phase 1 = the H tiles plus as many projection tiles as it takes to give every wave the same number of tasks.  The other
+    // projection tiles (they depend on nothing but F) are run by the waves BETWEEN their column tiles of phase 2 (affine
+    // path): phase 2's epilogue is pure VALU work (Philox, Box-Muller, masks, update), the projection tiles pure MFMA work, and
+    // the partner waves of a SIMD then feed different pipes instead of queueing for the same one phase after phase.
+    nHtasks = nH;
+    const int nw1 = nth >> 6, wave1 = tid >> 6;
+    int n1 = ntask;
+    if (AFFINE) {
+        n1 = ((nH + nw1 - 1) / nw1) * nw1;
+        if (n1 > ntask) n1 = ntask;
+    }
+    for (int t = wave1; t < n1; t += nw1) {
+        run_tile(t);
+        if (t == 0) stamp(ra.dbg, 6);
+    }
+
+    stamp(ra.dbg, 7);
+    // No workgroup barrier here: phase 2 only READS the rank-2 block (its results go straight to HBM), so a wave may start
+    // it as soon as H is complete -- the waves with the lighter phase-1 tasks do not wait for the projection tasks.
+    // Every wave of the workgroup is resident and runs its phase-1 tasks unconditionally, so the count is always reached:
+    // the wait has no give-up path into phase 2 (an incomplete H would mean silently wrong scores).  The guard only turns a
+    // broken invariant (never observed; ~10 s of polling) into a loud kernel abort instead of an endless spin.
+    if (nHtasks > 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(&s_hdone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < nHtasks) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins == (1u << 27)) __builtin_trap();
+        }
+    }
+#endif
+
+    // ---- phase 2: (H F) per 16-column tile, ScoreNetworkF element-wise, epilogue straight to HBM.
+    // H's A-fragments live in registers for the whole phase.
+    stamp(ra.dbg, 3);
+    float s_net = 0.f, s_z = 0.f;
+    const int ntn = (K + 15) >> 4, ksE = Ep4 >> 2;
+    auto epi4 = [&](int e0, int k, const float* hf) {
+        if (e0 >= E || k >= K) return;
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ep.mode != MODE_SCORE) raw_noise_r4(na, b, e0 >> 2, k, E, K, z);   // one Philox group = 4 edge rows
+        const float fr = (float)sFrb[k];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = e0 + r;
+            if (e >= E) continue;
+            const float f = sF[e * ldk + k];
+            const float m = sFl[e] * fr;                         // flags_left * flags_right, cc_utils.py:590
+            const float net = fnet_element<AFFINE>(p, w, f, hf[r], m);
+            const size_t gi = ((size_t)b * E + e) * K + k;
+            if (ep.mode == MODE_SCORE) {
+                ep.out[gi] = ep.sscale * net;
+            } else {
+                const float zz = z[r] * m;                       // gen_noise_rank2, cc_utils.py:613-615
+                if (ep.mode == MODE_NORMS) {
+                    ep.out[gi] = net;
+                    s_net = fmaf(net, net, s_net);
+                    s_z = fmaf(zz, zz, s_z);
+                } else {
+                    const float mean = fmaf(ep.pa, f, ep.pb * net);
+                    if (ep.mean) ep.mean[gi] = mean;
+                    ep.out[gi] = fmaf(ep.pc, zz, mean);
+                }
+            }
+        }
+    };
+#ifdef CCSD_EMU
+    for (int tn = 0; tn < ntn; ++tn) {
+        float hfv[64][16];
+        for (int e = 0; e < E; ++e)
+            for (int j = 0; j < 16; ++j) {
+                const int k = 16 * tn + j;
+                float acc = 0.f;
+                if (p.f_cnum == 2 && k < K)
+                    for (int e2 = 0; e2 < E; ++e2) acc = fmaf(sH[e * ldh + e2], sF[e2 * ldk + k], acc);
+                hfv[e][j] = acc;
+            }
+        for (int e0 = 0; e0 < E; e0 += 4)
+            for (int j = 0; j < 16; ++j) {
+                const float v[4] = {hfv[e0][j], e0 + 1 < E ? hfv[e0 + 1][j] : 0.f, e0 + 2 < E ? hfv[e0 + 2][j] : 0.f, e0 + 3 < E ? hfv[e0 + 3][j] : 0.f};
+                epi4(e0, 16 * tn + j, v);
+            }
+    }
+#else
+    if constexpr (AFFINE) {
+        // Affine ScoreNetworkF (every shipped CC checkpoint but ENZYMES): net = fl[e] fr[k] (alpha f + beta (H F) + gamma).
+        // The tile loop is specialised per epilogue mode and noise source (no per-element mode branches) and organised so that
+        // the epilogue needs no address arithmetic of its own:
+        //  * contraction index in the PERMUTED slot order for the TF full 16-wide blocks (k slot kq of step j of block t <->
+        //    e' = 16 t + 4 kq + j): the lane's B operands of block t ARE F[16 t + 4 kq + r][n], r = 0..3, i.e. the F values of its
+        //    own accumulator rows of row tile t -- the epilogue reads f from registers; the remainder of E (E mod 16 <= 12)
+        //    follows in RS plain steps (e' = 16 TF + 4 s + kq): no MFMA step is spent on padding of the contraction index;
+        //  * H's A-fragments are re-read from LDS per column tile (16-byte aligned rows: one ds_read_b128 per (row tile, block))
+        //    instead of living in 36 registers for the whole phase;
+        //  * masks: fl of the lane's four rows is one ds_read_b128 of sFl, fr one byte per column tile;
+        //  * HBM: uniform base pointer + one per-lane 32-bit element offset, advanced by uniform row / tile strides.
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const int wave = tid >> 6, nw = nth >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+        constexpr int TF = RS ? MT - 1 : MT;               // full blocks of the contraction index
+        const bool padblk = RS == 0 && (E & 15) != 0;      // the last full block reaches beyond E: its A values are zeroed
+        const int ar0 = (l15 < E ? l15 : E - 1) * ldh + 4 * kq;   // A: row l15 of row tile 0, slot group kq
+        const int arL = ((16 * (MT - 1) + l15 < E) ? 16 * (MT - 1) + l15 : E - 1) * ldh + 4 * kq;   // ... of the last row tile (clamped)
+        const int brow = 4 * kq * ldk;                     // B: row 4 kq of block 0; block t, step j: + (16 t + j) ldk
+        const unsigned vo = (unsigned)(4 * kq * K + l15);  // element offset of (row 4 kq, column l15) inside the complex's block
+        const bool cn2 = p.f_cnum == 2;
+        auto coltile = [&](auto MODE_, auto INJ_, int tn) {
+            constexpr int MODE = decltype(MODE_)::value;   // 0 score, 1 norms, 2 predictor, 3 predictor + mean output
+            constexpr bool INJ = decltype(INJ_)::value;    // host-supplied raw draws instead of Philox
+            // net' = s * net with s = sscale (score), 1 (norms), pb (predictor): folded into the three affine constants
+            const float s_ = MODE == 0 ? ep.sscale : MODE == 1 ? 1.f : ep.pb;
+            const float sa = s_ * p.f_alpha, sb = s_ * p.f_beta, sg = s_ * p.f_gamma;
+            const float pa = ep.pa, pc = ep.pc;
+            float* const outp = ep.out + (size_t)b * E * K;
+            float* const meanp = MODE == 3 ? ep.mean + (size_t)b * E * K : nullptr;
+            const float* const zrp = INJ ? na.zr + (size_t)b * E * K : nullptr;
+            {
+                const int n = 16 * tn + l15;
+                const bool nin = n < K;
+                const int nc = nin ? n : K - 1;
+                // B operands: bv[4 t + j] = F[16 t + 4 kq + j][n] (permuted blocks), bvr[s] = F[16 TF + 4 s + kq][n] (remainder)
+                float bv[TF ? 4 * TF : 1], bvr[RS ? RS : 1];
+                const float* fb = sF + brow + nc;
+#pragma unroll
+                for (int t = 0; t < TF; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = 16 * t + 4 * kq + j;
+                        bv[4 * t + j] = (t < MT - 1 || !padblk) ? fb[(16 * t + j) * ldk] : sF[(c < E ? c : E - 1) * ldk + nc];
+                    }
+#pragma unroll
+                for (int s0 = 0; s0 < RS; ++s0) {
+                    const int c = 16 * TF + 4 * s0 + kq;
+                    bvr[s0] = sF[(c < E ? c : E - 1) * ldk + nc];
+                }
+                f32x4 acc[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (cn2) {
+                    int ao = ar0, aL = arL;
+                    asm volatile("" : "+v"(ao), "+v"(aL));  // opaque per tile: the loop-invariant A loads must not be hoisted into registers
+#pragma unroll
+                    for (int t = 0; t < TF; ++t) {
+                        float4 a4[MT];
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+                            a4[i] = *reinterpret_cast<const float4*>(sH + (i < MT - 1 ? ao + 16 * i * ldh : aL) + 16 * t);
+                        if (t == MT - 1 && padblk) {       // columns 16 t + 4 kq + j >= E: whatever was read, the operand is zero
+                            const int c0 = 16 * t + 4 * kq;
+#pragma unroll
+                            for (int i = 0; i < MT; ++i) {
+                                a4[i].x = c0 < E ? a4[i].x : 0.f; a4[i].y = c0 + 1 < E ? a4[i].y : 0.f;
+                                a4[i].z = c0 + 2 < E ? a4[i].z : 0.f; a4[i].w = c0 + 3 < E ? a4[i].w : 0.f;
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) {
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].x, bv[4 * t + 0], acc[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].y, bv[4 * t + 1], acc[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].z, bv[4 * t + 2], acc[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].w, bv[4 * t + 3], acc[i], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int s0 = 0; s0 < RS; ++s0) {
+                        const int c = 16 * TF + 4 * s0 + kq;   // contraction index of this lane's slot
+                        const int cc = (c < E ? c : E - 1) - 4 * kq;
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) {
+                            const float av = sH[(i < MT - 1 ? ao + 16 * i * ldh : aL) + cc];
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(c < E ? av : 0.f, bvr[s0], acc[i], 0, 0, 0);
+                        }
+                    }
+                }
+                if (nin) {                                 // false only for the padding columns of the last column tile
+                    const float fr = (float)sFrb[n];
+                    unsigned gi = vo + 16u * (unsigned)tn;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const bool last = i == MT - 1;     // only the last row tile can reach beyond E
+                        const int e0 = 16 * i + 4 * kq;
+                        if (!last || e0 < E) {
+                            float z[4] = {0.f, 0.f, 0.f, 0.f};
+                            if (MODE != 0) {
+                                if (INJ) {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) z[r] = (!last || e0 + r < E) ? zrp[gi + (unsigned)(r * K)] : 0.f;
+                                } else {
+                                    philox_normal4(na.seed, na.draw_r, na.b_off + b, (unsigned)((4 * i + kq) * K + n), z);   // one Philox group = 4 edge rows
+                                }
+                            }
+                            const float4 fl4 = *reinterpret_cast<const float4*>(sFl + e0);   // sFl: 64 entries, zero beyond E
+                            const float flv[4] = {fl4.x, fl4.y, fl4.z, fl4.w};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int e = e0 + r;
+                                const float f = i < TF ? bv[4 * (i < TF ? i : 0) + r] : sF[(e < E ? e : E - 1) * ldk + n];
+                                const float m = flv[r] * fr;                     // flags_left * flags_right, cc_utils.py:590
+                                const float net = m * fmaf(sb, acc[i][r], fmaf(sa, f, sg));
+                                const unsigned g = gi + (unsigned)(r * K);
+                                if (!last || e < E) {
+                                    if (MODE == 0) {
+                                        outp[g] = net;
+                                    } else {
+                                        const float zz = z[r] * m;               // gen_noise_rank2, cc_utils.py:613-615
+                                        if (MODE == 1) {
+                                            outp[g] = net;
+                                            s_net = fmaf(net, net, s_net);
+                                            s_z = fmaf(zz, zz, s_z);
+                                        } else {
+                                            const float mean = fmaf(pa, f, net); // v_mean = pa v + pb net (pb folded into net)
+                                            if (MODE == 3) meanp[g] = mean;
+                                            outp[g] = fmaf(pc, zz, mean);
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        gi += 16u * (unsigned)K;
+                    }
+                }
+            }
+        };
+        typedef std::integral_constant<bool, false> NoInj;
+        typedef std::integral_constant<bool, true> Inj;
+        const bool inj = na.zr != nullptr && ep.mode != MODE_SCORE;
+        const int cmode = ep.mode == MODE_SCORE ? 0 : ep.mode == MODE_NORMS ? 1 : ep.mean == nullptr ? 2 : 3;
+        // Static schedule of a wave: its column tiles tn = wave, wave + nw, ... with its projection tiles (task n1 + wave, + nw,
+        // ...) in between -- before the first column tile for the waves of the lower half, after the second one for the upper
+        // half, so that the two waves a SIMD holds are in MFMA-bound and VALU-bound code at different times.  (Static, hence
+        // the per-thread accumulation order of the Langevin norms is fixed and runs are bitwise reproducible.)
+        int pt = n1 + wave;
+        const int pslot = wave < (nw >> 1) ? 0 : 2;
+        int cnt = 0;
+        for (int tn = wave; tn < ntn; tn += nw, ++cnt) {
+            if (cnt == pslot && pt < ntask) { run_tile(pt); pt += nw; }
+            switch (cmode * 2 + (inj ? 1 : 0)) {
+                case 0: case 1: coltile(std::integral_constant<int, 0>{}, NoInj{}, tn); break;
+                case 2: coltile(std::integral_constant<int, 1>{}, NoInj{}, tn); break;
+                case 3: coltile(std::integral_constant<int, 1>{}, Inj{}, tn); break;
+                case 4: coltile(std::integral_constant<int, 2>{}, NoInj{}, tn); break;
+                case 5: coltile(std::integral_constant<int, 2>{}, Inj{}, tn); break;
+                case 6: coltile(std::integral_constant<int, 3>{}, NoInj{}, tn); break;
+                default: coltile(std::integral_constant<int, 3>{}, Inj{}, tn); break;
+            }
+        }
+        for (; pt < ntask; pt += nw) run_tile(pt);
+    } else {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const int wave = tid >> 6, nw = nth >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+        constexpr int KSE = 4 * MT;                        // ceil(16*MT / 4) k-steps cover E <= 16*MT
+        float hA[MT][KSE];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int s0 = 0; s0 < KSE; ++s0) {
+                const int r = 16 * i + l15, c = 4 * s0 + kq;
+                const float v = sH[(r < E ? r : E - 1) * ldh + (c < E ? c : E - 1)];
+                hA[i][s0] = (r < E && c < E) ? v : 0.f;
+            }
+        // (static tile -> wave assignment: the per-thread accumulation order of the Langevin norms stays fixed, runs are
+        // bitwise reproducible)
+        for (int tn = wave; tn < ntn; tn += nw) {
+            const int n = 16 * tn + l15;
+            const bool nin = n < K;
+            f32x4 acc[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p.f_cnum == 2) {
+                float bv[KSE];
+#pragma unroll
+                for (int s0 = 0; s0 < KSE; ++s0) {
+                    const int kk = 4 * s0 + kq;
+                    const float v = sF[(kk < E ? kk : E - 1) * ldk + (nin ? n : K - 1)];
+                    bv[s0] = (kk < E && nin) ? v : 0.f;
+                }
+#pragma unroll
+                for (int s0 = 0; s0 < KSE; ++s0)
+                    if (s0 < ksE) {
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(hA[i][s0], bv[s0], acc[i], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const float v[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+                epi4(16 * i + 4 * kq, n, v);
+            }
+        }
+    }
+#endif
+    // (no phase 3: the epilogue wrote the results to HBM)
+    stamp(ra.dbg, 4);
+    if (ep.mode == MODE_NORMS) {
+        const float tn_ = block_sum(s_net, sRed);
+        const float tz_ = block_sum(s_z, sRed);
+        if (tid == 0) { ep.part[(size_t)b * 2 + 0] = tn_; ep.part[(size_t)b * 2 + 1] = tz_; }
+    }
+    stamp(ra.dbg, 5);
+}

@@ -1,0 +1,429 @@
+// ccsd_k_rank2.h -- k_flagbits and the tiled rank-2 kernels: k_gemm_h (H = F F^T), k_gemm_p / k_gemm_p0 (hodge projections), k_edgecoef, k_hf_score
+// Part of the kernel source of libccsd_hip.so (see ccsd_kernels.h for the map).
+#pragma once
+#include "ccsd_rank2_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// k_flagbits: offbits[b] has bit n set iff flags[b][n] == 0  (get_rank2_flags tests `flags == 0`,
+// cc_utils.py:549)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_flagbits(const float* __restrict__ flags, unsigned long long* __restrict__ offbits, int B, int N) {
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+        unsigned long long m = 0;
+        for (int n = 0; n < N; ++n)
+            if (flags[(size_t)b * N + n] == 0.f) m |= 1ull << n;
+        offbits[b] = m;
+    }
+}
+// ---------------------------------------------------------------------------------------------
+// k_gemm_h: H[b] = (F[b] F[b]^T) * hodge_mask           hodge_laplacian + mask, cc_utils.py:929, 964-969
+// grid (ceil(E/64), ceil(E/64), B)
+// ---------------------------------------------------------------------------------------------
+#define H_BK 32   // k per slab (two 16-wide MFMA k blocks)
+#define H_LD 40   // LDS row stride in floats: 16-byte aligned rows, == 8 mod 32 -> conflict-free ds_read_b128 fragments
+__global__ __launch_bounds__(256) void k_gemm_h(const float* __restrict__ rank2, float* __restrict__ H, int E, int K,
+                                                int zero_diag) {
+    const int b = blockIdx.z, m0 = blockIdx.y * T_BM, n0 = blockIdx.x * T_BN;
+    if (blockIdx.x < blockIdx.y) return;        // H is symmetric: upper-triangle tiles only, mirrored on store
+    const float* Fb = rank2 + (size_t)b * E * K;
+    TileAcc acc;
+    tile_zero(acc);
+#ifdef CCSD_EMU
+    static float As[T_BK * T_LD], Bs[T_BK * T_LD];
+    for (int k0 = 0; k0 < K; k0 += T_BK) {
+        for (int idx = threadIdx.x; idx < T_BM * T_BK; idx += blockDim.x) {
+            const int r = idx / T_BK, kk = idx % T_BK, k = k0 + kk;
+            const int ra = m0 + r, rb = n0 + r;
+            As[kk * T_LD + r] = (ra < E && k < K) ? Fb[(size_t)ra * K + k] : 0.f;
+            Bs[kk * T_LD + r] = (rb < E && k < K) ? Fb[(size_t)rb * K + k] : 0.f;
+        }
+        tile_mma(acc, As, Bs);
+    }
+#else
+    // Both operands are rows of F, contiguous along the contraction index: the slabs are straight row copies
+    // (As[row][k], 16-byte vectors, no transposition), and with the MFMA k slot kq of step j of a 16-wide block assigned
+    // to k = 16*t + 4*kq + j a lane's four-step fragment is one ds_read_b128.  The next slab's global loads are issued
+    // before the MFMAs of the current one.
+    __shared__ __align__(16) float As[T_BM * H_LD];
+    __shared__ __align__(16) float Bs[T_BN * H_LD];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const bool diag = blockIdx.x == blockIdx.y, vec = (K & 3) == 0;
+    // thread -> (row, 4-float column group) of the 64 x 32 slab: two groups per thread and matrix
+    const int r0 = tid >> 3, c4 = (tid & 7) * 4;
+    auto ldg = [&](int row, int k) -> float4 {
+        const int rc = row < E ? row : E - 1;
+        const float* src = Fb + (size_t)rc * K;
+        float4 v;
+        if (vec && k + 3 < K) v = *reinterpret_cast<const float4*>(src + k);
+        else {
+            v.x = k < K ? src[k] : 0.f; v.y = k + 1 < K ? src[k + 1] : 0.f;
+            v.z = k + 2 < K ? src[k + 2] : 0.f; v.w = k + 3 < K ? src[k + 3] : 0.f;
+        }
+        if (row >= E) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        return v;
+    };
+    float4 ra[2], rb[2];
+    ra[0] = ldg(m0 + r0, c4); ra[1] = ldg(m0 + r0 + 32, c4);
+    if (!diag) { rb[0] = ldg(n0 + r0, c4); rb[1] = ldg(n0 + r0 + 32, c4); }
+    const float* Bp = diag ? As : Bs;
+    for (int k0 = 0; k0 < K; k0 += H_BK) {
+        __syncthreads();                                   // the previous slab's MFMAs are done reading LDS
+        *reinterpret_cast<float4*>(As + r0 * H_LD + c4) = ra[0];
+        *reinterpret_cast<float4*>(As + (r0 + 32) * H_LD + c4) = ra[1];
+        if (!diag) {
+            *reinterpret_cast<float4*>(Bs + r0 * H_LD + c4) = rb[0];
+            *reinterpret_cast<float4*>(Bs + (r0 + 32) * H_LD + c4) = rb[1];
+        }
+        __syncthreads();
+        if (k0 + H_BK < K) {                               // next slab: in flight during the MFMAs
+            ra[0] = ldg(m0 + r0, k0 + H_BK + c4); ra[1] = ldg(m0 + r0 + 32, k0 + H_BK + c4);
+            if (!diag) { rb[0] = ldg(n0 + r0, k0 + H_BK + c4); rb[1] = ldg(n0 + r0 + 32, k0 + H_BK + c4); }
+        }
+#pragma unroll
+        for (int t = 0; t < H_BK / 16; ++t) {
+            const float4 a0 = *reinterpret_cast<const float4*>(As + (wm + l15) * H_LD + 16 * t + 4 * kq);
+            const float4 a1 = *reinterpret_cast<const float4*>(As + (wm + 16 + l15) * H_LD + 16 * t + 4 * kq);
+            const float4 b0 = *reinterpret_cast<const float4*>(Bp + (wn + l15) * H_LD + 16 * t + 4 * kq);
+            const float4 b1 = *reinterpret_cast<const float4*>(Bp + (wn + 16 + l15) * H_LD + 16 * t + 4 * kq);
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc.a[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[j], bv0[j], acc.a[0][0], 0, 0, 0);
+                acc.a[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[j], bv1[j], acc.a[0][1], 0, 0, 0);
+                acc.a[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[j], bv0[j], acc.a[1][0], 0, 0, 0);
+                acc.a[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[j], bv1[j], acc.a[1][1], 0, 0, 0);
+            }
+        }
+    }
+#endif
+    float* Hb = H + (size_t)b * E * E;
+    tile_foreach4(acc, [&](int ml, int nl, const float* v) {
+        const int n = n0 + nl;
+        if (n >= E) return;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int m = m0 + ml + s;
+            if (m < E) {
+                const float hv = (zero_diag && m == n) ? 0.f : v[s];
+                Hb[(size_t)m * E + n] = hv;
+                if (blockIdx.x != blockIdx.y) Hb[(size_t)n * E + m] = hv;
+            }
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gemm_p: P[r][c] = sum_k A(r,k) * Wcat[k][c]   over the flattened rows r = b*E + e.
+// layer 0: A = rank2 as given                               (DenseHCNConv out = rank2 @ W, hodge_layers.py:185)
+// layer 1: A = rank2' = mask_rank2(mlp_value(stack_c a_c[e]*rank2[e,k]))   (hodge_attention.py:107,322-323
+//          with the layer-0 hodge adjacency diagonal, cc_utils.py:1536) -- produced on the fly, never stored.
+// grid (ceil(wc/64), ceil(B*E/64), 1)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gemm_p(const float* __restrict__ rank2, const float* __restrict__ W,
+                                                float* __restrict__ P, int rows, int E, int K, int wc, int wcat_off,
+                                                int layer, MlpD mval, int cin, const float* __restrict__ acoef,
+                                                const unsigned long long* __restrict__ offbits,
+                                                const unsigned char* __restrict__ edges,
+                                                const unsigned long long* __restrict__ cells) {
+    __shared__ float As[T_BK * T_LD];
+    __shared__ float Bs[T_BK * T_LD];
+    __shared__ float s_mv[CCSD_MAXLIN * CCSD_HWBLK];   // mlp_value as zero-padded 8x8 blocks (LDS broadcast reads)
+    const int m0 = blockIdx.y * T_BM, n0 = blockIdx.x * T_BN;
+    const float* Wc = W + wcat_off;
+    TileAcc acc;
+    tile_zero(acc);
+    if (layer == 1) { stage_mlp_blocks(mval, W, s_mv); __syncthreads(); }
+    for (int k0 = 0; k0 < K; k0 += T_BK) {
+        for (int idx = threadIdx.x; idx < T_BM * T_BK; idx += blockDim.x) {
+            const int r = idx / T_BK, kk = idx % T_BK, k = k0 + kk, row = m0 + r;
+            float v = 0.f;
+            if (row < rows && k < K) {
+                v = rank2[(size_t)row * K + k];
+                if (layer == 1) {
+                    const int b = row / E, e = row % E;
+                    const unsigned long long off = offbits[b];
+                    float in[CCSD_SMALLW], out[CCSD_SMALLW];
+#pragma unroll
+                    for (int c = 0; c < CCSD_SMALLW; ++c) in[c] = c < cin ? acoef[((size_t)b * cin + c) * E + e] * v : 0.f;
+                    small_mlp_lds<CCSD_SMALLW>(s_mv, mval.n, in, out);
+                    v = edge_on(off, edges, e) * out[0] * cell_on(off, cells, k);
+                }
+            }
+            As[kk * T_LD + r] = v;
+        }
+        for (int idx = threadIdx.x; idx < T_BK * T_BN; idx += blockDim.x) {
+            const int kk = idx / T_BN, c = idx % T_BN, k = k0 + kk, col = n0 + c;
+            Bs[kk * T_LD + c] = (k < K && col < wc) ? Wc[(size_t)k * wc + col] : 0.f;
+        }
+        __syncthreads();
+        tile_mma(acc, As, Bs);
+        __syncthreads();
+    }
+    tile_foreach4(acc, [&](int ml, int nl, const float* v) {
+        const int n = n0 + nl;
+        if (n >= wc) return;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int m = m0 + ml + s;
+            if (m < rows) P[(size_t)m * wc + n] = v[s];
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gemm_p0: layer-0 hodge projections  P_0[r][c] = sum_k rank2[r][k] * Wcat_0[k][c]  (DenseHCNConv out = rank2 @ W,
+// hodge_layers.py:185) over the flattened rows r = b*E + e, for narrow outputs (wc <= 64: 16 columns for every shipped
+// network).  One workgroup = 64 rows x all pad16(wc) columns: both operands are row copies (rank2 rows, rows of the
+// transposed packed weights Wcat^T[col][Kp]) read back as ds_read_b128 permuted-k fragments; wave w owns rows
+// 16w..16w+15 and every 16-column tile, so no MFMA is spent on the 64-column padding of the general tile engine.
+// ---------------------------------------------------------------------------------------------
+#ifndef CCSD_EMU
+template <int NT>
+__global__ __launch_bounds__(256) void k_gemm_p0(const float* __restrict__ rank2, const float* __restrict__ WT, float* __restrict__ P,
+                                                 int rows, int K, int Kp, int wc) {
+    __shared__ __align__(16) float As[T_BM * H_LD];
+    __shared__ __align__(16) float Bs[16 * NT * H_LD];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * T_BM;
+    const bool vec = (K & 3) == 0;
+    const int r0 = tid >> 3, c4 = (tid & 7) * 4;           // (row, 4-float column group) of a 64 x 32 slab; rows r0, r0 + 32
+    auto lda = [&](int row, int k) -> float4 {
+        const float* src = rank2 + (size_t)(row < rows ? row : rows - 1) * K;
+        float4 v;
+        if (vec && k + 3 < K) v = *reinterpret_cast<const float4*>(src + k);
+        else {
+            v.x = k < K ? src[k] : 0.f; v.y = k + 1 < K ? src[k + 1] : 0.f;
+            v.z = k + 2 < K ? src[k + 2] : 0.f; v.w = k + 3 < K ? src[k + 3] : 0.f;
+        }
+        return v;
+    };
+    f32x4 acc[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 ra[2], rb[(NT + 1) / 2];
+    auto load_slab = [&](int k0) {
+        ra[0] = lda(m0 + r0, k0 + c4); ra[1] = lda(m0 + r0 + 32, k0 + c4);
+#pragma unroll
+        for (int u = 0; u < (NT + 1) / 2; ++u) {           // 16*NT weight rows x 8 float4: tid + 256u < 128*NT
+            const int idx = tid + 256 * u, wr = idx >> 3;
+            rb[u] = wr < 16 * NT ? *reinterpret_cast<const float4*>(WT + (size_t)wr * Kp + k0 + (idx & 7) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    load_slab(0);
+    for (int k0 = 0; k0 < Kp; k0 += H_BK) {
+        __syncthreads();
+        *reinterpret_cast<float4*>(As + r0 * H_LD + c4) = ra[0];
+        *reinterpret_cast<float4*>(As + (r0 + 32) * H_LD + c4) = ra[1];
+#pragma unroll
+        for (int u = 0; u < (NT + 1) / 2; ++u) {
+            const int idx = tid + 256 * u, wr = idx >> 3;
+            if (wr < 16 * NT) *reinterpret_cast<float4*>(Bs + wr * H_LD + (idx & 7) * 4) = rb[u];
+        }
+        __syncthreads();
+        if (k0 + H_BK < Kp) load_slab(k0 + H_BK);
+#pragma unroll
+        for (int t = 0; t < H_BK / 16; ++t) {
+            const float4 a = *reinterpret_cast<const float4*>(As + (16 * wave + l15) * H_LD + 16 * t + 4 * kq);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                const float4 bq = *reinterpret_cast<const float4*>(Bs + (16 * c + l15) * H_LD + 16 * t + 4 * kq);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc[c], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const int n = 16 * c + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * wave + 4 * kq + r;
+            if (m < rows && n < wc) P[(size_t)m * wc + n] = acc[c][r];
+        }
+    }
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// k_edgecoef: acoef[b][c][e] = (adj^(c+1))[i_e][j_e]      pow_tensor + adj_to_hodgedual,
+// graph_utils.py:285-292, cc_utils.py:1525-1536.  One workgroup per graph; LDS: 3*N*N floats.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_edgecoef(const float* __restrict__ adj, float* __restrict__ acoef, int N, int E, int cinit,
+                           const unsigned char* __restrict__ edges) {
+    CCSD_DYN_SMEM(sm);
+    float* A = sm;
+    float* P0 = sm + N * N;
+    float* P1 = sm + 2 * N * N;
+    const int b = blockIdx.x, NN = N * N;
+    for (int i = threadIdx.x; i < NN; i += blockDim.x) { A[i] = adj[(size_t)b * NN + i]; P0[i] = A[i]; }
+    __syncthreads();
+    for (int c = 0; c < cinit; ++c) {
+        for (int e = threadIdx.x; e < E; e += blockDim.x)
+            acoef[((size_t)b * cinit + c) * E + e] = P0[edges[2 * e] * N + edges[2 * e + 1]];
+        if (c + 1 < cinit) {
+            for (int i = threadIdx.x; i < NN; i += blockDim.x) {
+                const int r = i / N, cc = i % N;
+                float acc = 0.f;
+                for (int k = 0; k < N; ++k) acc = fmaf(P0[r * N + k], A[k * N + cc], acc);
+                P1[i] = acc;
+            }
+            __syncthreads();
+            float* t = P0; P0 = P1; P1 = t;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_hf_score: ScoreNetworkF.  Tile (edge rows m0.., cell columns n0..) of  H.F  on MFMA, then per
+// element the channel MLP stack of ScoreNetwork_F.py:198-217 and one of three fused epilogues.
+// grid (ceil(K/64), ceil(E/64), B)
+// ---------------------------------------------------------------------------------------------
+template <bool AFFINE, int FW>
+__global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan, const float* __restrict__ w,
+                                                  const float* __restrict__ rank2, const float* __restrict__ H,
+                                                  const unsigned long long* __restrict__ offbits,
+                                                  const unsigned char* __restrict__ edges,
+                                                  const unsigned long long* __restrict__ cells, RankEpi ep,
+                                                  NoiseArgs na) {
+    __shared__ float red[64];
+    const PlanD& p = *plan;
+    const int E = p.E, K = p.K;
+    const int b = blockIdx.z, m0 = blockIdx.y * T_BM, n0 = blockIdx.x * T_BN;
+    const float* Fb = rank2 + (size_t)b * E * K;
+    const float* Hb = H + (size_t)b * E * E;
+    TileAcc acc;
+    tile_zero(acc);
+#ifdef CCSD_EMU
+    static float As[T_BK * T_LD], Bs[T_BK * T_LD];
+    if (p.f_cnum == 2) {
+        for (int k0 = 0; k0 < E; k0 += T_BK) {
+            for (int idx = threadIdx.x; idx < T_BM * T_BK; idx += blockDim.x) {
+                const int r = idx / T_BK, kk = idx % T_BK, k = k0 + kk, row = m0 + r;
+                As[kk * T_LD + r] = (row < E && k < E) ? Hb[(size_t)row * E + k] : 0.f;
+            }
+            for (int idx = threadIdx.x; idx < T_BK * T_BN; idx += blockDim.x) {
+                const int kk = idx / T_BN, c = idx % T_BN, k = k0 + kk, col = n0 + c;
+                Bs[kk * T_LD + c] = (k < E && col < K) ? Fb[(size_t)k * K + col] : 0.f;
+            }
+            tile_mma(acc, As, Bs);
+        }
+    }
+#else
+    // (H F) tile: A = rows of H (contraction index contiguous: row-copy slab As[row][k], one ds_read_b128 per 16-wide k
+    // block with the permuted k slots k = 16t + 4kq + j); B = rows of F, k-major slab Bs[k][col] read with the same
+    // permutation (row stride 68: 4 * 68 == 16 mod 32 keeps the four kq groups on disjoint banks).  Next slab's global
+    // loads are issued before the MFMAs of the current one.
+    constexpr int BLD = 68;
+    __shared__ __align__(16) float As[T_BM * H_LD];
+    __shared__ __align__(16) float Bs[H_BK * BLD];
+    if (p.f_cnum == 2) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+        const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+        const bool vec = (K & 3) == 0;
+        // A slab 64 x 32: thread -> (row ar + 8u, column ak), u < 8 (scalar: E is not 16-byte friendly in general)
+        const int ar = tid >> 5, ak = tid & 31;
+        // B slab 32 x 64: thread -> (k row bk + 16u, 4-float column group bc4), u < 2
+        const int bk = tid >> 4, bc4 = (tid & 15) * 4;
+        float ra[8];
+        float4 rb[2];
+        auto load_slab = [&](int k0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = m0 + ar + 8 * u, k = k0 + ak;
+                const float v = Hb[(size_t)(row < E ? row : E - 1) * E + (k < E ? k : E - 1)];
+                ra[u] = (row < E && k < E) ? v : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = k0 + bk + 16 * u, col = n0 + bc4;
+                const float* src = Fb + (size_t)(k < E ? k : E - 1) * K;
+                float4 v;
+                if (vec && col + 3 < K) v = *reinterpret_cast<const float4*>(src + col);
+                else {
+                    v.x = col < K ? src[col] : 0.f; v.y = col + 1 < K ? src[col + 1] : 0.f;
+                    v.z = col + 2 < K ? src[col + 2] : 0.f; v.w = col + 3 < K ? src[col + 3] : 0.f;
+                }
+                if (k >= E) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[u] = v;
+            }
+        };
+        load_slab(0);
+        for (int k0 = 0; k0 < E; k0 += H_BK) {
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) As[(ar + 8 * u) * H_LD + ak] = ra[u];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) *reinterpret_cast<float4*>(Bs + (bk + 16 * u) * BLD + bc4) = rb[u];
+            __syncthreads();
+            if (k0 + H_BK < E) load_slab(k0 + H_BK);
+#pragma unroll
+            for (int t = 0; t < H_BK / 16; ++t) {
+                const float4 a0 = *reinterpret_cast<const float4*>(As + (wm + l15) * H_LD + 16 * t + 4 * kq);
+                const float4 a1 = *reinterpret_cast<const float4*>(As + (wm + 16 + l15) * H_LD + 16 * t + 4 * kq);
+                const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+                float bv0[4], bv1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float* br = Bs + (16 * t + 4 * kq + j) * BLD + wn + l15;
+                    bv0[j] = br[0]; bv1[j] = br[16];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc.a[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[j], bv0[j], acc.a[0][0], 0, 0, 0);
+                    acc.a[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[j], bv1[j], acc.a[0][1], 0, 0, 0);
+                    acc.a[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[j], bv0[j], acc.a[1][0], 0, 0, 0);
+                    acc.a[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[j], bv1[j], acc.a[1][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+#endif
+    const unsigned long long off = offbits[b];
+    float s_net = 0.f, s_z = 0.f;
+    tile_foreach4(acc, [&](int ml, int nl, const float* hf) {
+        const int k = n0 + nl, e0 = m0 + ml;
+        if (k >= K || e0 >= E) return;
+        const float fr = cell_on(off, cells, k);
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ep.mode != MODE_SCORE) raw_noise_r4(na, b, e0 >> 2, k, E, K, z);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int e = e0 + s;
+            if (e >= E) continue;
+            const size_t gi = ((size_t)b * E + e) * K + k;
+            const float f = Fb[(size_t)e * K + k];
+            const float m = edge_on(off, edges, e) * fr;          // flags_left * flags_right, cc_utils.py:590
+            const float net = fnet_element<AFFINE, FW>(p, w, f, hf[s], m);
+            const float zz = z[s] * m;                            // gen_noise_rank2, cc_utils.py:613-615
+            if (ep.mode == MODE_SCORE) {
+                ep.out[gi] = ep.sscale * net;
+            } else if (ep.mode == MODE_NORMS) {
+                ep.out[gi] = net;
+                s_net = fmaf(net, net, s_net);
+                s_z = fmaf(zz, zz, s_z);
+            } else {
+                const float mean = fmaf(ep.pa, f, ep.pb * net);   // v_mean = pa*v + pb*net
+                if (ep.mean) ep.mean[gi] = mean;
+                ep.out[gi] = fmaf(ep.pc, zz, mean);
+            }
+        }
+    });
+    if (ep.mode == MODE_NORMS) {
+        const float tn = block_sum(s_net, red);
+        const float tz = block_sum(s_z, red);
+        if (threadIdx.x == 0) {
+            const int tile = blockIdx.y * gridDim.x + blockIdx.x, nt = gridDim.x * gridDim.y;
+            ep.part[((size_t)b * nt + tile) * 2 + 0] = tn;
+            ep.part[((size_t)b * nt + tile) * 2 + 1] = tz;
+        }
+    }
+}
+

@@ -1,0 +1,253 @@
+// ccsd_k_update.h -- k_normsum, k_langevin_apply, k_s4_apply, k_init_state, k_quantize, k_rank2_cells
+// Part of the kernel source of libccsd_hip.so (see ccsd_kernels.h for the map).
+#pragma once
+#include "ccsd_rank2_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// k_normsum: sums[0..5] = sum_b sqrt(|net_x|^2), |net_adj|, |net_rank2|, |z_x|, |z_adj|, |z_rank2|
+// (torch.norm(...).mean() numerators, solver.py:763-767).  One workgroup, deterministic order.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_normsum(const float* __restrict__ norm2, const float* __restrict__ part, int B, int ntiles,
+                          int is_cc, float* __restrict__ sums) {
+    __shared__ float red[64];
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        acc[0] += sqrtf(norm2[b * 4 + 0]);
+        acc[1] += sqrtf(norm2[b * 4 + 1]);
+        acc[3] += sqrtf(norm2[b * 4 + 2]);
+        acc[4] += sqrtf(norm2[b * 4 + 3]);
+        if (is_cc) {
+            float sn = 0.f, sz = 0.f;
+            for (int t = 0; t < ntiles; ++t) {
+                sn += part[((size_t)b * ntiles + t) * 2 + 0];
+                sz += part[((size_t)b * ntiles + t) * 2 + 1];
+            }
+            acc[2] += sqrtf(sn);
+            acc[5] += sqrtf(sz);
+        }
+    }
+    for (int i = 0; i < 6; ++i) {
+        const float t = block_sum(acc[i], red);
+        if (threadIdx.x == 0) sums[i] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_langevin_apply: step = (snr * zn / gn)^2 * 2 * alpha; v_mean = v + step*score;
+// v = v_mean + sqrt(2 step) * z * scale_eps          (solver.py:767-769, 781-783, 797-801)
+// score = sscale * net, so gn = |sscale| * sum|net| and step*score = step*sscale*net.
+// grid-stride over the three tensors of the whole batch.
+// ---------------------------------------------------------------------------------------------
+struct LangArgs {
+    const float* x; const float* adj; const float* r;          // state in
+    const float* nx; const float* nadj; const float* nr;        // raw network outputs kept by the NORMS pass
+    float* ox; float* oadj; float* orr;                          // state out
+    const float* flags;
+    const float* sums;
+    float ss[3], alpha[3];
+    float snr, seps;
+    int B, N, F, E, K, is_cc;
+};
+CCSD_DEV void langevin_coef(const LangArgs& a, int t, float* c1, float* c2) {
+    const float gn = fabsf(a.ss[t]) * a.sums[t], zn = a.sums[3 + t];
+    const float q = a.snr * zn / gn;
+    const float step = q * q * 2.f * a.alpha[t];
+    *c1 = step * a.ss[t];
+    *c2 = sqrtf(step * 2.f) * a.seps;
+}
+__global__ void k_langevin_apply(LangArgs a, NoiseArgs na, const unsigned long long* __restrict__ offbits,
+                                 const unsigned char* __restrict__ edges, const unsigned long long* __restrict__ cells) {
+    const long long nxe = (long long)a.B * a.N * a.F, nae = (long long)a.B * a.N * a.N;
+    const long long nre = a.is_cc ? (long long)a.B * ((a.E + 3) / 4) * a.K : 0;  // one thread per 4-edge group x column
+    const long long total = nxe + nae + nre;
+    float c1x, c2x, c1a, c2a, c1r = 0.f, c2r = 0.f;
+    langevin_coef(a, 0, &c1x, &c2x);
+    langevin_coef(a, 1, &c1a, &c2a);
+    if (a.is_cc) langevin_coef(a, 2, &c1r, &c2r);
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        if (t < nxe) {
+            const int per = a.N * a.F, b = (int)(t / per), idx = (int)(t % per), i = idx / a.F;
+            const float z = raw_noise_x(na, b, idx, per) * a.flags[(size_t)b * a.N + i];
+            a.ox[t] = fmaf(c2x, z, fmaf(c1x, a.nx[t], a.x[t]));
+        } else if (t < nxe + nae) {
+            const long long u = t - nxe;
+            const int per = a.N * a.N, b = (int)(u / per), ij = (int)(u % per), i = ij / a.N, j = ij % a.N;
+            const float z = raw_noise_adj(na, b, i, j, a.N) * a.flags[(size_t)b * a.N + i] * a.flags[(size_t)b * a.N + j];
+            a.oadj[u] = fmaf(c2a, z, fmaf(c1a, a.nadj[u], a.adj[u]));
+        } else {
+            const long long u = t - nxe - nae;
+            const int eg_n = (a.E + 3) / 4;
+            const int k = (int)(u % a.K), eg = (int)((u / a.K) % eg_n), b = (int)(u / ((long long)a.K * eg_n));
+            float z[4];
+            raw_noise_r4(na, b, eg, k, a.E, a.K, z);
+            const unsigned long long off = offbits[b];
+            const float fr = cell_on(off, cells, k);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int e = 4 * eg + s;
+                if (e >= a.E) continue;
+                const size_t gi = ((size_t)b * a.E + e) * a.K + k;
+                const float zz = z[s] * edge_on(off, edges, e) * fr;
+                a.orr[gi] = fmaf(c2r, zz, fmaf(c1r, a.nr[gi], a.r[gi]));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_s4_apply: the update half of one S4_solver step (solver.py:1296-1352 graph, 1446-1529 CC), element-wise:
+//   v1 = v + step*score + sqrt(2 step)*z1*scale_eps        Langevin-style correction with the step's score
+//   v2 = m1*v1 + s1*z2                                     sde.transition(v1, t, dt/2)
+//   v3 = v2 + d*net                                        + Sdrift*dt, Sdrift = -g(t)^2 * score
+//   mean = m2*v3 ;  v = mean + s2*z3                       sde.transition(v3, t + dt/2, dt/2)
+// Same indexing and masks as k_langevin_apply; three independent draws per element.
+// ---------------------------------------------------------------------------------------------
+struct S4Args {
+    LangArgs a;                       // state in/out, raw nets, flags, norm sums, Langevin scalars
+    float m1[3], s1[3], d[3], m2[3], s2[3];
+    float* mx; float* madj; float* mr;   // means (nullable)
+};
+CCSD_DEV float s4_chain(float v, float net, float z1, float z2, float z3, float c1, float c2, const S4Args& q, int t, float* mean) {
+    const float v1 = fmaf(c2, z1, fmaf(c1, net, v));
+    const float v2 = fmaf(q.s1[t], z2, q.m1[t] * v1);
+    const float v3 = fmaf(q.d[t], net, v2);
+    const float mu = q.m2[t] * v3;
+    *mean = mu;
+    return fmaf(q.s2[t], z3, mu);
+}
+__global__ void k_s4_apply(S4Args q, NoiseArgs n1, NoiseArgs n2, NoiseArgs n3, const unsigned long long* __restrict__ offbits,
+                           const unsigned char* __restrict__ edges, const unsigned long long* __restrict__ cells) {
+    const LangArgs& a = q.a;
+    const long long nxe = (long long)a.B * a.N * a.F, nae = (long long)a.B * a.N * a.N;
+    const long long nre = a.is_cc ? (long long)a.B * ((a.E + 3) / 4) * a.K : 0;
+    const long long total = nxe + nae + nre;
+    float c1x, c2x, c1a, c2a, c1r = 0.f, c2r = 0.f;
+    langevin_coef(a, 0, &c1x, &c2x);
+    langevin_coef(a, 1, &c1a, &c2a);
+    if (a.is_cc) langevin_coef(a, 2, &c1r, &c2r);
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        float mu;
+        if (t < nxe) {
+            const int per = a.N * a.F, b = (int)(t / per), idx = (int)(t % per), i = idx / a.F;
+            const float fl = a.flags[(size_t)b * a.N + i];
+            a.ox[t] = s4_chain(a.x[t], a.nx[t], raw_noise_x(n1, b, idx, per) * fl, raw_noise_x(n2, b, idx, per) * fl,
+                               raw_noise_x(n3, b, idx, per) * fl, c1x, c2x, q, 0, &mu);
+            if (q.mx) q.mx[t] = mu;
+        } else if (t < nxe + nae) {
+            const long long u = t - nxe;
+            const int per = a.N * a.N, b = (int)(u / per), ij = (int)(u % per), i = ij / a.N, j = ij % a.N;
+            const float fl = a.flags[(size_t)b * a.N + i] * a.flags[(size_t)b * a.N + j];
+            a.oadj[u] = s4_chain(a.adj[u], a.nadj[u], raw_noise_adj(n1, b, i, j, a.N) * fl, raw_noise_adj(n2, b, i, j, a.N) * fl,
+                                 raw_noise_adj(n3, b, i, j, a.N) * fl, c1a, c2a, q, 1, &mu);
+            if (q.madj) q.madj[u] = mu;
+        } else {
+            const long long u = t - nxe - nae;
+            const int eg_n = (a.E + 3) / 4;
+            const int k = (int)(u % a.K), eg = (int)((u / a.K) % eg_n), b = (int)(u / ((long long)a.K * eg_n));
+            float z1[4], z2[4], z3[4];
+            raw_noise_r4(n1, b, eg, k, a.E, a.K, z1);
+            raw_noise_r4(n2, b, eg, k, a.E, a.K, z2);
+            raw_noise_r4(n3, b, eg, k, a.E, a.K, z3);
+            const unsigned long long off = offbits[b];
+            const float fr = cell_on(off, cells, k);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int e = 4 * eg + s;
+                if (e >= a.E) continue;
+                const size_t gi = ((size_t)b * a.E + e) * a.K + k;
+                const float m = edge_on(off, edges, e) * fr;
+                a.orr[gi] = s4_chain(a.r[gi], a.nr[gi], z1[s] * m, z2[s] * m, z3[s] * m, c1r, c2r, q, 2, &mu);
+                if (q.mr) q.mr[gi] = mu;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_init_state: masked prior (solver.py:1111-1118; sde.py:436,448-449).  Same indexing as above.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_init_state(float* x, float* adj, float* r, const float* __restrict__ flags, NoiseArgs na,
+                             const unsigned long long* __restrict__ offbits, const unsigned char* __restrict__ edges,
+                             const unsigned long long* __restrict__ cells, int B, int N, int F, int E, int K, int is_cc) {
+    const long long nxe = (long long)B * N * F, nae = (long long)B * N * N;
+    const int eg_n = (E + 3) / 4;
+    const long long nre = is_cc ? (long long)B * eg_n * K : 0;
+    const long long total = nxe + nae + nre;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        if (t < nxe) {
+            const int per = N * F, b = (int)(t / per), idx = (int)(t % per);
+            x[t] = raw_noise_x(na, b, idx, per) * flags[(size_t)b * N + idx / F];
+        } else if (t < nxe + nae) {
+            const long long u = t - nxe;
+            const int per = N * N, b = (int)(u / per), ij = (int)(u % per), i = ij / N, j = ij % N;
+            adj[u] = raw_noise_adj(na, b, i, j, N) * flags[(size_t)b * N + i] * flags[(size_t)b * N + j];
+        } else {
+            const long long u = t - nxe - nae;
+            const int k = (int)(u % K), eg = (int)((u / K) % eg_n), b = (int)(u / ((long long)K * eg_n));
+            float z[4];
+            raw_noise_r4(na, b, eg, k, E, K, z);
+            const unsigned long long off = offbits[b];
+            const float fr = cell_on(off, cells, k);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int e = 4 * eg + s;
+                if (e < E) r[((size_t)b * E + e) * K + k] = edge_on(off, edges, e) * z[s] * fr;
+            }
+        }
+    }
+}
+
+// quantize / quantize_mol (graph_utils.py:191, 209-213)
+__global__ void k_quantize(const float* __restrict__ in, long long n, float thr, long long* __restrict__ out) {
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const float v = in[t];
+        long long q;
+        if (thr >= 0.f) q = v < thr ? 0 : 1;
+        else q = v >= 2.5f ? 3 : v >= 1.5f ? 2 : v >= 0.5f ? 1 : 0;
+        out[t] = q;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rank2_cells: sparse form of the quantised rank-2 incidence matrix -- the input cc_from_incidence needs
+// (cc_utils.py:243-262: column k holds a rank-2 cell iff any of its entries is non-zero after quantize()).
+// bits[b][k / 64] bit (k % 64) = any_e( rank2[b][e][k] >= thr );  counts[b] = number of set bits.
+// One workgroup per complex; a wave covers 64 consecutive columns per pass (coalesced rows), its ballot is the word.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_rank2_cells(const float* __restrict__ rank2, int E, int K, float thr, unsigned long long* __restrict__ bits,
+                              int* __restrict__ counts) {
+    const int b = blockIdx.x, W = (K + 63) >> 6;
+    const float* Fb = rank2 + (size_t)b * E * K;
+#ifdef CCSD_EMU
+    int total = 0;
+    for (int wd = 0; wd < W; ++wd) {
+        unsigned long long m = 0;
+        for (int q = 0; q < 64; ++q) {
+            const int k = 64 * wd + q;
+            bool any = false;
+            if (k < K)
+                for (int e = 0; e < E; ++e) any = any || Fb[(size_t)e * K + k] >= thr;
+            if (any) { m |= 1ull << q; ++total; }
+        }
+        bits[(size_t)b * W + wd] = m;
+    }
+    counts[b] = total;
+#else
+    __shared__ int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    int mine = 0;
+    for (int wd = wave; wd < W; wd += nw) {
+        const int k = 64 * wd + lane, kc = k < K ? k : K - 1;
+        bool any = false;
+        for (int e = 0; e < E; ++e) any = any || Fb[(size_t)e * K + kc] >= thr;
+        const unsigned long long m = __ballot(any && k < K);
+        if (lane == 0) { bits[(size_t)b * W + wd] = m; mine += __popcll(m); }
+    }
+    if (lane == 0 && mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[b] = s_cnt;
+#endif
+}
+

@@ -1,0 +1,718 @@
+// ccsd_k_xa.h -- k_xa: ScoreNetworkX + ScoreNetworkA / ScoreNetworkA_CC for one graph per workgroup
+// Part of the kernel source of libccsd_hip.so (see ccsd_kernels.h for the map).
+#pragma once
+#include "ccsd_rank2_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// k_xa: ScoreNetworkX + ScoreNetworkA / ScoreNetworkA_CC for one graph per workgroup.
+// ---------------------------------------------------------------------------------------------
+#define XA_PLAIN 0
+#define XA_HB 1
+#define XA_GMH 2
+#define XA_GEN 3          /* everything, selected at run time from the plan: both of the above together, conv = "MLP" */
+struct XaArgs {
+    // inputs: the X-network and the A-network may see different (x, adj) when the Langevin
+    // corrector runs more than one inner step (solver.py:759-784)
+    const float* xX; const float* adjX;
+    const float* xA; const float* adjA;
+    const float* flags;
+    const float* P0; const float* P1;     // hodge projections (B*E, wc_l)
+    int do_x, do_a;
+    int mode;
+    float ss_x, ss_a;                     // MODE_SCORE scaling
+    float pa_x, pb_x, pc_x, pa_a, pb_a, pc_a;
+    float* out_x; float* out_a;           // SCORE: scores; NORMS: raw nets; PRED: new state
+    float* mean_x; float* mean_a;         // PRED, nullable
+    float* norm2;                         // NORMS: [B][4] = |net_x|^2, |net_adj|^2, |z_x|^2, |z_adj|^2
+    float* chan_ws;                       // GCH: [B][a_fdim][N*N] channel stack in the workspace
+    const float* wp;                      // packed (zero-padded) chain-MLP weights
+    const unsigned char* hpairs;          // (e, e2), e <= e2: unordered pairs of the dense hodge layer
+    long long* dbg;
+    CorrFuse cf;
+};
+
+// fused Langevin corrector apply for x and adj held in LDS (same expressions as k_langevin_apply)
+CCSD_DEV void corr_apply_xa(const CorrFuse& cf, const NoiseArgs& na, int b, int N, int F, float* s_x, float* s_adj,
+                            const float* s_flags) {
+    float c1x, c2x, c1a, c2a;
+    corr_coef(cf, 0, &c1x, &c2x);
+    corr_coef(cf, 1, &c1a, &c2a);
+    NoiseArgs nc = na;
+    nc.zx = nullptr; nc.zadj = nullptr; nc.draw_x = cf.draw_x; nc.draw_adj = cf.draw_adj;
+    for (int t = threadIdx.x; t < N * F; t += blockDim.x) {
+        const float z = raw_noise_x(nc, b, t, N * F) * s_flags[t / F];
+        s_x[t] = fmaf(c2x, z, fmaf(c1x, cf.net_x[(size_t)b * N * F + t], s_x[t]));
+    }
+    for (int t = threadIdx.x; t < N * N; t += blockDim.x) {
+        const int i = t / N, j = t % N;
+        const float z = raw_noise_adj(nc, b, i, j, N) * s_flags[i] * s_flags[j];
+        s_adj[t] = fmaf(c2a, z, fmaf(c1a, cf.net_adj[(size_t)b * N * N + t], s_adj[t]));
+    }
+}
+
+// clamp(rowsum(A with unit diagonal), 1)^-1/2 for `nc` channels   (DenseGCNConv, layers.py:139-145)
+CCSD_DEV void gcn_dinv(const float* a, float* dinv, int nc, int N) {
+    const FastDiv dN(N);
+    for (int t = threadIdx.x; t < nc * N; t += blockDim.x) {
+        int c, i;
+        dN.divmod(t, c, i);
+        const float* r = a + c * N * N + i * N;
+        float s = 0.f;
+        for (int j = 0; j < N; ++j) s += (i == j) ? 1.f : r[j];
+        dinv[t] = 1.0f / sqrtf(fmaxf(s, 1.f));
+    }
+}
+
+// GCH: the channel stack (every AttentionLayer's adjacency channels, the final MLP's input) does not fit LDS
+// (zinc250k, N = 38: 266 KB) and lives in a per-graph slab of the workspace instead; a workgroup's waves share one
+// CU and its L1, so __syncthreads() orders those global accesses exactly like the LDS ones.
+// Weights are read in place from L2.
+// VAR: XA_PLAIN; XA_HB: the plan holds HodgeBaselineLayers (ScoreNetworkA_Base_CC); XA_GMH: the X-network is
+// ScoreNetworkX_GMH; XA_GEN: both, and conv = "MLP" attention.  Separate instantiations keep those branches out of the register allocation of the headline variant.
+template <bool GCH, int VAR>
+__global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict__ plan, const float* __restrict__ w,
+                                            const unsigned char* __restrict__ edges, XaArgs xa, NoiseArgs na) {
+    CCSD_DYN_SMEM(sm);
+    const PlanD& p = *plan;
+    constexpr bool HB = VAR == XA_HB || VAR == XA_GEN, GMH = VAR == XA_GMH || VAR == XA_GEN, CONVMLP = VAR == XA_GEN;
+    const int N = p.N, F = p.F, NN = N * N, E = p.E, ldn = p.ldn;
+    const int b = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    float* s_flags = sm + p.o_flags;
+    float* s_x = sm + p.o_x;
+    float* s_adj = sm + p.o_adj;
+    float* s_dinv = sm + p.o_an;
+    float* s_red = sm + (xa.do_a ? p.o_red : p.o_xcat);   // block reductions: a region that is idle at the end of the launch
+    float* s_R = sm + p.o_c0;            // shared region: GCN scratch | MLP hidden activations | dense hodge layer
+    const FastDiv dN(N), dNN(NN), dF(F), dE(E > 0 ? E : 1);
+    const float* wp = xa.wp;
+#ifdef CCSD_EMU
+    const int wave_id = 0, n_waves = 1;
+#else
+    const int wave_id = tid >> 6, n_waves = nth >> 6;
+#endif
+
+    stamp(xa.dbg, 0);
+    for (int i = tid; i < N; i += nth) s_flags[i] = xa.flags[(size_t)b * N + i];
+    float nx_net = 0.f, nx_z = 0.f, na_net = 0.f, na_z = 0.f;
+
+    // ================= ScoreNetworkX (ScoreNetwork_X.py:102-132) =================
+    if (xa.do_x) {
+        float* s_xcat = sm + p.o_xcat;
+        float* s_h1 = sm + p.o_h1;
+        float* s_h2 = sm + p.o_h2;
+        float* s_xw = s_R;
+        const float* wx = w;
+        for (int i = tid; i < N * F; i += nth) s_x[i] = xa.xX[(size_t)b * N * F + i];
+        for (int i = tid; i < NN; i += nth) s_adj[i] = xa.adjX[(size_t)b * NN + i];
+        if (xa.cf.on) { __syncthreads(); corr_apply_xa(xa.cf, na, b, N, F, s_x, s_adj, s_flags); }
+        __syncthreads();
+        const int H = p.x_nhid;
+        if (GMH && p.x_gmh) {
+            float* s_chan = GCH ? xa.chan_ws + (size_t)b * p.chan_rows * NN : sm + p.o_chan;
+            // unordered pair e -> (i, j), i < j: the edge table, copied to LDS once (the global copy costs an L2 round trip
+            // at the head of every per-pair phase)
+            int* s_edge = reinterpret_cast<int*>(sm + p.o_edge);
+            for (int e = tid; e < E; e += nth) s_edge[e] = ((int)edges[2 * e] << 8) | (int)edges[2 * e + 1];
+            auto edge_i = [&](int e) { return s_edge[e] >> 8; };
+            auto edge_j = [&](int e) { return s_edge[e] & 255; };
+            auto pair_off = [&](int e) { const int v = s_edge[e]; return (v >> 8) * N + (v & 255); };
+            float* s_att = sm + p.o_att;
+            float* s_xcur = sm + p.o_xcur;
+            float* s_xnext = sm + p.o_xnext;
+            float* s_mch = sm + p.o_vcat;
+            // ScoreNetworkX_GMH.forward_graph (ScoreNetwork_X.py:290-318): x_list = [x, tanh(AttentionLayer_k(...))...]
+            for (int t = tid; t < N * F; t += nth) { int i, f; dF.divmod(t, i, f); s_xcat[f * ldn + i] = s_x[t]; s_xcur[f * ldn + i] = s_x[t]; }
+            for (int i = tid; i < NN; i += nth) s_chan[i] = s_adj[i];
+            __syncthreads();
+            for (int c = 1; c < p.g_cinit; ++c) {                  // pow_tensor (graph_utils.py:285-292)
+                for (int t = tid; t < NN; t += nth) {
+                    int i, j;
+                    dN.divmod(t, i, j);
+                    float acc = 0.f;
+                    for (int k = 0; k < N; ++k) acc = fmaf(s_chan[(c - 1) * NN + i * N + k], s_adj[k * N + j], acc);
+                    s_chan[c * NN + t] = acc;
+                }
+                __syncthreads();
+            }
+            auto gmh_tap = [&](int l) {
+                for (int t = tid; t < N * H; t += nth) {
+                    int o, i;
+                    dN.divmod(t, o, i);
+                    const float v = tanh_f(s_xcur[o * ldn + i]);   // x = self.activation(x): feeds the next layer and x_list
+                    s_xcur[o * ldn + i] = v;
+                    s_xcat[(F + l * H + o) * ldn + i] = v;
+                }
+                __syncthreads();
+            };
+#define ATTN_LAYERS p.gl
+#define ATTN_NL p.x_depth
+#define ATTN_TAP(l) gmh_tap(l)
+#include "ccsd_attn_stack.inc"
+#undef ATTN_LAYERS
+#undef ATTN_NL
+#undef ATTN_TAP
+        } else {
+        gcn_dinv(s_adj, s_dinv, 1, N);
+        for (int t = tid; t < N * F; t += nth) { int i, f; dF.divmod(t, i, f); s_xcat[f * ldn + i] = s_x[t]; }
+        __syncthreads();
+        for (int l = 0; l < p.x_depth; ++l) {
+            const int fin = l ? H : F;
+            const float* src = s_xcat + (l ? (F + (l - 1) * H) : 0) * ldn;
+            const float* W = wx + p.x_gw[l];
+            const float* B = wx + p.x_gb[l];
+            float* dst = s_xcat + (F + l * H) * ldn;
+            // tanh(DenseGCNConv(x, adj)) (ScoreNetwork_X.py:118-121): 16-column tiles over the waves
+            for (int ct = wave_id; ct < (H + 15) >> 4; ct += n_waves)
+                gcn_tile_n<GCH>(src, ldn, fin, N, s_adj, s_dinv, 16 * ct, H,
+                           [&](int k, int col) { return W[k * H + col]; }, [&](int col) { return B[col]; },
+                           [&](int i, int col, float v) { dst[col * ldn + i] = tanh_f(v); });
+            __syncthreads();
+        }
+        }
+        const MlpD& m = p.x_fin;
+        if (m.chain) {
+            auto epx = [&](int row, int f, float v) { s_h1[f * ldn + row] = v; };
+            auto ident = [](int r) { return r; };
+            if (m.chain == 2) mlp_chain<2, 3, 1>(m, wp, s_xcat, ldn, s_xcat, m.in, N, ident, epx);
+            else mlp_chain<3, 6, 1>(m, wp, s_xcat, ldn, s_xcat, m.in, N, ident, epx);
+        } else {
+            block_linear<1>(s_h1, ldn, s_xcat, ldn, s_xcat, m.in, wx + m.w[0], wx + m.b[0], m.in, m.hid, N);
+            __syncthreads();
+            block_linear<1>(s_h2, ldn, s_h1, ldn, s_h1, m.hid, wx + m.w[1], wx + m.b[1], m.hid, m.hid, N);
+            __syncthreads();
+            block_linear<0>(s_h1, ldn, s_h2, ldn, s_h2, m.hid, wx + m.w[2], wx + m.b[2], m.hid, m.out, N);
+        }
+        __syncthreads();
+        for (int t = tid; t < N * F; t += nth) {
+            int i, f;
+            dF.divmod(t, i, f);
+            const float fl = s_flags[i];
+            const float net = s_h1[f * ldn + i] * fl;                   // mask_x, graph_utils.py:37
+            const size_t gi = (size_t)b * N * F + t;
+            if (xa.mode == MODE_SCORE) {
+                xa.out_x[gi] = xa.ss_x * net;
+            } else {
+                const float z = raw_noise_x(na, b, t, N * F) * fl;       // gen_noise(sym=False)
+                if (xa.mode == MODE_NORMS) {
+                    xa.out_x[gi] = net;
+                    nx_net = fmaf(net, net, nx_net);
+                    nx_z = fmaf(z, z, nx_z);
+                } else {
+                    const float mean = fmaf(xa.pa_x, s_x[t], xa.pb_x * net);
+                    if (xa.mean_x) xa.mean_x[gi] = mean;
+                    xa.out_x[gi] = fmaf(xa.pc_x, z, mean);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    stamp(xa.dbg, 1);
+    // ================= ScoreNetworkA / ScoreNetworkA_CC =================
+    if (xa.do_a) {
+        float* s_chan = GCH ? xa.chan_ws + (size_t)b * p.chan_rows * NN : sm + p.o_chan;
+        // unordered pair e -> (i, j), i < j: the edge table, copied to LDS once (the global copy costs an L2 round trip
+        // at the head of every per-pair phase)
+        int* s_edge = reinterpret_cast<int*>(sm + p.o_edge);
+        for (int e = tid; e < E; e += nth) s_edge[e] = ((int)edges[2 * e] << 8) | (int)edges[2 * e + 1];
+        auto edge_i = [&](int e) { return s_edge[e] >> 8; };
+        auto edge_j = [&](int e) { return s_edge[e] & 255; };
+        auto pair_off = [&](int e) { const int v = s_edge[e]; return (v >> 8) * N + (v & 255); };
+        float* s_att = sm + p.o_att;
+        float* s_xcur = sm + p.o_xcur;
+        float* s_xnext = sm + p.o_xnext;
+        float* s_mch = sm + p.o_vcat;
+        if (xa.cf.on) {
+            // fused corrector: the A-network sees the corrected (x, adj).  When the X-network phase of this launch has just
+            // built them from the same inputs (predictor launches: xA == xX, adjA == adjX) they are still in LDS.
+            const bool reuse = xa.do_x && xa.xA == xa.xX && xa.adjA == xa.adjX;
+            __syncthreads();
+            if (!reuse) {
+                for (int i = tid; i < N * F; i += nth) s_x[i] = xa.xA[(size_t)b * N * F + i];
+                for (int i = tid; i < NN; i += nth) s_adj[i] = xa.adjA[(size_t)b * NN + i];
+                __syncthreads();
+                corr_apply_xa(xa.cf, na, b, N, F, s_x, s_adj, s_flags);
+                __syncthreads();
+            }
+            for (int t = tid; t < N * F; t += nth) { int i, f; dF.divmod(t, i, f); s_xcur[f * ldn + i] = s_x[t]; }
+            for (int i = tid; i < NN; i += nth) s_chan[i] = s_adj[i];
+        } else {
+            for (int t = tid; t < N * F; t += nth) {
+                const float v = xa.xA[(size_t)b * N * F + t];
+                int i, f;
+                dF.divmod(t, i, f);
+                s_xcur[f * ldn + i] = v;
+            }
+            for (int i = tid; i < NN; i += nth) { const float v = xa.adjA[(size_t)b * NN + i]; s_adj[i] = v; s_chan[i] = v; }
+        }
+        __syncthreads();
+        // pow_tensor: channel c = channel(c-1) @ adj   (graph_utils.py:285-292)
+        for (int c = 1; c < p.a_cinit; ++c) {
+            for (int t = tid; t < NN; t += nth) {
+                int i, j;
+                dN.divmod(t, i, j);
+                float acc = 0.f;
+                for (int k = 0; k < N; ++k) acc = fmaf(s_chan[(c - 1) * NN + i * N + k], s_adj[k * N + j], acc);
+                s_chan[c * NN + t] = acc;
+            }
+            __syncthreads();
+        }
+#define ATTN_LAYERS p.al
+#define ATTN_NL p.a_L
+#define ATTN_TAP(l) (void)0
+#include "ccsd_attn_stack.inc"
+#undef ATTN_LAYERS
+#undef ATTN_NL
+#undef ATTN_TAP
+
+        stamp(xa.dbg, 12);
+        // ---- hodge branch of ScoreNetworkA_CC (ScoreNetwork_A_CC.py:295-316)
+        if (VAR != XA_HB && p.h_L > 0) {
+            float* s_hd = sm + p.o_hd;          // [hodge channel][E]: diagonals that reach the final MLP
+            float* s_hq = sm + p.o_hq;          // [channel][E][2*adim]
+            float* s_h1m = s_R;                 // [cout0][E][E] dense output of the first hodge layer
+            const float kscale = (float)sqrt((double)p.K);  // hodge_attention.py:118,122: / sqrt(out_dim), out_dim = K
+            const float rks = 1.0f / kscale;
+            float* s_hw = sm + p.o_hw;         // zero-padded mlp_attention weight blocks of both hodge layers
+            stage_mlp_blocks(p.hl[0].matt, w, s_hw);
+            if (p.h_L > 1) stage_mlp_blocks(p.hl[1].matt, w, s_hw + p.hw_stride);
+            const HodgeLayerD& h0 = p.hl[0];
+            const int qw0 = 2 * h0.adim;
+            const FastDiv dqw0(qw0), dEqw0(E * qw0);
+            const float* P0b = xa.P0 + (size_t)b * E * h0.wc;
+            // adj_to_hodgedual (cc_utils.py:1525-1536): diagonal hodge adjacency = upper triangle of the adjacency powers;
+            // DenseHCNConv on a diagonal matrix (hodge_layers.py:185-193) is a row scaling
+            for (int t = tid; t < p.a_cinit * E; t += nth) {
+                int c, e;
+                dE.divmod(t, c, e);
+                s_hd[t] = s_chan[c * NN + pair_off(e)];
+            }
+            for (int t = tid; t < h0.cin * E * qw0; t += nth) {
+                int c, r, e, d;
+                dEqw0.divmod(t, c, r);
+                dqw0.divmod(r, e, d);
+                const float a = s_chan[c * NN + pair_off(e)];
+                const float g = 1.0f / sqrtf(fmaxf(a, 1.f));
+                s_hq[t] = fmaf(g * a * g, P0b[(size_t)e * h0.wc + c * qw0 + d], w[h0.bcat + c * qw0 + d]);
+            }
+            const bool w4_0 = mlp_maxw(h0.matt) <= 4 && h0.cin <= 4;
+            __syncthreads();
+            stamp(xa.dbg, 16);
+            if (p.h_L == 1) {
+                // only the diagonal is ever used (hodgedual_to_adj, cc_utils.py:1571)
+                for (int e = tid; e < E; e += nth) {
+                    float in[CCSD_SMALLW], out[CCSD_SMALLW];
+#pragma unroll
+                    for (int c = 0; c < CCSD_SMALLW; ++c) {
+                        float sacc = 0.f;
+                        if (c < h0.cin) {
+                            const float* q = s_hq + (c * E + e) * qw0;
+                            for (int hh = 0; hh < h0.nchunk; ++hh) {
+                                float d = 0.f;
+                                for (int u = 0; u < h0.dsplit; ++u) d = fmaf(q[hh * h0.dsplit + u], q[h0.adim + hh * h0.dsplit + u], d);
+                                sacc += tanh_f(d * rks);
+                            }
+                            sacc *= 1.0f / (float)h0.nchunk;
+                        }
+                        in[c] = sacc;
+                    }
+                    small_mlp_lds<CCSD_SMALLW>(s_hw, h0.matt.n, in, out);   // mlp_attention -> mask -> tanh -> + transpose
+                    const float fh = s_flags[edge_i(e)] * s_flags[edge_j(e)];
+#pragma unroll
+                    for (int o = 0; o < CCSD_SMALLW; ++o)
+                        if (o < h0.cout) { const float tv = tanh_f(out[o] * fh * fh); s_hd[(p.a_cinit + o) * E + e] = tv + tv; }
+                }
+                __syncthreads();
+            } else {
+                // dense E x E attention of every channel, mlp_attention, mask, tanh, + transpose (hodge_attention.py:315-320):
+                // one thread per unordered pair (e <= e2) from the pair table, both halves stored
+                const HodgeLayerD& h1 = p.hl[1];
+                const int qw1 = 2 * h1.adim;
+                const float rnc0 = 1.0f / (float)h0.nchunk;
+                const int npair = E * (E + 1) / 2;
+                const float* P1b = xa.P1 + (size_t)b * E * h1.wc;   // [E][wc1] projections of the second layer (L2)
+                const int mtE = (E + 15) >> 4, ntq = (qw1 + 15) >> 4, ksE = (E + 3) >> 2;
+#ifndef CCSD_EMU
+                // The second layer's projection tasks are (channel, 16-column tile) x row tiles; with one (channel, column
+                // tile) per wave its B operands are the same for every row tile: fetch them now, so the L2 latency hides
+                // behind the dense attention below
+                const bool pf_ok = h1.cin * ntq <= n_waves && ksE <= 16;
+                float pfb[16];
+                const int pf_c = wave_id / ntq, pf_ct = wave_id % ntq;
+                const int pf_l15 = tid & 15, pf_kq = (tid & 63) >> 4;
+                if (pf_ok && wave_id < h1.cin * ntq) {
+#pragma unroll
+                    for (int s0 = 0; s0 < 16; ++s0) {
+                        const int k = 4 * s0 + pf_kq, d = 16 * pf_ct + pf_l15;
+                        pfb[s0] = P1b[(k < E ? k : E - 1) * h1.wc + pf_c * qw1 + (d < qw1 ? d : qw1 - 1)];
+                    }
+                }
+#endif
+                int pe_n = 0, pe2_n = 0;
+                if (tid < npair) { pe_n = xa.hpairs[2 * tid]; pe2_n = xa.hpairs[2 * tid + 1]; }
+                for (int t = tid; t < npair; t += nth) {
+                    const int e = pe_n, e2 = pe2_n;
+                    if (t + nth < npair) { pe_n = xa.hpairs[2 * (t + nth)]; pe2_n = xa.hpairs[2 * (t + nth) + 1]; }   // next pair: in flight
+                    float in[CCSD_SMALLW], out[CCSD_SMALLW];
+#pragma unroll
+                    for (int c = 0; c < CCSD_SMALLW; ++c) {
+                        float v = 0.f;
+                        if (c < h0.cin) {
+                            const float* q1 = s_hq + (c * E + e) * qw0;
+                            const float* q2 = s_hq + (c * E + e2) * qw0;
+                            float s1 = 0.f, s2 = 0.f;
+                            for (int hh = 0; hh < h0.nchunk; ++hh) {
+                                float d1 = 0.f, d2 = 0.f;
+                                for (int u = 0; u < h0.dsplit; ++u) {
+                                    const int oq = hh * h0.dsplit + u, ok = h0.adim + oq;
+                                    d1 = fmaf(q1[oq], q2[ok], d1);
+                                    d2 = fmaf(q2[oq], q1[ok], d2);
+                                }
+                                s1 += tanh_f(d1 * rks);
+                                s2 += tanh_f(d2 * rks);
+                            }
+                            v = (s1 * rnc0 + s2 * rnc0) * 0.5f;
+                        }
+                        in[c] = v;
+                    }
+                    if (w4_0) small_mlp_lds<4>(s_hw, h0.matt.n, in, out); else small_mlp_lds<CCSD_SMALLW>(s_hw, h0.matt.n, in, out);
+                    const float fh = s_flags[edge_i(e)] * s_flags[edge_j(e)];
+                    const float fh2 = s_flags[edge_i(e2)] * s_flags[edge_j(e2)];
+#pragma unroll
+                    for (int o = 0; o < CCSD_SMALLW; ++o)
+                        if (o < h0.cout) {
+                            const float tv = tanh_f(out[o] * fh * fh2);   // inputs are exactly symmetric -> h + h^T = 2h
+                            s_h1m[o * E * E + e * E + e2] = tv + tv;
+                            s_h1m[o * E * E + e2 * E + e] = tv + tv;
+                            if (e == e2) s_hd[(p.a_cinit + o) * E + e] = tv + tv;
+                        }
+                }
+                __syncthreads();
+                stamp(xa.dbg, 17);
+                // second (last) HodgeAdjAttentionLayer: dense hodge adjacency, only the diagonal of its output
+                float* s_deg = sm + p.o_deg;         // [cin1][E]
+                for (int t = tid; t < h1.cin * E; t += nth) {
+                    int c, e;
+                    dE.divmod(t, c, e);
+                    // degree = row sum; the matrix is symmetric, so walk the column: consecutive lanes hit consecutive banks
+                    const float* Hc = s_h1m + (size_t)c * E * E + e;
+                    float s0 = 0.f, s1 = 0.f;
+                    int e2 = 0;
+                    for (; e2 + 2 <= E; e2 += 2) { s0 += Hc[e2 * E]; s1 += Hc[(e2 + 1) * E]; }
+                    if (e2 < E) s0 += Hc[e2 * E];
+                    s_deg[t] = 1.0f / sqrtf(fmaxf(s0 + s1, 1.f));
+                }
+                __syncthreads();
+                stamp(xa.dbg, 18);
+                // Q|K of the dense layer on MFMA: per channel  Y = D H D P1_c  (hodge_layers.py:185-193), tile tasks
+                // (channel, 16 rows of e) x 16 columns (2*adim <= 16 used) over the waves
+                {
+#ifndef CCSD_EMU
+                    if (pf_ok) {
+                        if (wave_id < h1.cin * ntq) {
+                            typedef float f32x4 __attribute__((ext_vector_type(4)));
+                            const float* Hc = s_h1m + (size_t)pf_c * E * E;
+                            const float* dg = s_deg + pf_c * E;
+                            const int d = 16 * pf_ct + pf_l15;
+                            float bval[16];
+#pragma unroll
+                            for (int s0 = 0; s0 < 16; ++s0) {
+                                const int k = 4 * s0 + pf_kq;
+                                bval[s0] = (k < E && d < qw1) ? dg[k < E ? k : E - 1] * pfb[s0] : 0.f;
+                            }
+                            const float bias = w[h1.bcat + pf_c * qw1 + (d < qw1 ? d : qw1 - 1)];
+                            for (int rt = 0; rt < mtE; ++rt) {
+                                const int e = 16 * rt + pf_l15, ec = e < E ? e : E - 1;
+                                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                                for (int s0 = 0; s0 < 16; ++s0)
+                                    if (s0 < ksE) {
+                                        const int k = 4 * s0 + pf_kq;
+                                        const float hv = Hc[ec * E + (k < E ? k : E - 1)];
+                                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32((e < E && k < E) ? hv : 0.f, bval[s0], acc, 0, 0, 0);
+                                    }
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int eo = 16 * rt + 4 * pf_kq + r;
+                                    if (eo < E && d < qw1) s_hq[(pf_c * E + eo) * qw1 + d] = fmaf(dg[eo], acc[r], bias);
+                                }
+                            }
+                        }
+                    } else
+#endif
+                    for (int task = wave_id; task < h1.cin * mtE * ntq; task += n_waves) {
+                        const int c = task / (mtE * ntq), rem = task % (mtE * ntq), rt = rem / ntq, ct = rem % ntq;
+                        const float* Hc = s_h1m + (size_t)c * E * E;
+                        const float* dg = s_deg + c * E;
+                        wave_tile(16 * rt, 16 * ct, ksE,
+                                  [&](int e, int k) { const float v = Hc[(e < E ? e : E - 1) * E + (k < E ? k : E - 1)]; return (e < E && k < E) ? v : 0.f; },
+                                  [&](int k, int d) {
+                                      const int kc = k < E ? k : E - 1, dc = d < qw1 ? d : qw1 - 1;
+                                      const float v = dg[kc] * P1b[kc * h1.wc + c * qw1 + dc];
+                                      return (k < E && d < qw1) ? v : 0.f;
+                                  },
+                                  [&](int e, int d, float acc) {
+                                      if (e < E && d < qw1) s_hq[(c * E + e) * qw1 + d] = fmaf(dg[e], acc, w[h1.bcat + c * qw1 + d]);
+                                  });
+                    }
+                }
+                __syncthreads();
+                stamp(xa.dbg, 19);
+                const bool w4_1 = mlp_maxw(h1.matt) <= 4 && h1.cin <= 4;
+                for (int e = tid; e < E; e += nth) {
+                    float in[CCSD_SMALLW], out[CCSD_SMALLW];
+#pragma unroll
+                    for (int c = 0; c < CCSD_SMALLW; ++c) {
+                        float sacc = 0.f;
+                        if (c < h1.cin) {
+                            const float* q = s_hq + (c * E + e) * qw1;
+                            for (int hh = 0; hh < h1.nchunk; ++hh) {
+                                float d = 0.f;
+                                for (int u = 0; u < h1.dsplit; ++u) d = fmaf(q[hh * h1.dsplit + u], q[h1.adim + hh * h1.dsplit + u], d);
+                                sacc += tanh_f(d * rks);
+                            }
+                            sacc *= 1.0f / (float)h1.nchunk;
+                        }
+                        in[c] = sacc;
+                    }
+                    if (w4_1) small_mlp_lds<4>(s_hw + p.hw_stride, h1.matt.n, in, out); else small_mlp_lds<CCSD_SMALLW>(s_hw + p.hw_stride, h1.matt.n, in, out);
+                    const float fh = s_flags[edge_i(e)] * s_flags[edge_j(e)];
+#pragma unroll
+                    for (int o = 0; o < CCSD_SMALLW; ++o)
+                        if (o < h1.cout) { const float tv = tanh_f(out[o] * fh * fh); s_hd[(p.a_cinit + h0.cout + o) * E + e] = tv + tv; }
+                }
+                __syncthreads();
+            }
+            stamp(xa.dbg, 20);
+            // hodgedual_to_adj (cc_utils.py:1552-1588): scatter the diagonals behind the graph channels
+            for (int t = tid; t < p.a_nch_hodge * E; t += nth) {
+                int c, e;
+                dE.divmod(t, c, e);
+                const int i = edge_i(e), j = edge_j(e);
+                const float v = s_hd[t];
+                s_chan[(p.a_nch_graph + c) * NN + i * N + j] = v;
+                s_chan[(p.a_nch_graph + c) * NN + j * N + i] = v;
+            }
+            __syncthreads();
+        }
+
+        // ---- hodge branch of ScoreNetworkA_Base_CC (ScoreNetwork_A_Base_CC.py:295-316): HodgeBaselineLayers
+        // (hodge_layers.py:385-416) on the E x E hodge adjacency channels.  Their rank-2 outputs (bmm + mlp_rank2) never
+        // reach the score and are not evaluated; of the last layer only the diagonal does (hodgedual_to_adj), so the dense
+        // E x E output of the first layer is produced a chunk of rows at a time and consumed on the spot.
+        if (HB && p.hb_L > 0) {
+            float* s_hd = sm + p.o_hd;            // [hodge channel][E]: diagonals that reach the final MLP
+            float* s_g = sm + p.o_hbg;            // [cin0][E][hid0]: hidden rows of the first layer's BaselineBlocks
+            const HodgeBaseD& b0 = p.hb[0];
+            const int hd0 = b0.hid;
+            // mlp_hodge of both layers as zero-padded 16 x 16 blocks in LDS (broadcast reads instead of per-weight scalar loads)
+            constexpr int HBS = CCSD_FW * CCSD_FW + CCSD_FW;
+            float* s_mh = sm + p.o_hbw;
+            stage_mlp_blocks_w<CCSD_FW>(b0.mh, w, s_mh);
+            if (p.hb_L > 1) stage_mlp_blocks_w<CCSD_FW>(p.hb[1].mh, w, s_mh + CCSD_MAXLIN * HBS);
+            const FastDiv dh0(hd0), dEh0(E * hd0);
+            // adj_to_hodgedual: row e of input channel c is a_c[e] * onehot(e)  =>  hidden = elu(W1[:, e] * a_c[e] + b1)
+            for (int t = tid; t < p.a_cinit * E; t += nth) {
+                int c, e;
+                dE.divmod(t, c, e);
+                s_hd[t] = s_chan[c * NN + pair_off(e)];
+            }
+            for (int t = tid; t < b0.cin * E * hd0; t += nth) {
+                int c, r, e, h;
+                dEh0.divmod(t, c, r);
+                dh0.divmod(r, e, h);
+                const float* blk = w + b0.blk_base + c * b0.blk_stride;       // W1[hid][E] b1[hid] W2[E][hid] b2[E]
+                const float a = s_chan[c * NN + pair_off(e)];
+                s_g[t] = elu1(fmaf(blk[h * E + e], a, blk[hd0 * E + h]));
+            }
+            __syncthreads();
+            stamp(xa.dbg, 16);
+            // tanh(mlp_layer(H_c))[e][e2] from the hidden row of e (BaselineBlock.forward, hodge_layers.py:264)
+            auto blockv = [&](int c, int e, int e2) {
+                const float* blk = w + b0.blk_base + c * b0.blk_stride;
+                const float* w2t = wp + b0.w2t + c * hd0 * E + e2;       // W2^T [hid][E]: lanes along e2 read consecutive floats
+                const float* g = s_g + (c * E + e) * hd0;
+                const float bias = blk[hd0 * E + hd0 + E * hd0 + e2];
+                return tanh_f(dot_gl<true>(w2t, E, g, hd0) + bias);
+            };
+            // mlp_hodge over the symmetrised channels -> mask_hodge_adjs -> tanh -> + transpose, element (e, e2) of layer 0
+            auto layer0 = [&](int e, int e2, float* out) {
+                float in[CCSD_FW];
+#pragma unroll
+                for (int c = 0; c < CCSD_FW; ++c) in[c] = 0.f;
+#pragma unroll
+                for (int c = 0; c < CCSD_FW; ++c)
+                    if (c < b0.cin) in[c] = e == e2 ? blockv(c, e, e) : (blockv(c, e, e2) + blockv(c, e2, e)) * 0.5f;
+                small_mlp_ldsw<CCSD_FW>(s_mh, b0.mh.n, in, out);
+                const float fh = s_flags[edge_i(e)] * s_flags[edge_j(e)] * s_flags[edge_i(e2)] * s_flags[edge_j(e2)];
+#pragma unroll
+                for (int o = 0; o < CCSD_FW; ++o) { const float tv = tanh_f(out[o] * fh); out[o] = tv + tv; }
+            };
+            if (p.hb_L == 1) {
+                for (int e = tid; e < E; e += nth) {
+                    float out[CCSD_FW];
+                    layer0(e, e, out);
+#pragma unroll
+                    for (int o = 0; o < CCSD_FW; ++o)
+                        if (o < b0.cout) s_hd[(p.a_cinit + o) * E + e] = out[o];
+                }
+                __syncthreads();
+            } else {
+                const HodgeBaseD& b1 = p.hb[1];
+                const int hd1 = b1.hid, R = p.hb_rows;
+                float* s_row = s_R;                           // [cout0][R][E]: rows r0 .. r0 + R of layer 0's output
+                float* s_g2 = s_R + b0.cout * R * E;          // [R][cin1][hid1]: hidden rows of the second layer's blocks
+                float* s_S = s_g2 + R * b1.cin * b1.hid;      // [cin0][R * E]: symmetrised block outputs = mlp_hodge's input rows
+                const FastDiv dRE(R * E);
+                float* s_d2 = sm + p.o_hbd;                   // [cin1][E]: diagonal of tanh(mlp_layer(H1_c))
+                const FastDiv dch1(b1.cin * hd1);
+                for (int r0 = 0; r0 < E; r0 += R) {
+                    const int nr = (E - r0) < R ? (E - r0) : R;
+                    if (r0 == 0) stamp(xa.dbg, 17);
+                    if (b0.mh.chain) {
+                        // (channel, pair) tasks fill mlp_hodge's input, then the MLP runs per 16-pair tile on MFMA
+                        for (int t = tid; t < b0.cin * R * E; t += nth) {
+                            int c, r, er, e2;
+                            dRE.divmod(t, c, r);
+                            dE.divmod(r, er, e2);
+                            const int e = r0 + er;
+                            if (er < nr) s_S[t] = e == e2 ? blockv(c, e, e) : (blockv(c, e, e2) + blockv(c, e2, e)) * 0.5f;
+                        }
+                        __syncthreads();
+                        if (r0 == 0) stamp(xa.dbg, 18);
+                        mlp_chain<1, 1, 1>(b0.mh, wp, s_S, R * E, s_S, b0.mh.in, nr * E, [](int r) { return r; },
+                                           [&](int r, int o, float v) {
+                                               int er, e2;
+                                               dE.divmod(r, er, e2);
+                                               const int e = r0 + er;
+                                               const float fh = s_flags[edge_i(e)] * s_flags[edge_j(e)] * s_flags[edge_i(e2)] * s_flags[edge_j(e2)];
+                                               const float tv = tanh_f(v * fh);
+                                               s_row[(o * R + er) * E + e2] = tv + tv;
+                                               if (e == e2) s_hd[(p.a_cinit + o) * E + e] = tv + tv;
+                                           });
+                    } else
+                    for (int t = tid; t < nr * E; t += nth) {
+                        int er, e2;
+                        dE.divmod(t, er, e2);
+                        const int e = r0 + er;
+                        float out[CCSD_FW];
+                        layer0(e, e2, out);
+#pragma unroll
+                        for (int o = 0; o < CCSD_FW; ++o)
+                            if (o < b0.cout) {
+                                s_row[(o * R + er) * E + e2] = out[o];
+                                if (e == e2) s_hd[(p.a_cinit + o) * E + e] = out[o];
+                            }
+                    }
+                    __syncthreads();
+                    if (r0 == 0) stamp(xa.dbg, 19);
+                    for (int t = tid; t < nr * b1.cin * hd1; t += nth) {
+                        int er, r, c, h;
+                        dch1.divmod(t, er, r);
+                        c = r / hd1; h = r - c * hd1;
+                        const float* blk = w + b1.blk_base + c * b1.blk_stride;
+                        const float* w1t = wp + b1.w1t + c * E * hd1 + h;      // W1^T [E][hid]: lanes along h read consecutive floats
+                        const float* row = s_row + (c * R + er) * E;
+                        const float bias = blk[hd1 * E + h];
+                        s_g2[t] = elu1(dot_gl<true>(w1t, hd1, row, E) + bias);
+                    }
+                    __syncthreads();
+                    for (int t = tid; t < nr * b1.cin; t += nth) {
+                        const int er = t / b1.cin, c = t - er * b1.cin, e = r0 + er;
+                        const float* blk = w + b1.blk_base + c * b1.blk_stride;
+                        const float* w2 = blk + hd1 * E + hd1 + e * hd1;
+                        const float* g = s_g2 + t * hd1;
+                        const float bias = blk[hd1 * E + hd1 + E * hd1 + e];
+                        s_d2[c * E + e] = tanh_f(dot_gl<false>(w2, 1, g, hd1) + bias);
+                    }
+                    __syncthreads();
+                    if (r0 == 0) stamp(xa.dbg, 20);
+                }
+                stamp(xa.dbg, 21);
+                for (int e = tid; e < E; e += nth) {
+                    float in[CCSD_FW], out[CCSD_FW];
+#pragma unroll
+                    for (int c = 0; c < CCSD_FW; ++c) in[c] = c < b1.cin ? s_d2[(c < b1.cin ? c : 0) * E + e] : 0.f;
+                    small_mlp_ldsw<CCSD_FW>(s_mh + CCSD_MAXLIN * HBS, b1.mh.n, in, out);
+                    const float fh = s_flags[edge_i(e)] * s_flags[edge_j(e)];
+#pragma unroll
+                    for (int o = 0; o < CCSD_FW; ++o)
+                        if (o < b1.cout) { const float tv = tanh_f(out[o] * fh * fh); s_hd[(p.a_cinit + b0.cout + o) * E + e] = tv + tv; }
+                }
+                __syncthreads();
+            }
+            // hodgedual_to_adj (cc_utils.py:1552-1588): scatter the diagonals behind the graph channels
+            for (int t = tid; t < p.a_nch_hodge * E; t += nth) {
+                int c, e;
+                dE.divmod(t, c, e);
+                const int i = edge_i(e), j = edge_j(e);
+                const float v = s_hd[t];
+                s_chan[(p.a_nch_graph + c) * NN + i * N + j] = v;
+                s_chan[(p.a_nch_graph + c) * NN + j * N + i] = v;
+            }
+            __syncthreads();
+        }
+
+        stamp(xa.dbg, 13);
+        // ---- final MLP over every (i,j) on [graph channels | hodge channels]  (ScoreNetwork_A_CC.py:318-331)
+        const MlpD& m = p.a_fin;
+        const float* wf = w;
+        const int fc = m.chain ? NN : p.pch, ldf = p.ldp;
+        float* f0 = s_R;
+        float* f1 = s_R + m.hid * ldf;
+        for (int p0 = 0; p0 < NN; p0 += fc) {
+            const int rows = (NN - p0) < fc ? (NN - p0) : fc;
+            if (m.chain) {
+                // symmetric input channels, masked diagonal: the E unordered pairs suffice (see the edge MLP above)
+                auto epf = [&](int e, int f, float v) { (void)f; const int i = edge_i(e), j = edge_j(e); f0[i * N + j] = v; f0[j * N + i] = v; };
+                if (m.chain == 3) mlp_chain<2, 4, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
+                else if (m.chain == 4) mlp_chain<3, 5, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
+                else if (m.chain == 5) mlp_chain<3, 6, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
+                else mlp_chain<4, 7, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
+                stamp(xa.dbg, 11);
+            } else {
+                block_linear<1>(f0, ldf, s_chan + p0, NN, s_chan + p0, m.in, wf + m.w[0], wf + m.b[0], m.in, m.hid, rows);
+                __syncthreads();
+                block_linear<1>(f1, ldf, f0, ldf, f0, m.hid, wf + m.w[1], wf + m.b[1], m.hid, m.hid, rows);
+                __syncthreads();
+                block_linear<0>(f0, ldf, f1, ldf, f1, m.hid, wf + m.w[2], wf + m.b[2], m.hid, 1, rows);
+            }
+            __syncthreads();
+            stamp(xa.dbg, 15);
+            for (int r = tid; r < rows; r += nth) {
+                const int ij = p0 + r;
+                int i, j;
+                dN.divmod(ij, i, j);
+                const float fm = s_flags[i] * s_flags[j];
+                const float net = (i == j) ? 0.f : f0[r] * fm;         // * no-diag mask, then mask_adjs
+                const size_t gi = (size_t)b * NN + ij;
+                if (xa.mode == MODE_SCORE) {
+                    xa.out_a[gi] = xa.ss_a * net;
+                } else {
+                    const float z = raw_noise_adj(na, b, i, j, N) * fm;   // gen_noise(sym=True), graph_utils.py:173-175
+                    if (xa.mode == MODE_NORMS) {
+                        xa.out_a[gi] = net;
+                        na_net = fmaf(net, net, na_net);
+                        na_z = fmaf(z, z, na_z);
+                    } else {
+                        const float mean = fmaf(xa.pa_a, s_adj[ij], xa.pb_a * net);
+                        if (xa.mean_a) xa.mean_a[gi] = mean;
+                        xa.out_a[gi] = fmaf(xa.pc_a, z, mean);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    stamp(xa.dbg, 14);
+    if (xa.mode == MODE_NORMS) {
+        __syncthreads();
+        const float t0 = block_sum(nx_net, s_red), t1 = block_sum(na_net, s_red);
+        const float t2 = block_sum(nx_z, s_red), t3 = block_sum(na_z, s_red);
+        if (tid == 0) {
+            float* o = xa.norm2 + (size_t)b * 4;
+            if (xa.do_x) { o[0] = t0; o[2] = t2; }
+            if (xa.do_a) { o[1] = t1; o[3] = t3; }
+        }
+    }
+}

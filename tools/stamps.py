@@ -48,4 +48,5 @@ if os.environ.get("STAMPS_CKPT", "").endswith("Base_CC"):
     hb = [12, 16, 17, 18, 19, 20, 21, 13]
     print("baseline hodge: stage+hidden0, (to chunk 0), fill S, mlp_hodge chain, hidden rows + diag of layer 1, remaining chunks, head+scatter:",
           [int(np.median(x[:, hb[i + 1]] - x[:, hb[i]])) for i in range(7)], " rows per chunk", "see plan")
-print("layer 1, first channel group: dinv, gcn tiles, attention pairs + multi_channel accumulate:", [int(np.median(x[:, b] - x[:, a])) for a, b in ((5, 22), (22, 23), (23, 24))])
+print("layer 1, first channel group: bias fill + dinv, gcn tiles (+barrier), attention pairs (wave 0), multi_channel accumulate (+barrier):", [int(np.median(x[:, b] - x[:, a])) for a, b in ((5, 22), (22, 23), (23, 25), (25, 24))])
+print("layer 1 rest: edge MLP chain + node linear (+barrier), symmetrise/tanh:", [int(np.median(x[:, b] - x[:, a])) for a, b in ((24, 6), (6, 7))])
