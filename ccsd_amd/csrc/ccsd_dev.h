@@ -140,6 +140,19 @@ CCSD_DEV void raw_noise_r4(const NoiseArgs& na, int b, int eg, int k, int E, int
     }
 }
 
+// Sum of the values two ADJACENT work items (t even, t + 1) hold, valid in both on the GPU: the partner is the neighbouring
+// lane.  In the host emulation (one "thread" walks all items in order) the partner is the previous iteration: `stash` carries
+// its value, and only the odd item sees the sum -- callers store from the odd item.
+CCSD_DEV float pair_sum(float v, int t, float& stash) {
+#ifdef CCSD_EMU
+    if (!(t & 1)) { stash = v; return v; }
+    return stash + v;
+#else
+    (void)t; (void)stash;
+    return v + __shfl_xor(v, 1, 64);
+#endif
+}
+
 // block-wide sum; result valid in every thread.  `red` = 64 floats of LDS.
 CCSD_DEV float block_sum(float v, float* red) {
 #ifdef CCSD_EMU
@@ -526,7 +539,7 @@ CCSD_DEV void gcn_tile(const float* xT, int ldn, int fin, int N, const float* A,
 #pragma unroll
     for (int tn = 0; tn < NTN; ++tn) xw[tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int ks = (fin + 3) >> 2;
-    if (NTN == 1 || !BATCH) {       // small graphs (fin of a few k-steps): the plain loop is as fast and lighter on registers
+    if (!BATCH) {                    // plain loop (kept for reference / diagnostics)
         for (int s0 = 0; s0 < ks; ++s0) {
             const int k = 4 * s0 + kq, kc = k < fin ? k : fin - 1;
             const float bw = wf(kc, colc);

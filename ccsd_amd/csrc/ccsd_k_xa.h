@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
             float* dst = s_xcat + (F + l * H) * ldn;
             // tanh(DenseGCNConv(x, adj)) (ScoreNetwork_X.py:118-121): 16-column tiles over the waves
             for (int ct = wave_id; ct < (H + 15) >> 4; ct += n_waves)
-                gcn_tile_n<GCH>(src, ldn, fin, N, s_adj, s_dinv, 16 * ct, H,
+                gcn_tile_n<true>(src, ldn, fin, N, s_adj, s_dinv, 16 * ct, H,
                            [&](int k, int col) { return W[k * H + col]; }, [&](int col) { return B[col]; },
                            [&](int i, int col, float v) { dst[col * ldn + i] = tanh_f(v); });
             __syncthreads();

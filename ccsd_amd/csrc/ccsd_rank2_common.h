@@ -93,7 +93,8 @@ CCSD_DEV float fnet_element(const PlanD& p, const float* __restrict__ w, float f
 //   phase 3  coalesced LDS -> HBM copy of the result
 // Same arithmetic as k_gemm_h / k_gemm_p / k_hf_score (those remain the general path).
 // ---------------------------------------------------------------------------------------------
-template <class LA, class LB, class EP>
+// D = k-steps whose operand loads are issued together, ahead of the MFMAs that consume them (one L2 / LDS round trip per D steps)
+template <int D = 4, class LA, class LB, class EP>
 CCSD_DEV void wave_tile(int m0, int n0, int ks, LA la, LB lb, EP ep) {
 #ifdef CCSD_EMU
     for (int i = 0; i < 16; ++i)
@@ -106,15 +107,18 @@ CCSD_DEV void wave_tile(int m0, int n0, int ks, LA la, LB lb, EP ep) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    int s = 0;
-    for (; s + 4 <= ks; s += 4) {          // issue the 8 operand loads of four k-steps before the MFMAs consume them
-        float a[4], bv[4];
+    for (int s = 0; s < ks; s += D) {
+        float a[D], bv[D];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { a[u] = la(m0 + l15, 4 * (s + u) + kq); bv[u] = lb(4 * (s + u) + kq, n0 + l15); }
+        for (int u = 0; u < D; ++u) {
+            const int sc = s + u < ks ? s + u : ks - 1;       // tail: a harmless reload of the last step
+            a[u] = la(m0 + l15, 4 * sc + kq);
+            bv[u] = lb(4 * sc + kq, n0 + l15);
+        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bv[u], acc, 0, 0, 0);
+        for (int u = 0; u < D; ++u)
+            if (s + u < ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bv[u], acc, 0, 0, 0);
     }
-    for (; s < ks; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(la(m0 + l15, 4 * s + kq), lb(4 * s + kq, n0 + l15), acc, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) ep(m0 + 4 * kq + r, n0 + l15, acc[r]);
 #endif
