@@ -140,6 +140,29 @@ CCSD_DEV void raw_noise_r4(const NoiseArgs& na, int b, int eg, int k, int E, int
     }
 }
 
+// sum over head chunks of tanh(q_h . k_h * scale): the attention logits of one direction of one pair (attention.py:111-129,
+// hodge_attention.py:108-124).  The chunk width DS = attn_dim // num_heads is a compile-time constant for the common widths
+// (inner loop unrolled: no per-term loop overhead), any other width takes the counted loop.
+template <int DS>
+CCSD_DEV float attn_logit_sum(const float* q, const float* k, int nchunk, int dsplit, float scale) {
+    float s = 0.f;
+    for (int h = 0; h < nchunk; ++h) {
+        float d = 0.f;
+        if (DS > 0) {
+#pragma unroll
+            for (int u = 0; u < DS; ++u) d = fmaf(q[h * DS + u], k[h * DS + u], d);
+        } else {
+            for (int u = 0; u < dsplit; ++u) d = fmaf(q[h * dsplit + u], k[h * dsplit + u], d);
+        }
+        s += tanh_f(d * scale);
+    }
+    return s;
+}
+CCSD_DEV float attn_logits(const float* q, const float* k, int nchunk, int dsplit, float scale) {
+    if (dsplit == 2) return attn_logit_sum<2>(q, k, nchunk, dsplit, scale);      // qm9_CC (10 // 4), the hodge layers (4 // 2)
+    return attn_logit_sum<0>(q, k, nchunk, dsplit, scale);
+}
+
 // Sum of the values two ADJACENT work items (t even, t + 1) hold, valid in both on the GPU: the partner is the neighbouring
 // lane.  In the host emulation (one "thread" walks all items in order) the partner is the previous iteration: `stash` carries
 // its value, and only the odd item sees the sum -- callers store from the odd item.
@@ -612,6 +635,105 @@ CCSD_DEV void gcn_tile_n(const float* xT, int ldn, int fin, int N, const float* 
     else if (N <= 32) gcn_tile<2, BATCH>(xT, ldn, fin, N, A, dinv, col0, ncols, wf, bf, out);
     else if (N <= 48) gcn_tile<3, BATCH>(xT, ldn, fin, N, A, dinv, col0, ncols, wf, bf, out);
     else gcn_tile<4, BATCH>(xT, ldn, fin, N, A, dinv, col0, ncols, wf, bf, out);
+}
+
+// gcn_tile_multi: NC adjacent 16-column tiles of a DenseGCNConv for all nodes of one graph by one wave -- the same two
+// products as gcn_tile, with everything that does not depend on the column tile done once: the x fragments of the first
+// product and the masked, unit-diagonal adjacency fragments of the second are shared by the NC accumulators.  Wp: packed
+// weights [fin][cp] followed by [cp] biases (AttnLayerD::qkvp), zero padded: no column bounds logic on the loads.
+template <int NTN, int NC, class OUT>
+CCSD_DEV void gcn_tile_multi(const float* xT, int ldn, int fin, int N, const float* A, const float* dinv, int col0, int ncols,
+                             const float* __restrict__ Wp, int cp, OUT out) {
+#ifdef CCSD_EMU
+    for (int cc = 0; cc < 16 * NC; ++cc) {
+        const int col = col0 + cc;
+        if (col >= ncols) break;
+        float xw[16 * NTN];
+        for (int j = 0; j < N; ++j) {
+            float acc = 0.f;
+            for (int k = 0; k < fin; ++k) acc = fmaf(xT[k * ldn + j], Wp[k * cp + col], acc);
+            xw[j] = acc * dinv[j];
+        }
+        for (int i = 0; i < N; ++i) {
+            float acc = 0.f;
+            for (int j = 0; j < N; ++j) acc = fmaf((i == j) ? 1.f : A[i * N + j], xw[j], acc);
+            out(i, col, fmaf(acc, dinv[i], Wp[fin * cp + col]));
+        }
+    }
+#else
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));          // keeps each instantiation's index arithmetic inside it (see mlp_chain_tile)
+    const int l15 = lane & 15, kq = lane >> 4;
+    const float* wcol = Wp + col0 + l15;    // column col0 + 16 c + l15 of the packed block (always inside the padding)
+    f32x4 xw[NC][NTN];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int tn = 0; tn < NTN; ++tn) xw[c][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int ks = (fin + 3) >> 2;
+    for (int s00 = 0; s00 < ks; s00 += 4) {  // weights of four k-steps fetched together: one L2 round trip per four steps
+        float bw[4][NC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = 4 * (s00 + u) + kq, kc = k < fin ? k : fin - 1;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) bw[u][c] = wcol[kc * cp + 16 * c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (s00 + u < ks) {
+                const int k = 4 * (s00 + u) + kq, kc = k < fin ? k : fin - 1;
+#pragma unroll
+                for (int tn = 0; tn < NTN; ++tn) {
+                    const int j = 16 * tn + l15;
+                    const float a0 = xT[kc * ldn + (j < N ? j : N - 1)];
+                    const float av = (j < N && k < fin) ? a0 : 0.f;      // rows beyond N / k beyond fin contribute nothing
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) xw[c][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[u][c], xw[c][tn], 0, 0, 0);
+                }
+            }
+    }
+#pragma unroll
+    for (int tn = 0; tn < NTN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * tn + 4 * kq + r;
+            const float dj = j < N ? dinv[j < N ? j : N - 1] : 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) xw[c][tn][r] *= dj;
+        }
+    float bb[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) bb[c] = wcol[fin * cp + 16 * c];
+#pragma unroll
+    for (int ti = 0; ti < NTN; ++ti) {
+        const int i = 16 * ti + l15, ic = i < N ? i : N - 1;
+        f32x4 acc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tn = 0; tn < NTN; ++tn)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = 16 * tn + 4 * kq + jj, jc = j < N ? j : N - 1;
+                const float a0 = A[ic * N + jc];
+                const float av = (i < N && j < N) ? (i == j ? 1.f : a0) : 0.f;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xw[c][tn][jj], acc[c], 0, 0, 0);
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int io = 16 * ti + 4 * kq + r;
+            if (io < N) {
+                const float di = dinv[io];
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (col0 + 16 * c + l15 < ncols) out(io, col0 + 16 * c + l15, fmaf(acc[c][r], di, bb[c]));
+            }
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -307,12 +307,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                         float sacc = 0.f;
                         if (c < h0.cin) {
                             const float* q = s_hq + (c * E + e) * qw0;
-                            for (int hh = 0; hh < h0.nchunk; ++hh) {
-                                float d = 0.f;
-                                for (int u = 0; u < h0.dsplit; ++u) d = fmaf(q[hh * h0.dsplit + u], q[h0.adim + hh * h0.dsplit + u], d);
-                                sacc += tanh_f(d * rks);
-                            }
-                            sacc *= 1.0f / (float)h0.nchunk;
+                            sacc = attn_logits(q, q + h0.adim, h0.nchunk, h0.dsplit, rks) * (1.0f / (float)h0.nchunk);
                         }
                         in[c] = sacc;
                     }
@@ -360,17 +355,8 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                         if (c < h0.cin) {
                             const float* q1 = s_hq + (c * E + e) * qw0;
                             const float* q2 = s_hq + (c * E + e2) * qw0;
-                            float s1 = 0.f, s2 = 0.f;
-                            for (int hh = 0; hh < h0.nchunk; ++hh) {
-                                float d1 = 0.f, d2 = 0.f;
-                                for (int u = 0; u < h0.dsplit; ++u) {
-                                    const int oq = hh * h0.dsplit + u, ok = h0.adim + oq;
-                                    d1 = fmaf(q1[oq], q2[ok], d1);
-                                    d2 = fmaf(q2[oq], q1[ok], d2);
-                                }
-                                s1 += tanh_f(d1 * rks);
-                                s2 += tanh_f(d2 * rks);
-                            }
+                            const float s1 = attn_logits(q1, q2 + h0.adim, h0.nchunk, h0.dsplit, rks);
+                            const float s2 = attn_logits(q2, q1 + h0.adim, h0.nchunk, h0.dsplit, rks);
                             v = (s1 * rnc0 + s2 * rnc0) * 0.5f;
                         }
                         in[c] = v;
@@ -466,12 +452,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                         float sacc = 0.f;
                         if (c < h1.cin) {
                             const float* q = s_hq + (c * E + e) * qw1;
-                            for (int hh = 0; hh < h1.nchunk; ++hh) {
-                                float d = 0.f;
-                                for (int u = 0; u < h1.dsplit; ++u) d = fmaf(q[hh * h1.dsplit + u], q[h1.adim + hh * h1.dsplit + u], d);
-                                sacc += tanh_f(d * rks);
-                            }
-                            sacc *= 1.0f / (float)h1.nchunk;
+                            sacc = attn_logits(q, q + h1.adim, h1.nchunk, h1.dsplit, rks) * (1.0f / (float)h1.nchunk);
                         }
                         in[c] = sacc;
                     }

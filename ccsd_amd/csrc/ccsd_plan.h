@@ -41,6 +41,9 @@ struct AttnLayerD {
     int conv_mlp;                // conv="MLP": Q / K blocks are W1[2ad][fin] b1[2ad] W2[ad][2ad] b2[ad] (attention.py:168-178)
     int w_lo, w_hi;              // blob range of this layer's weights (attention blocks, mlp, multi_channel)
     MlpD mlp, mc;
+    // packed buffer (conv = "GCN"): per input channel [fin][cp] weights + [cp] biases with the Q | K | V columns side by side,
+    // zero padded to cp = pad16(2 adim + fout) -- the B operand / bias of gcn_tile_multi without column-part arithmetic
+    int qkvp, cp;
 };
 struct HodgeLayerD {
     int cin, cout, adim, dsplit, nchunk, wc;   // wc = cin*2*adim columns of Wcat
@@ -179,6 +182,23 @@ static inline void ccsd_pack_mlp(const MlpD& m, const float* w, float* packed) {
     }
 }
 
+// Q | K | V weights of a GCN-conv AttentionLayer side by side, zero padded (AttnLayerD::qkvp)
+static inline void ccsd_pack_qkv(const AttnLayerD& a, const float* w, float* packed) {
+    if (a.conv_mlp) return;
+    const int ad = a.adim, fo = a.fout, fi = a.fin, cp = a.cp;
+    for (int c = 0; c < a.cin; ++c) {
+        const float* blk = w + a.attn_base + (size_t)c * a.attn_stride;      // Wq[fi][ad] bq[ad] Wk[fi][ad] bk[ad] Wv[fi][fo] bv[fo]
+        float* dst = packed + a.qkvp + (size_t)c * (fi * cp + cp);
+        for (int part = 0; part < 3; ++part) {
+            const int ow = part == 2 ? fo : ad, c0 = part * ad;
+            const float* wp_ = blk + part * (fi * ad + ad);
+            for (int k = 0; k < fi; ++k)
+                for (int o = 0; o < ow; ++o) dst[k * cp + c0 + o] = wp_[k * ow + o];
+            for (int o = 0; o < ow; ++o) dst[fi * cp + c0 + o] = wp_[fi * ow + o];
+        }
+    }
+}
+
 static inline int round_ld(int rows) {  // node-row stride of the feature-major LDS arrays: multiple of 8, never a multiple of 32
     int r = (rows + 7) / 8 * 8;          // (== 16 mod 32 is conflict-free for the MFMA A-fragment reads, 8 / 24 mod 32 two-way)
     if (r % 32 == 0) r += 8;
@@ -217,6 +237,9 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
                         a.fin * a.fout + a.fout;
         a.attn_base = pb.take((int64_t)a.cin * a.attn_stride);
         a.w_lo = a.attn_base;
+        a.cp = pad16(2 * a.adim + a.fout);
+        a.qkvp = pb.pcur;
+        if (!a.conv_mlp) pb.pcur += a.cin * (a.fin * a.cp + a.cp);
         const int hid = 2 * (a.cin > a.cout ? a.cin : a.cout);
         a.mlp = pb.mlp(num_linears, 2 * a.cin, hid, a.cout);
         pb.chainify(a.mlp, CCSD_CHAIN_EDGE);
