@@ -315,7 +315,7 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
         int ldh = Ep4;                                                     // 16-byte aligned rows: phase 2 re-reads H's fragments per column tile as ds_read_b128
         const size_t fl = (size_t)E * ldk + (size_t)E * ldh + 64 * 2 + (size_t)p.a_cinit * E + 3 * N * N + 64 + (Kp4 + 3) / 4 + 4;
         const bool wc_ok = fnet_width(p) <= CCSD_FW;        // the fused kernel's per-element MLPs are padded to <= 16
-        if (fl * 4 + 64 <= 160 * 1024 && wc_ok && r2_kernel(pl) != nullptr) {
+        if (fl * 4 + 64 <= 160 * 1024 && wc_ok && r2_kernel(pl) != nullptr && p.f_cnum <= 2) {   // more Hodge powers: tiled kernels
             pl->fused_r2 = 1; pl->r2_ldk = ldk; pl->r2_ldh = ldh; pl->r2_lds = fl * 4;
         }
     }
@@ -345,7 +345,7 @@ static Workspace carve_ws(const ccsd_plan* pl, int B, void* base) {
     auto take = [&](size_t nbytes) { size_t r = o; o += (nbytes + 255) / 256 * 256; return base ? (char*)base + r : (char*)nullptr; };
     w.offbits = (unsigned long long*)take((size_t)B * 8);
     const size_t E = p.E, K = p.K;
-    w.H = (float*)take(p.is_cc ? (size_t)B * E * E * 4 : 0);
+    w.H = (float*)take(p.is_cc ? (size_t)B * E * E * 4 * (p.f_cnum > 2 ? p.f_cnum - 1 : 1) : 0);   // H, H^2, ... (cnum > 2: one slab per power)
     w.P0 = (float*)take(p.h_L > 0 ? (size_t)B * E * p.hl[0].wc * 4 : 0);
     w.P1 = (float*)take(p.h_L > 1 ? (size_t)B * E * p.hl[1].wc * 4 : 0);
     w.acoef = (float*)take(p.h_L > 1 ? (size_t)B * p.a_cinit * E * 4 : 0);
@@ -399,6 +399,13 @@ static int launch_h(const ccsd_plan* pl, int B, const float* rank2, Workspace& w
     CCSD_LAUNCH(k_gemm_h, g, dim3(CCSD_NTHREADS), 0, stream, rank2, w.H, p.E, p.K, p.f_hmask);
     prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_H, stream);
     LAUNCH_CHECK();
+    for (int j = 2; j < p.f_cnum; ++j) {       // H^j = H^(j-1) . H  (pow_tensor_cc, cc_utils.py:972-977)
+        const size_t slab = (size_t)B * p.E * p.E;
+        const int nt = (p.E + 15) / 16, per = CCSD_NTHREADS >= 64 ? CCSD_NTHREADS / 64 : 1;
+        CCSD_LAUNCH(k_gemm_pow, dim3((nt * nt + per - 1) / per, 1, B), dim3(CCSD_NTHREADS), 0, stream,
+                    (const float*)(w.H + (size_t)(j - 2) * slab), (const float*)w.H, w.H + (size_t)(j - 1) * slab, p.E);
+        LAUNCH_CHECK();
+    }
     return CCSD_OK;
 }
 // hodge projections for ScoreNetworkA_CC from (adj, rank2)
@@ -476,10 +483,15 @@ static int launch_hf(const ccsd_plan* pl, int B, const float* rank2, RankEpi& ep
 #define HF_ARGS (const PlanD*)pl->d, (const float*)pl->w, rank2, (const float*)w.H, (const unsigned long long*)w.offbits, \
                 (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, ep, na
     const int fw = fnet_width(p);
-    if (p.f_affine) CCSD_LAUNCH((k_hf_score<true, 8>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS);
-    else if (fw <= 8) CCSD_LAUNCH((k_hf_score<false, 8>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS);
-    else if (fw <= CCSD_FW) CCSD_LAUNCH((k_hf_score<false, CCSD_FW>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS);
-    else CCSD_LAUNCH((k_hf_score<false, CCSD_FWMAX>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS);
+#define HF_GO(NP_) \
+    do { \
+        if (p.f_affine) CCSD_LAUNCH((k_hf_score<true, 8, NP_>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS); \
+        else if (fw <= 8) CCSD_LAUNCH((k_hf_score<false, 8, NP_>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS); \
+        else if (fw <= CCSD_FW) CCSD_LAUNCH((k_hf_score<false, CCSD_FW, NP_>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS); \
+        else CCSD_LAUNCH((k_hf_score<false, CCSD_FWMAX, NP_>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS); \
+    } while (0)
+    if (p.f_cnum <= 2) HF_GO(1); else HF_GO(CCSD_MAXCN - 1);
+#undef HF_GO
 #undef HF_ARGS
     prof_mark(const_cast<ccsd_plan*>(pl), KID_HF, stream);
     LAUNCH_CHECK();

@@ -808,4 +808,30 @@ CCSD_DEV void tile_foreach4(TileAcc& t, Fn f) {
         }
 #endif
 }
-
+// the same over NP accumulators that share their geometry: f(m_local, n_local, v[NP][4])
+template <int NP, class Fn>
+CCSD_DEV void tile_foreach4n(TileAcc* t, Fn f) {
+#ifdef CCSD_EMU
+    for (int i = 0; i < T_BM; i += 4)
+        for (int j = 0; j < T_BN; ++j) {
+            float v[NP][4];
+            for (int q = 0; q < NP; ++q)
+                for (int r = 0; r < 4; ++r) v[q][r] = t[q].a[i + r][j];
+            f(i, j, v);
+        }
+#else
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32, l15 = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[NP][4];
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[q][r] = t[q].a[i][j][r];
+            f(wm + 16 * i + 4 * kq, wn + 16 * j + l15, v);
+        }
+#endif
+}

@@ -416,7 +416,8 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
             if (e >= E) continue;
             const float f = sF[e * ldk + k];
             const float m = sFl[e] * fr;                         // flags_left * flags_right, cc_utils.py:590
-            const float net = fnet_element<AFFINE>(p, w, f, hf[r], m);
+            const float hf1[CCSD_MAXCN - 1] = {hf[r], 0.f, 0.f};      // (cnum > 2 takes the tiled kernels: ccsd_plan::fused_r2)
+            const float net = fnet_element<AFFINE>(p, w, f, hf1, m);
             const size_t gi = ((size_t)b * E + e) * K + k;
             if (ep.mode == MODE_SCORE) {
                 ep.out[gi] = ep.sscale * net;

@@ -251,6 +251,29 @@ __global__ __launch_bounds__(256) void k_gemm_p0(const float* __restrict__ rank2
 #endif
 
 // ---------------------------------------------------------------------------------------------
+// k_gemm_pow: next Hodge power  Hn = Hp . H1  per complex (pow_tensor_cc with cnum > 2, cc_utils.py:972-977: x_ = bmm(H, x_)
+// repeatedly, i.e. channel j = H^j F).  E x E x E per complex: one 16x16 output tile per wave.  grid (ceil(nt^2 / waves), 1, B)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gemm_pow(const float* __restrict__ Hp, const float* __restrict__ H1, float* __restrict__ Hn, int E) {
+    const int b = blockIdx.z, nt = (E + 15) >> 4;
+#ifdef CCSD_EMU
+    const int wave = 0, nw = 1;
+#else
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#endif
+    const float* A = Hp + (size_t)b * E * E;
+    const float* Bm = H1 + (size_t)b * E * E;
+    float* C = Hn + (size_t)b * E * E;
+    for (int tile = blockIdx.x * nw + wave; tile < nt * nt; tile += gridDim.x * nw) {
+        const int ti = tile / nt, tj = tile - ti * nt;
+        wave_tile<8>(16 * ti, 16 * tj, (E + 3) >> 2,
+                     [&](int r, int k) { const float v = A[(size_t)(r < E ? r : E - 1) * E + (k < E ? k : E - 1)]; return (r < E && k < E) ? v : 0.f; },
+                     [&](int k, int c) { const float v = Bm[(size_t)(k < E ? k : E - 1) * E + (c < E ? c : E - 1)]; return (k < E && c < E) ? v : 0.f; },
+                     [&](int r, int c, float acc) { if (r < E && c < E) C[(size_t)r * E + c] = acc; });
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_edgecoef: acoef[b][c][e] = (adj^(c+1))[i_e][j_e]      pow_tensor + adj_to_hodgedual,
 // graph_utils.py:285-292, cc_utils.py:1525-1536.  One workgroup per graph; LDS: 3*N*N floats.
 // ---------------------------------------------------------------------------------------------
@@ -285,7 +308,8 @@ __global__ void k_edgecoef(const float* __restrict__ adj, float* __restrict__ ac
 // element the channel MLP stack of ScoreNetwork_F.py:198-217 and one of three fused epilogues.
 // grid (ceil(K/64), ceil(E/64), B)
 // ---------------------------------------------------------------------------------------------
-template <bool AFFINE, int FW>
+// NP: Hodge powers the instantiation can hold (1: cnum <= 2, the common case -- one accumulator, no loop; CCSD_MAXCN - 1 otherwise)
+template <bool AFFINE, int FW, int NP>
 __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan, const float* __restrict__ w,
                                                   const float* __restrict__ rank2, const float* __restrict__ H,
                                                   const unsigned long long* __restrict__ offbits,
@@ -297,12 +321,20 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
     const int E = p.E, K = p.K;
     const int b = blockIdx.z, m0 = blockIdx.y * T_BM, n0 = blockIdx.x * T_BN;
     const float* Fb = rank2 + (size_t)b * E * K;
-    const float* Hb = H + (size_t)b * E * E;
-    TileAcc acc;
-    tile_zero(acc);
+    // one (H^j F) tile per Hodge power j = 1 .. cnum - 1 (pow_tensor_cc, cc_utils.py:961-979): the powers H^j (B, E, E) lie
+    // behind each other in the workspace (k_gemm_h, k_gemm_pow); the F slabs are re-read per power (cnum > 2 only)
+    const int npow = p.f_cnum - 1;
+    TileAcc accs[NP];
+#pragma unroll
+    for (int jp = 0; jp < NP; ++jp) tile_zero(accs[jp]);
+#pragma unroll
+    for (int jp = 0; jp < NP; ++jp) {
+    if (jp >= npow) break;
+    TileAcc& acc = accs[jp];
+    const float* Hb = H + ((size_t)jp * gridDim.z + b) * E * E;
 #ifdef CCSD_EMU
     static float As[T_BK * T_LD], Bs[T_BK * T_LD];
-    if (p.f_cnum == 2) {
+    {
         for (int k0 = 0; k0 < E; k0 += T_BK) {
             for (int idx = threadIdx.x; idx < T_BM * T_BK; idx += blockDim.x) {
                 const int r = idx / T_BK, kk = idx % T_BK, k = k0 + kk, row = m0 + r;
@@ -323,7 +355,7 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
     constexpr int BLD = 68;
     __shared__ __align__(16) float As[T_BM * H_LD];
     __shared__ __align__(16) float Bs[H_BK * BLD];
-    if (p.f_cnum == 2) {
+    {
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
         const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
@@ -386,9 +418,10 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
         }
     }
 #endif
+    }
     const unsigned long long off = offbits[b];
     float s_net = 0.f, s_z = 0.f;
-    tile_foreach4(acc, [&](int ml, int nl, const float* hf) {
+    tile_foreach4n<NP>(accs, [&](int ml, int nl, const float (*hfp)[4]) {
         const int k = n0 + nl, e0 = m0 + ml;
         if (k >= K || e0 >= E) return;
         const float fr = cell_on(off, cells, k);
@@ -401,7 +434,8 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
             const size_t gi = ((size_t)b * E + e) * K + k;
             const float f = Fb[(size_t)e * K + k];
             const float m = edge_on(off, edges, e) * fr;          // flags_left * flags_right, cc_utils.py:590
-            const float net = fnet_element<AFFINE, FW>(p, w, f, hf[s], m);
+            const float hf[CCSD_MAXCN - 1] = {hfp[0][s], NP > 1 ? hfp[NP > 1 ? 1 : 0][s] : 0.f, NP > 2 ? hfp[NP > 2 ? 2 : 0][s] : 0.f};
+            const float net = fnet_element<AFFINE, FW>(p, w, f, hf, m);
             const float zz = z[s] * m;                            // gen_noise_rank2, cc_utils.py:613-615
             if (ep.mode == MODE_SCORE) {
                 ep.out[gi] = ep.sscale * net;

@@ -10,6 +10,7 @@
 #define CCSD_MAXL 8       // attention layers / GCN depth
 #define CCSD_MAXHL 2      // hodge layers handled by the HIP path
 #define CCSD_MAXFL 4      // HodgeNetworkLayers in ScoreNetworkF
+#define CCSD_MAXCN 4      // channels [F, HF, H^2 F, H^3 F] of ScoreNetworkF's input (cnum, cc_utils.py:961-979)
 #define CCSD_SMALLW 8     // widest per-thread MLP in the hodge branch
 #define CCSD_FW 16        // widest per-thread MLP in ScoreNetworkF's general path (fused kernel; hodge baseline mlp_hodge)
 #define CCSD_FWMAX 32     // ... in the tiled k_hf_score path
@@ -102,6 +103,7 @@ struct PlanD {
     // ScoreNetworkX_GMH (x_gmh = 1): x_depth AttentionLayers gl[] on g_cinit adjacency powers, g_nch channels in all
     int x_gmh, g_cinit, g_nch;
     AttnLayerD gl[CCSD_MAXL];
+    float f_betas[CCSD_MAXCN];    // affine ScoreNetworkF with cnum > 2: coefficient of H^j F, j = 1 .. cnum - 1 (f_betas[1] == f_beta)
 };
 
 #ifndef CCSD_DEVICE_ONLY
@@ -343,7 +345,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     // ---- ScoreNetworkF
     if (c->is_cc) {
         if (c->f_num_layers < 1 || c->f_num_layers > CCSD_MAXFL) { pb.fail(CCSD_ERR_UNSUPPORTED, "f_num_layers out of range"); return 0; }
-        if (c->f_cnum < 1 || c->f_cnum > 2) { pb.fail(CCSD_ERR_UNSUPPORTED, "HIP path supports cnum in {1,2}"); return 0; }
+        if (c->f_cnum < 1 || c->f_cnum > CCSD_MAXCN) { pb.fail(CCSD_ERR_UNSUPPORTED, "HIP path supports cnum in 1..4"); return 0; }
         p->f_L = c->f_num_layers; p->f_cnum = c->f_cnum; p->f_hmask = c->f_use_hodge_mask;
         int fch = c->f_cnum;
         for (int l = 0; l < p->f_L; ++l) {
@@ -546,24 +548,26 @@ static inline void ccsd_pack_fnet_blocks(const PlanD* p, const float* w, float* 
 // the fold is exact in real arithmetic.
 static inline void ccsd_fold_fnet(PlanD* p, const float* w) {
     if (!p->is_cc || !p->f_affine) return;
-    const int fd = p->f_fdim;
-    std::vector<double> A(fd * 3, 0.0);  // channel j = A[j][0]*F + A[j][1]*HF + A[j][2]
-    A[0 * 3 + 0] = 1.0;
-    if (p->f_cnum == 2) A[1 * 3 + 1] = 1.0;
-    int ci0 = 0, co0 = p->f_cnum;
+    const int fd = p->f_fdim, cn = p->f_cnum, nb = cn + 1;
+    std::vector<double> A((size_t)fd * nb, 0.0);  // channel j = sum_i A[j][i] * H^i F  (i < cnum)  + A[j][cnum]
+    for (int j = 0; j < cn; ++j) A[(size_t)j * nb + j] = 1.0;
+    int ci0 = 0, co0 = cn;
     for (int l = 0; l < p->f_L; ++l) {
         const MlpD& m = p->fl[l];
         for (int oo = 0; oo < m.out; ++oo) {
-            double acc[3] = {0, 0, (double)w[m.b[0] + oo]};
+            std::vector<double> acc(nb, 0.0);
+            acc[cn] = (double)w[m.b[0] + oo];
             for (int i = 0; i < m.in; ++i)
-                for (int t = 0; t < 3; ++t) acc[t] += (double)w[m.w[0] + oo * m.in + i] * A[(ci0 + i) * 3 + t];
-            for (int t = 0; t < 3; ++t) A[(co0 + oo) * 3 + t] = acc[t];
+                for (int t = 0; t < nb; ++t) acc[t] += (double)w[m.w[0] + oo * m.in + i] * A[(size_t)(ci0 + i) * nb + t];
+            for (int t = 0; t < nb; ++t) A[(size_t)(co0 + oo) * nb + t] = acc[t];
         }
         ci0 = co0; co0 += m.out;
     }
-    double r[3] = {0, 0, (double)w[p->f_fin.b[0]]};
+    std::vector<double> r(nb, 0.0);
+    r[cn] = (double)w[p->f_fin.b[0]];
     for (int j = 0; j < fd; ++j)
-        for (int t = 0; t < 3; ++t) r[t] += (double)w[p->f_fin.w[0] + j] * A[j * 3 + t];
-    p->f_alpha = (float)r[0]; p->f_beta = (float)r[1]; p->f_gamma = (float)r[2];
+        for (int t = 0; t < nb; ++t) r[t] += (double)w[p->f_fin.w[0] + j] * A[(size_t)j * nb + t];
+    p->f_alpha = (float)r[0]; p->f_beta = cn > 1 ? (float)r[1] : 0.f; p->f_gamma = (float)r[cn];
+    for (int j = 0; j < CCSD_MAXCN; ++j) p->f_betas[j] = (j >= 1 && j < cn) ? (float)r[j] : 0.f;
 }
 #endif  // CCSD_DEVICE_ONLY

@@ -23,17 +23,24 @@ struct RankEpi {
     float* part;             // NORMS: [B][ntiles][2] partial sums of net^2 and z^2
 };
 
-// FW: width the per-element MLPs are padded to (8 when every layer of the network fits, else CCSD_FW = 16)
+// FW: width the per-element MLPs are padded to (8 when every layer of the network fits, else CCSD_FW = 16).
+// hf[j] = (H^(j+1) F) at this element, j < cnum - 1 (pow_tensor_cc, cc_utils.py:961-979).
 template <bool AFFINE, int FW = CCSD_FW>
-CCSD_DEV float fnet_element(const PlanD& p, const float* __restrict__ w, float f, float hf, float m) {
-    if (AFFINE) return m * fmaf(p.f_alpha, f, fmaf(p.f_beta, hf, p.f_gamma));
+CCSD_DEV float fnet_element(const PlanD& p, const float* __restrict__ w, float f, const float* hf, float m) {
+    if (AFFINE) {
+        float t = fmaf(p.f_alpha, f, p.f_gamma);
+#pragma unroll
+        for (int j = 1; j < CCSD_MAXCN; ++j)
+            if (j < p.f_cnum) t = fmaf(p.f_betas[j], hf[j - 1], t);
+        return m * t;
+    }
     if (p.f_blk >= 0) {
         // every layer <= 8 wide, single-Linear head: zero-padded blocks behind the weight blob (ccsd_pack_fnet_blocks), read
         // with wide scalar loads; each layer's output stays in its own registers and the head is accumulated segment by
         // segment in concat order (no dynamic register indexing, padded lanes contribute exact zeros)
         const float* fb = w + p.f_blk;
         const float* hd = fb + CCSD_FBLK_HEAD;
-        float prev[8] = {f, p.f_cnum == 2 ? hf : 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float prev[8] = {f, p.f_cnum > 1 ? hf[0] : 0.f, p.f_cnum > 2 ? hf[1] : 0.f, p.f_cnum > 3 ? hf[2] : 0.f, 0.f, 0.f, 0.f, 0.f};
         float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc = fmaf(prev[i], hd[i], acc);
@@ -55,7 +62,9 @@ CCSD_DEV float fnet_element(const PlanD& p, const float* __restrict__ w, float f
 #pragma unroll
     for (int i = 0; i < FW; ++i) ch[i] = 0.f;
     ch[0] = f;
-    if (p.f_cnum == 2) ch[1] = hf;
+#pragma unroll
+    for (int j = 1; j < CCSD_MAXCN; ++j)
+        if (j < p.f_cnum) ch[j] = hf[j - 1];
     int ci0 = 0, co0 = p.f_cnum;
     for (int l = 0; l < p.f_L; ++l) {
         float in[FW], out[FW];

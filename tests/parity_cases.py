@@ -620,3 +620,21 @@ def case_zinc5b(lib, device):
     assert safe.double().mean().item() > 0.99
     q = PCEngine(None, None, None, None, None, None, N=N, F=1, is_cc=False, device=device, lib=lib).quantize(res[1], -1.0).cpu()
     assert torch.equal(q[safe], torch.from_numpy(g["k3/quantize_mol_adj"])[safe])
+
+
+def case_kat_cnum(lib, device):
+    """ScoreNetworkF with three / four Hodge powers (cnum = 3, 4) against the reference constructor's outputs: affine fold with
+    several beta_j, the per-element MLP path with a wider input, with and without the Hodge mask; E = 10 and E = 66.  More than
+    two powers always take the tiled kernels (k_gemm_h -> k_gemm_pow -> k_hf_score)."""
+    g = load_golden("kat_cnum.npz")
+    meta = json.loads(str(g["meta"]))
+    for tag, params in meta.items():
+        flags, rank2 = (torch.from_numpy(g[f"{tag}/{k}"]).to(device) for k in ("flags", "rank2"))
+        sd = {k[len(tag) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}/w/")}
+        N = params["max_node_num"]
+        B = flags.shape[0]
+        eng = PCEngine(None, None, None, None, params, sd, N=N, F=2, is_cc=True, d_min=params["d_min"], d_max=params["d_max"],
+                       device=device, lib=lib)
+        x = torch.zeros(B, N, 2, device=device)
+        adj = torch.zeros(B, N, N, device=device)
+        assert_close(eng.score(2, x, adj, rank2, flags), g[f"{tag}/out"], f"kat cnum {tag}")

@@ -87,6 +87,10 @@ def test_fp64_arbiter_qm9(lib):
         assert e_ref < 5e-5 and e_mine < 5e-5, (p, e_ref, e_mine)
 
 
+def test_kat_cnum_more_hodge_powers(lib):
+    pc.case_kat_cnum(lib, DEV)
+
+
 def test_zinc5b_substitute(lib):
     pc.case_zinc5b(lib, DEV)
 

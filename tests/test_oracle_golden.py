@@ -229,6 +229,17 @@ def test_g5_pc_sampler_identical_seed(gname, ckpt, cases):
             assert np.array_equal(O.quantize(res[2]).numpy().astype(np.uint8), g[f"{case}/quantize_rank2"])
 
 
+def test_kat_cnum_more_hodge_powers():
+    g = load_golden("kat_cnum.npz")
+    meta = json.loads(str(g["meta"]))
+    for tag, params in meta.items():
+        flags, rank2 = (torch.from_numpy(g[f"{tag}/{k}"]) for k in ("flags", "rank2"))
+        w = {k[len(tag) + 3:]: torch.from_numpy(g[k]).requires_grad_(True) for k in g.files if k.startswith(f"{tag}/w/")}
+        with torch.no_grad():
+            out = O.run_network(params, w, None, None, rank2, flags)
+        _close(out.numpy(), g[f"{tag}/out"], tag)
+
+
 def test_zinc5b_substitute_networks_and_sampler():
     """SURVEY 8(d) substitute 5b (N = 38 CC, d_min = d_max = 3, zinc250k_CC.yaml hyper-parameters, reference-initialised
     weights): forwards and a 3-scale sampler run."""

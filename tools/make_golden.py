@@ -460,6 +460,43 @@ def kat_zinc5b():
     print("kat_zinc5b: E, K =", E, K, "min thr dist", float(out["k3/min_thr_dist"]), {k: v.shape for k, v in out.items() if k.endswith("out") or k.endswith("sample")})
 
 
+def kat_cnum():
+    """ScoreNetworkF with more than two Hodge powers in its input (cnum = 3, 4: pow_tensor_cc, cc_utils.py:961-979), built by the
+    reference's constructor: the affine case (single Linears) and the general per-element MLP case, at N = 5 (E = 10, K = 15) and
+    N = 12 (E = 66, K = 715)."""
+    from ccsd.src.models.ScoreNetwork_F import ScoreNetworkF
+
+    out, meta = {}, {}
+    cases = {
+        "affine3": (5, 3, 4, dict(num_layers_mlp=1, num_layers=2, num_linears=1, nhid=3, c_hid=3, c_final=2, cnum=3), [5, 4, 3]),
+        "general3": (5, 3, 4, dict(num_layers_mlp=2, num_layers=2, num_linears=2, nhid=4, c_hid=3, c_final=2, cnum=3), [5, 4, 3]),
+        "affine4_n12": (12, 3, 4, dict(num_layers_mlp=1, num_layers=1, num_linears=1, nhid=2, c_hid=2, c_final=2, cnum=4), [12, 9]),
+        "general4_nomask": (5, 3, 4, dict(num_layers_mlp=1, num_layers=2, num_linears=2, nhid=4, c_hid=2, c_final=2, cnum=4, use_hodge_mask=False), [5, 2]),
+    }
+    torch.manual_seed(909)
+    for tag, (N, dmin, dmax, hp, counts) in cases.items():
+        prm = dict(hp, max_node_num=N, d_min=dmin, d_max=dmax, use_bn=False, is_cc=True)
+        prm.setdefault("use_hodge_mask", True)
+        ref_cc.default_mask.cache_clear()
+        m = ScoreNetworkF(**prm)
+        for k, p_ in m.named_parameters():
+            if k.endswith("bias"):
+                p_.data.normal_(0, 0.2)
+        m.eval()
+        B = len(counts)
+        flags = make_flags(B, N, counts)
+        x, adj, rank2 = masked_state(31, B, N, 2, True, dmin, dmax, flags, 0.5)
+        out[f"{tag}/flags"], out[f"{tag}/rank2"] = flags.numpy(), rank2.numpy()
+        with torch.no_grad():
+            for k, v in m.state_dict().items():
+                out[f"{tag}/w/{k}"] = v.numpy()
+            out[f"{tag}/out"] = m(x, adj, rank2, flags).numpy()
+        meta[tag] = dict(prm, model_type="ScoreNetworkF")
+    out["meta"] = json.dumps(meta)
+    np.savez_compressed(os.path.join(GOLD, "kat_cnum.npz"), **out)
+    print("kat_cnum", {k: (v.shape, float(np.abs(v).max())) for k, v in out.items() if k.endswith("/out")})
+
+
 def reference_variant_status():
     """What the reference itself does with the two config switches no shipped config sets: use_bn=True (layers.py:219-224,
     262-275: BatchNorm1d(hidden) applied to (B, N, hidden) / (B, N, N, hidden) activations) and conv_hodge="MLP"
@@ -599,6 +636,8 @@ def main():
                    {"k4": (4, None)}, seed=25, min_dist=5e-3)
     if not only or "zinc5b" in only:
         kat_zinc5b()
+    if not only or "cnum" in only:
+        kat_cnum()
     if not only or "gmh" in only:
         kat_gmh_models()
     if not only or "base" in only:
