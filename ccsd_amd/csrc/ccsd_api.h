@@ -334,8 +334,9 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
 // ---------------- workspace ----------------
 struct Workspace {
     unsigned long long* offbits;
-    float *H, *P0, *P1, *acoef, *net_x, *net_adj, *net_r, *norm2, *part, *sums, *chan;
+    float *H, *P0, *P1, *U1, *acoef, *net_x, *net_adj, *net_r, *norm2, *part, *sums, *chan;
     int ntiles;
+    int p1_raw;     // who filled P1 last: k_r2 with the raw factors (1, see k_r2) or k_gemm_p with the finished projections (0)
     size_t bytes;
 };
 static Workspace carve_ws(const ccsd_plan* pl, int B, void* base) {
@@ -348,6 +349,7 @@ static Workspace carve_ws(const ccsd_plan* pl, int B, void* base) {
     w.H = (float*)take(p.is_cc ? (size_t)B * E * E * 4 * (p.f_cnum > 2 ? p.f_cnum - 1 : 1) : 0);   // H, H^2, ... (cnum > 2: one slab per power)
     w.P0 = (float*)take(p.h_L > 0 ? (size_t)B * E * p.hl[0].wc * 4 : 0);
     w.P1 = (float*)take(p.h_L > 1 ? (size_t)B * E * p.hl[1].wc * 4 : 0);
+    w.U1 = (float*)take(p.h_L > 1 ? (size_t)B * p.hl[1].wc * 4 : 0);
     w.acoef = (float*)take(p.h_L > 1 ? (size_t)B * p.a_cinit * E * 4 : 0);
     w.net_x = (float*)take((size_t)B * p.N * p.F * 4);
     w.net_adj = (float*)take((size_t)B * p.N * p.N * 4);
@@ -412,6 +414,7 @@ static int launch_h(const ccsd_plan* pl, int B, const float* rank2, Workspace& w
 static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* rank2, Workspace& w, void* stream) {
     const PlanD& p = pl->h;
     if (p.h_L < 1) return CCSD_OK;
+    w.p1_raw = 0;
     const int rows = B * p.E;
     {
         const HodgeLayerD& h = p.hl[0];
@@ -451,7 +454,8 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
     return CCSD_OK;
 }
 static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Workspace& w, void* stream) {
-    xa.P0 = w.P0; xa.P1 = w.P1; xa.chan_ws = w.chan; xa.dbg = pl->dbg ? pl->dbg + 32 : nullptr;
+    xa.P0 = w.P0; xa.P1 = w.P1; xa.U1 = w.U1; xa.chan_ws = w.chan;
+    xa.p1_raw = w.p1_raw; xa.dbg = pl->dbg ? pl->dbg + 32 : nullptr;
     const int xa_threads = pl->opt_xa_threads;   // 256 unless CCSD_XA_THREADS was set when the plan was created (diagnostic: 64..512)
     prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
     xa.wp = pl->wp; xa.hpairs = pl->hpairs;
@@ -502,8 +506,9 @@ static int launch_r2(const ccsd_plan* pl, int B, const float* rank2, const float
                      RankEpi& ep, NoiseArgs& na, Workspace& w, void* stream, const CorrFuse* cf = nullptr) {
     R2Args ra{};
     if (cf) ra.cf = *cf;
-    ra.rank2 = rank2; ra.adj = adj; ra.flags = flags; ra.offbits = w.offbits; ra.P0 = w.P0; ra.P1 = w.P1; ra.want_p = want_p;
+    ra.rank2 = rank2; ra.adj = adj; ra.flags = flags; ra.offbits = w.offbits; ra.P0 = w.P0; ra.P1 = w.P1; ra.U1 = w.U1; ra.want_p = want_p;
     ra.ldk = pl->r2_ldk; ra.ldh = pl->r2_ldh; ra.dbg = pl->dbg; ra.wp = pl->wp;
+    if (want_p && pl->h.h_L > 1) w.p1_raw = pl->h.hl[0].mval.n == 1;
     prof_mark(const_cast<ccsd_plan*>(pl), KID_R2, stream);
     const dim3 blk(CCSD_NTHREADS == 1 ? 1 : 512);
 #define R2_GO(MT_, RS_, A_, G_) \

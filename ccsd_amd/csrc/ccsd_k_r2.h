@@ -7,6 +7,7 @@ struct R2Args {
     const float* rank2; const float* adj; const float* flags;
     const unsigned long long* offbits;     // per-sample bitmask of switched-off nodes
     float* P0; float* P1;
+    float* U1;             // [B][wc_1]: fr . Wcat_1 of the complex (linear mlp_value: P1 then holds the raw (F o fr) Wcat_1)
     int want_p;            // write the hodge projections (the A-network will run on the same state)
     int ldk, ldh;
     long long* dbg;
@@ -97,8 +98,14 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
         }
     }
     for (int t = tid; t < E * (Kp4 - K); t += nth) { const int e = t / (Kp4 - K), k = K + t % (Kp4 - K); sF[e * ldk + k] = 0.f; }
+    // Second hodge layer's projections.  Linear mlp_value (every shipped checkpoint): rank2'[e,k] = fl[e] fr[k] (s[e] F[e,k] + b)
+    // with s[e] = sum_c w_c a_c[e] from the adjacency powers, so  P_1 = rank2' Wcat_1 = fl (s ((F o fr) Wcat_1) + b (fr Wcat_1)):
+    // this kernel delivers the two adjacency-independent factors -- Q_1 = (F o fr) Wcat_1 (in P1) and u_1 = fr Wcat_1 (in U1) --
+    // and k_xa, which holds the adjacency, applies s, b and fl.  Only a general (non-linear) mlp_value needs the adjacency
+    // powers here (rank2' is then formed element by element in the GEMM's loader).
     const int hodge2 = (p.h_L > 1) && ra.want_p;
-    if (hodge2) {
+    const bool adjpow = hodge2 && p.hl[0].mval.n > 1;
+    if (adjpow) {
         float c1a = 0.f, c2a = 0.f;
         if (ra.cf.on) corr_coef(ra.cf, 1, &c1a, &c2a);
         for (int i = tid; i < NN; i += nth) {
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     const unsigned long long off = s_off;
     for (int k = tid; k < Kp4; k += nth) sFrb[k] = (k < K && !(cells[k] & off)) ? 1 : 0;
     for (int e = tid; e < 64; e += nth) sFl[e] = e < E ? edge_on(off, edges, e) : 0.f;
-    if (hodge2) {
+    if (adjpow) {
         // acoef[c][e] = (adj^(c+1))[i_e][j_e]   (pow_tensor + adj_to_hodgedual, graph_utils.py:285-292, cc_utils.py:1525-1536)
         float* A = sAdj; float* P0_ = sAdj + NN; float* P1_ = sAdj + 2 * NN;
         for (int c = 0; c < p.a_cinit; ++c) {
@@ -166,15 +173,6 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     const bool doP0 = ra.want_p && p.h_L > 0, doP1 = hodge2;
     const bool lin1 = doP1 && h0.mval.n == 1;      // rank2' affine in rank2: fold it around the GEMM
     const int wc0 = doP0 ? h0.wc : 0, wc1 = doP1 ? h1.wc : 0;
-    if (lin1) {
-        // rank2'[e,k] = fl[e] fr[k] (sum_c w_c a_c[e] F[e,k] + b)  ->  P_1[e,:] = fl[e] (s[e] ((F.fr) W_1)[e,:] + b (fr W_1))
-        for (int e = tid; e < E; e += nth) {
-            float sc = 0.f;
-            for (int c = 0; c < h0.cin; ++c) sc = fmaf(w[h0.mval.w[0] + c], sAco[c * E + e], sc);
-            sRow[e] = sc;
-        }
-        __syncthreads();
-    }
 
     // ---- phase 1: H = F F^T (upper-triangle tiles, mirrored), P_0 = F Wcat_0, P_1 = rank2' Wcat_1.
     // One 16x16 output tile over the full K per task; a wave runs two tasks interleaved (independent MFMA
@@ -214,7 +212,8 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                 acc = fmaf(a, wv, acc);
                 un = fmaf(frk, wv, un);
             }
-            ra.P1[((size_t)b * E + m) * wc1 + n] = lin1 ? sFl[m] * fmaf(sRow[m], acc, w[h0.mval.b[0]] * un) : acc;
+            ra.P1[((size_t)b * E + m) * wc1 + n] = acc;
+            if (lin1 && m == 0) ra.U1[(size_t)b * wc1 + n] = un;
         }
     }
 #endif
@@ -232,7 +231,6 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     const float* WT0 = ra.wp + h0.wcatT;
     const float* WT1 = ra.wp + h1.wcatT;
     const bool hmask = p.f_hmask != 0;
-    const float mval_b0 = lin1 ? w[h0.mval.b[0]] : 0.f;       // fetched before the k loops
     auto run_tile = [&](int t) {
         const int lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
         int type, i, c;                                       // 0: H(i, c >= i); 1: P_0(i, c); 2: P_1(i, c)
@@ -357,15 +355,11 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
             un += __shfl_xor(un, 16, 64);
             un += __shfl_xor(un, 32, 64);
             if (n < wc1) {
-                // rank2'[e,k] = fl[e] fr[k] (s[e] F[e,k] + b)  ->  P_1[e,:] = fl[e] (s[e] ((F.fr) W_1)[e,:] + b (fr W_1))
-                float* dst = ra.P1 + ((size_t)b * E + mb) * wc1 + n;
-                const float bu = mval_b0 * un;
+                float* dst = ra.P1 + ((size_t)b * E + mb) * wc1 + n;      // Q_1 (linear mlp_value) / P_1 (general)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = mb + r, mc = m < E ? m : E - 1;
-                    const float v = GEN1 ? acc[r] : sFl[mc] * fmaf(sRow[mc], acc[r], bu);
-                    if (m < E) dst[(size_t)r * wc1] = v;
-                }
+                for (int r = 0; r < 4; ++r)
+                    if (mb + r < E) dst[(size_t)r * wc1] = acc[r];
+                if (!GEN1 && i == 0 && kq == 0) ra.U1[(size_t)b * wc1 + n] = un;
             }
         }
     };

@@ -17,6 +17,7 @@ struct XaArgs {
     const float* xA; const float* adjA;
     const float* flags;
     const float* P0; const float* P1;     // hodge projections (B*E, wc_l)
+    const float* U1; int p1_raw;          // p1_raw: P1 = (F o fr) Wcat_1 and U1 = fr Wcat_1 (B, wc_1); the kernel forms P_1 = fl (s P1 + b U1)
     int do_x, do_a;
     int mode;
     float ss_x, ss_a;                     // MODE_SCORE scaling
@@ -287,6 +288,19 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                 dE.divmod(t, c, e);
                 s_hd[t] = s_chan[c * NN + pair_off(e)];
             }
+            // P_1[e] = fl[e] (s[e] Q_1[e] + b u_1) with s[e] = sum_c w_c a_c[e] (linear mlp_value of the first layer,
+            // hodge_attention.py:322-323; a_c = the diagonal hodge adjacency) when k_r2 delivered the raw factors Q_1, u_1:
+            // per edge [fl s | fl b]
+            float* s_p1c = s_hd + p.a_nch_hodge * E;
+            if (p.h_L > 1 && xa.p1_raw) {
+                const float mvb0 = w[h0.mval.b[0]];
+                for (int e = tid; e < E; e += nth) {
+                    float sc = 0.f;
+                    for (int c = 0; c < h0.cin; ++c) sc = fmaf(w[h0.mval.w[0] + c], s_chan[c * NN + pair_off(e)], sc);
+                    const float fl = s_flags[edge_i(e)] * s_flags[edge_j(e)];
+                    s_p1c[e] = fl * sc; s_p1c[E + e] = fl * mvb0;
+                }
+            }
             for (int t = tid; t < h0.cin * E * qw0; t += nth) {
                 int c, r, e, d;
                 dEqw0.divmod(t, c, r);
@@ -326,20 +340,25 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                 const float rnc0 = 1.0f / (float)h0.nchunk;
                 const int npair = E * (E + 1) / 2;
                 const float* P1b = xa.P1 + (size_t)b * E * h1.wc;   // [E][wc1] projections of the second layer (L2)
+                auto p1_compose = [&](int e, float q, float u) {
+                    return xa.p1_raw ? fmaf(s_p1c[e], q, s_p1c[E + e] * u) : q;
+                };
                 const int mtE = (E + 15) >> 4, ntq = (qw1 + 15) >> 4, ksE = (E + 3) >> 2;
 #ifndef CCSD_EMU
                 // The second layer's projection tasks are (channel, 16-column tile) x row tiles; with one (channel, column
                 // tile) per wave its B operands are the same for every row tile: fetch them now, so the L2 latency hides
                 // behind the dense attention below
                 const bool pf_ok = h1.cin * ntq <= n_waves && ksE <= 16;
-                float pfb[16];
+                float pfb[16], pfu = 0.f;          // (issued here, composed and consumed after the dense attention)
                 const int pf_c = wave_id / ntq, pf_ct = wave_id % ntq;
                 const int pf_l15 = tid & 15, pf_kq = (tid & 63) >> 4;
                 if (pf_ok && wave_id < h1.cin * ntq) {
+                    const int d = 16 * pf_ct + pf_l15, col = pf_c * qw1 + (d < qw1 ? d : qw1 - 1);
+                    if (xa.p1_raw) pfu = xa.U1[(size_t)b * h1.wc + col];
 #pragma unroll
                     for (int s0 = 0; s0 < 16; ++s0) {
-                        const int k = 4 * s0 + pf_kq, d = 16 * pf_ct + pf_l15;
-                        pfb[s0] = P1b[(k < E ? k : E - 1) * h1.wc + pf_c * qw1 + (d < qw1 ? d : qw1 - 1)];
+                        const int k = 4 * s0 + pf_kq;
+                        pfb[s0] = P1b[(k < E ? k : E - 1) * h1.wc + col];
                     }
                 }
 #endif
@@ -404,7 +423,8 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
 #pragma unroll
                             for (int s0 = 0; s0 < 16; ++s0) {
                                 const int k = 4 * s0 + pf_kq;
-                                bval[s0] = (k < E && d < qw1) ? dg[k < E ? k : E - 1] * pfb[s0] : 0.f;
+                                const int kc = k < E ? k : E - 1;
+                                bval[s0] = (k < E && d < qw1) ? dg[kc] * p1_compose(kc, pfb[s0], pfu) : 0.f;
                             }
                             const float bias = w[h1.bcat + pf_c * qw1 + (d < qw1 ? d : qw1 - 1)];
                             for (int rt = 0; rt < mtE; ++rt) {
@@ -434,7 +454,8 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                                   [&](int e, int k) { const float v = Hc[(e < E ? e : E - 1) * E + (k < E ? k : E - 1)]; return (e < E && k < E) ? v : 0.f; },
                                   [&](int k, int d) {
                                       const int kc = k < E ? k : E - 1, dc = d < qw1 ? d : qw1 - 1;
-                                      const float v = dg[kc] * P1b[kc * h1.wc + c * qw1 + dc];
+                                      const float v = dg[kc] * p1_compose(kc, P1b[kc * h1.wc + c * qw1 + dc],
+                                                                          xa.p1_raw ? xa.U1[(size_t)b * h1.wc + c * qw1 + dc] : 0.f);
                                       return (k < E && d < qw1) ? v : 0.f;
                                   },
                                   [&](int e, int d, float acc) {

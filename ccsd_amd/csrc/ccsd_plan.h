@@ -466,7 +466,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
                     p->o_hq = carve(hq_floats);
                     if (p->h_L > 1 && p->hl[1].cin * E > mchid * p->ldn) p->o_deg = carve(p->hl[1].cin * E);
                 }
-                p->o_hd = carve(p->a_nch_hodge * E);
+                p->o_hd = carve(p->a_nch_hodge * E + (p->h_L > 1 ? 2 * E : 0));   // + [s fl | b fl] of P_1's composition (k_xa)
                 p->o_hw = carve(2 * hw_n * 72);
                 p->hw_stride = hw_n * 72;
             }
