@@ -5,6 +5,31 @@
 #include "ccsd_plan.h"
 #include <type_traits>
 
+#if defined(CCSD_BARRIER_PROF) && !defined(CCSD_EMU)
+// Diagnostic build only (tools/dev/barrier_prof.sh; never defined by __graft_entry__.build()): every __syncthreads() of the
+// unit adds, per wave, the cycles the wave spent inside it to g_bar[workgroup][wave] and counts it in g_bar[..][8 + wave];
+// k_xa copies its row to stamp slots 40.. at its end.  Waves that arrive early show up as barrier time: busy = life - barrier.
+__device__ long long g_bar[4096 * 16];
+__device__ long long g_arr[64 * 4 * 64];      // [workgroup < 64][wave < 4][barrier < 64]: arrival clock
+__device__ inline void ccsd_real_sync() { __syncthreads(); }
+__device__ inline void ccsd_prof_sync() {
+    const long long t0 = (long long)__builtin_readcyclecounter();
+    ccsd_real_sync();
+    const long long t1 = (long long)__builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) {
+        long long* r = g_bar + (size_t)blockIdx.x * 16 + (threadIdx.x >> 6);
+        if (blockIdx.x < 64 && r[8] < 64 && (threadIdx.x >> 6) < 4) g_arr[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + r[8]] = t0;
+        r[0] += t1 - t0; r[8] += 1;
+    }
+}
+__device__ long long g_ct[16];
+#define CCSD_CT(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_ct[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define CCSD_CTW(i, w) do { if (blockIdx.x == 0 && threadIdx.x == 64 * (w)) g_ct[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define __syncthreads() ccsd_prof_sync()
+#else
+#define CCSD_CT(i) do {} while (0)
+#define CCSD_CTW(i, w) do {} while (0)
+#endif
 // ---------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------
@@ -455,6 +480,7 @@ CCSD_DEV void mlp_chain_tile(const MlpD& m, const float* __restrict__ wp, const 
     // kernel is hoisted above the shape dispatch and spilled to scratch (42 MB of spill writes per k_xa launch, PMC).
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));
+    CCSD_CT(0);
     const int l15 = lane & 15, kq = lane >> 4;
     const int prow = rowoff((p0 + l15 < rows) ? p0 + l15 : rows - 1);      // clamped: rows beyond `rows` are never stored
     const int in = m.in;
@@ -469,16 +495,41 @@ CCSD_DEV void mlp_chain_tile(const MlpD& m, const float* __restrict__ wp, const 
             xin[t][j] = src[prow];
         }
     }
+    // Touch every 128-byte line of the later linears' packed weights now (one dword per line, results summed into a value
+    // nothing depends on): they reach the CU's L1 while the first linear runs, so the chain's in-order weight loads hit L1
+    // (~120 cycles) instead of exposing an L2 round trip at every tile of every linear.
+    float pfv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (m.n > 1) {
+        const float* pbase = wp + m.pw[1];
+        const int pn = m.pb[m.n - 1] + 16 * NO - m.pw[1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int o = (q * 64 + lane) * 32; if (o < pn) pfv[q] = pbase[o]; }
+    }
+    CCSD_CT(1);
     const size_t lo = (size_t)l15;
     if (m.n == 1) {
         chain_layer<NI, NO>(wp + m.pw[0] + lo * (16 * NI) + 4 * kq, wp + m.pb[0] + 4 * kq, 16 * NI, false, xin, yo);
     } else {
         chain_layer<NI, NH>(wp + m.pw[0] + lo * (16 * NI) + 4 * kq, wp + m.pb[0] + 4 * kq, 16 * NI, true, xin, h0);
+        CCSD_CT(2);
         for (int i = 1; i < m.n - 1; ++i) {
             chain_layer<NH, NH>(wp + m.pw[i] + lo * (16 * NH) + 4 * kq, wp + m.pb[i] + 4 * kq, 16 * NH, true, h0, h1);
 #pragma unroll
             for (int t = 0; t < NH; ++t) h0[t] = h1[t];
         }
+        CCSD_CT(3);
+#if defined(CCSD_BARRIER_PROF) && !defined(CCSD_EMU)
+        if (m.n > 2) {   // diagnostic: the middle linear three more times through ONE copy of its code (first pass: cold I-cache)
+#pragma unroll 1
+            for (int rep = 0; rep < 3; ++rep) {
+                CCSD_CT(6 + rep);
+                chain_layer<NH, NH>(wp + m.pw[1] + lo * (16 * NH) + 4 * kq, wp + m.pb[1] + 4 * kq, 16 * NH, true, h0, h1);
+#pragma unroll
+                for (int t = 0; t < NH; ++t) asm volatile("" :: "v"(h1[t][0]), "v"(h1[t][1]), "v"(h1[t][2]), "v"(h1[t][3]));
+                CCSD_CT(7 + rep);
+            }
+        }
+#endif
         const int il = m.n - 1;
         if (NO == 1 && m.out == 1) {
             // a single output feature: 16 of 16 MFMA rows would be padding -- dot product on the VALU instead; the lane
@@ -493,11 +544,15 @@ CCSD_DEV void mlp_chain_tile(const MlpD& m, const float* __restrict__ wp, const 
             d += __shfl_xor(d, 16, 64);
             d += __shfl_xor(d, 32, 64);
             d += wp[m.pb[il]];
+            CCSD_CT(4);
+            asm volatile("" :: "v"(pfv[0]), "v"(pfv[1]), "v"(pfv[2]), "v"(pfv[3]));     // (the touches retire here)
             if (kq == 0 && p0 + l15 < rows) epi(p0 + l15, 0, d);
+            CCSD_CT(5);
             return;
         }
         chain_layer<NH, NO>(wp + m.pw[il] + lo * (16 * NH) + 4 * kq, wp + m.pb[il] + 4 * kq, 16 * NH, false, h0, yo);
     }
+    asm volatile("" :: "v"(pfv[0]), "v"(pfv[1]), "v"(pfv[2]), "v"(pfv[3]));
     const bool rok = p0 + l15 < rows;
 #pragma unroll
     for (int to = 0; to < NO; ++to)

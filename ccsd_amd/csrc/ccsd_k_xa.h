@@ -707,6 +707,19 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
         }
     }
     stamp(xa.dbg, 14);
+#if defined(CCSD_BARRIER_PROF) && !defined(CCSD_EMU)
+    if ((tid & 63) == 0 && blockIdx.x < 4096) {
+        long long* r = g_bar + (size_t)blockIdx.x * 16 + (tid >> 6);
+        if (xa.dbg) xa.dbg[(size_t)blockIdx.x * 64 + 26 + (tid >> 6)] = r[0];     // slots 26..29: barrier cycles of waves 0..3
+        if (xa.dbg && tid == 0) xa.dbg[(size_t)blockIdx.x * 64 + 30] = r[8];      // slot 30: barriers passed
+        // rows gridDim.x + 4 b + wave of the stamp buffer (the caller allocates gridDim.x + 256 rows): arrival clocks per barrier
+        if (xa.dbg && blockIdx.x < 64 && (tid >> 6) < 4)
+            for (int k = 0; k < 64; ++k)
+                (xa.dbg - 32)[((size_t)gridDim.x + blockIdx.x * 4 + (tid >> 6)) * 64 + k] = k < r[8] ? g_arr[(blockIdx.x * 4 + (tid >> 6)) * 64 + k] : 0;
+        if (xa.dbg && blockIdx.x == 0 && tid == 0) for (int k = 0; k < 16; ++k) (xa.dbg - 32)[((size_t)gridDim.x + 255) * 64 + k] = g_ct[k];
+        r[0] = 0; r[8] = 0;
+    }
+#endif
     if (xa.mode == MODE_NORMS) {
         __syncthreads();
         const float t0 = block_sum(nx_net, s_red), t1 = block_sum(na_net, s_red);

@@ -45,6 +45,10 @@ struct AttnLayerD {
     // packed buffer (conv = "GCN"): per input channel [fin][cp] weights + [cp] biases with the Q | K | V columns side by side,
     // zero padded to cp = pad16(2 adim + fout) -- the B operand / bias of gcn_tile_multi without column-part arithmetic
     int qkvp, cp;
+    // packed buffer: multi_channel's first Linear W0[hid][cin*fout] as MFMA A fragments, [hidden tile][channel][k-step][lane]
+    // with lane = 16 (k & 3) + (unit & 15) and every channel's fout columns zero padded to mcs = ceil(fout / 4) k-steps:
+    // one coalesced 256-byte load per k-step (ccsd_pack_mc)
+    int mcp, mcs;
 };
 struct HodgeLayerD {
     int cin, cout, adim, dsplit, nchunk, wc;   // wc = cin*2*adim columns of Wcat
@@ -184,6 +188,18 @@ static inline void ccsd_pack_mlp(const MlpD& m, const float* w, float* packed) {
     }
 }
 
+// multi_channel's first Linear in MFMA A-fragment order, zero padded (AttnLayerD::mcp)
+static inline void ccsd_pack_mc(const AttnLayerD& a, const float* w, float* packed) {
+    const int hid = a.mc.hid, nht = pad16(hid) >> 4;
+    for (int ht = 0; ht < nht; ++ht)
+        for (int c = 0; c < a.cin; ++c)
+            for (int st = 0; st < a.mcs; ++st)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int hh = 16 * ht + (lane & 15), o = 4 * st + (lane >> 4);
+                    packed[a.mcp + (size_t)((ht * a.cin + c) * a.mcs + st) * 64 + lane] =
+                        (hh < hid && o < a.fout) ? w[a.mc.w[0] + (size_t)hh * a.mc.in + c * a.fout + o] : 0.f;
+                }
+}
 // Q | K | V weights of a GCN-conv AttentionLayer side by side, zero padded (AttnLayerD::qkvp)
 static inline void ccsd_pack_qkv(const AttnLayerD& a, const float* w, float* packed) {
     if (a.conv_mlp) return;
@@ -247,6 +263,9 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
         pb.chainify(a.mlp, CCSD_CHAIN_EDGE);
         a.mc = pb.mlp(2, a.cin * a.fout, hid, a.fout);
         a.w_hi = pb.cur;
+        a.mcs = (a.fout + 3) >> 2;
+        a.mcp = pb.pcur;
+        pb.pcur += (pad16(hid) >> 4) * a.cin * a.mcs * 64;
         return true;
     };
     p->x_gmh = c->x_gmh ? 1 : 0; p->g_cinit = 0; p->g_nch = 0;

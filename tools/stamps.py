@@ -19,11 +19,12 @@ flags = (bench.hist_flags(B, 9, bench.QM9_HIST) if Nn == 9 else bench.hist_flags
 st, sc, rs = eng.alloc_state(B), eng.alloc_state(B), eng.alloc_state(B)
 eng.init_state(flags, st, None, 1, 0)
 eng.run(flags, st, sc, rs, 1, 0, 0, 3)
-dbg = torch.zeros(B, 64, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(B + 256, 64, dtype=torch.int64, device="cuda")   # (+256 rows: barrier arrival tables of the diagnostic build)
 eng.lib.check(eng.lib.ccsd_debug_stamps(eng.handle, C.c_void_p(dbg.data_ptr())))
 eng.predictor(5, st, flags, None, 1, 0, sc, None)
 torch.cuda.synchronize()
-d = dbg.cpu().numpy()
+dfull = dbg.cpu().numpy()
+d = dfull[:B]
 names_r2 = ["load", "prep(masks,acoef,u)", "->phase1", "gemm tiles (H,P)", "HF+epilogue", "store"]
 print("k_r2 per-phase cycles (median over workgroups), total", np.median(d[:, 5] - d[:, 0]))
 for i in range(5):
@@ -50,3 +51,21 @@ if os.environ.get("STAMPS_CKPT", "").endswith("Base_CC"):
           [int(np.median(x[:, hb[i + 1]] - x[:, hb[i]])) for i in range(7)], " rows per chunk", "see plan")
 print("layer 1, first channel group: bias fill + dinv, gcn tiles (+barrier), attention pairs (wave 0), multi_channel accumulate (+barrier):", [int(np.median(x[:, b] - x[:, a])) for a, b in ((5, 22), (22, 23), (23, 25), (25, 24))])
 print("layer 1 rest: edge MLP chain + node linear (+barrier), symmetrise/tanh:", [int(np.median(x[:, b] - x[:, a])) for a, b in ((24, 6), (6, 7))])
+if os.environ.get("STAMPS_BARRIERS"):
+    life = x[:, 14] - x[:, 0]
+    print("k_xa barriers passed (wave 0):", int(np.median(x[:, 30])), " share of life inside __syncthreads(), waves 0..3:",
+          [round(float(np.median(x[:, 26 + k] / life)), 3) for k in range(4)])
+    nb = int(np.median(x[:, 30]))
+    arr = dfull[B:B + 256].reshape(64, 4, 64)[:, :, :nb].astype(np.float64)     # [workgroup][wave][barrier]
+    rel = arr.max(axis=1)                                                       # release ~ last arrival
+    start = x[:64, 0].astype(np.float64)
+    prev = np.concatenate([start[:, None], rel[:, :-1]], axis=1)
+    dur = np.median(rel - prev, axis=0)
+    busy = np.median(arr - prev[:, None, :], axis=0)                            # [wave][barrier]: time from the previous release to arrival
+    print("interval  duration   busy(w0 w1 w2 w3)   (cycles, median of 64 workgroups; interval k ends at the k-th __syncthreads)")
+    for k in range(nb):
+        print(f"  {k:3d} {dur[k]:9.0f}   " + " ".join(f"{busy[w, k]:7.0f}" for w in range(4)) + f"   at {np.median(rel[:, k] - start):8.0f}")
+    ct = dfull[B + 255, :16].astype(np.int64)
+    print("last mlp_chain_tile of workgroup 0, wave 0 (entry, gather issued, layer 1, middle layers, last layer, epilogue):", [int(ct[i + 1] - ct[i]) for i in range(5)])
+    print("  middle linear repeated through one copy of its code (diagnostic; first pass = cold I-cache):", [int(ct[7 + i] - ct[6 + i]) for i in range(3)])
+    print("  layer 1: multi_channel MFMA task (wave 3):", int(ct[11] - ct[10]), " pair loop (wave 3):", int(ct[12] - ct[11]), " pair loop (wave 0):", int(ct[14] - ct[13]))
