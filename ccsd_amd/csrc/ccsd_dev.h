@@ -422,16 +422,16 @@ CCSD_DEV void block_linear(float* Y, int ldy, const float* X, int ldx, const flo
 // ---------------------------------------------------------------------------------------------
 #ifndef CCSD_EMU
 typedef float chain_f32x4 __attribute__((ext_vector_type(4)));
-// one linear of the chain: TI input tiles (registers) -> TO output tiles, straight-line code
+// one linear of the chain: TI input tiles (registers) -> TO output tiles, straight-line code; W = the packed block + 4 * lane
+// (ccsd_chain_widx: [out tile][in tile][lane][4])
 template <int TI, int TO>
-CCSD_DEV void chain_layer(const float* __restrict__ W, const float* __restrict__ Bv, int ip, bool act,
+CCSD_DEV void chain_layer(const float* __restrict__ W, const float* __restrict__ Bv, bool act,
                           const chain_f32x4* in, chain_f32x4* out) {
 #pragma unroll
     for (int to = 0; to < TO; ++to) {
-        const float* Wr = W + (size_t)(16 * to) * ip;
         float4 wv[TI];
 #pragma unroll
-        for (int t = 0; t < TI; ++t) wv[t] = *reinterpret_cast<const float4*>(Wr + 16 * t);
+        for (int t = 0; t < TI; ++t) wv[t] = *reinterpret_cast<const float4*>(W + (size_t)(to * TI + t) * 256);
         const float4 bb = *reinterpret_cast<const float4*>(Bv + 16 * to);
         chain_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -467,7 +467,7 @@ CCSD_DEV void mlp_chain_tile(const MlpD& m, const float* __restrict__ wp, const 
             const float* Bv = wp + m.pb[i];
             for (int o = 0; o < op; ++o) {
                 float acc = 0.f;
-                for (int k = 0; k < ip; ++k) acc = fmaf(W[o * ip + k], a[k], acc);
+                for (int k = 0; k < ip; ++k) acc = fmaf(W[ccsd_chain_widx(o, k, ip)], a[k], acc);
                 acc += Bv[o];
                 t[o] = (i < m.n - 1) ? elu1(acc) : acc;
             }
@@ -495,25 +495,15 @@ CCSD_DEV void mlp_chain_tile(const MlpD& m, const float* __restrict__ wp, const 
             xin[t][j] = src[prow];
         }
     }
-    // Touch every 128-byte line of the later linears' packed weights now (one dword per line, results summed into a value
-    // nothing depends on): they reach the CU's L1 while the first linear runs, so the chain's in-order weight loads hit L1
-    // (~120 cycles) instead of exposing an L2 round trip at every tile of every linear.
-    float pfv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (m.n > 1) {
-        const float* pbase = wp + m.pw[1];
-        const int pn = m.pb[m.n - 1] + 16 * NO - m.pw[1];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const int o = (q * 64 + lane) * 32; if (o < pn) pfv[q] = pbase[o]; }
-    }
     CCSD_CT(1);
-    const size_t lo = (size_t)l15;
+    const int l4 = 4 * lane;
     if (m.n == 1) {
-        chain_layer<NI, NO>(wp + m.pw[0] + lo * (16 * NI) + 4 * kq, wp + m.pb[0] + 4 * kq, 16 * NI, false, xin, yo);
+        chain_layer<NI, NO>(wp + m.pw[0] + l4, wp + m.pb[0] + 4 * kq, false, xin, yo);
     } else {
-        chain_layer<NI, NH>(wp + m.pw[0] + lo * (16 * NI) + 4 * kq, wp + m.pb[0] + 4 * kq, 16 * NI, true, xin, h0);
+        chain_layer<NI, NH>(wp + m.pw[0] + l4, wp + m.pb[0] + 4 * kq, true, xin, h0);
         CCSD_CT(2);
         for (int i = 1; i < m.n - 1; ++i) {
-            chain_layer<NH, NH>(wp + m.pw[i] + lo * (16 * NH) + 4 * kq, wp + m.pb[i] + 4 * kq, 16 * NH, true, h0, h1);
+            chain_layer<NH, NH>(wp + m.pw[i] + l4, wp + m.pb[i] + 4 * kq, true, h0, h1);
 #pragma unroll
             for (int t = 0; t < NH; ++t) h0[t] = h1[t];
         }
@@ -523,7 +513,7 @@ CCSD_DEV void mlp_chain_tile(const MlpD& m, const float* __restrict__ wp, const 
 #pragma unroll 1
             for (int rep = 0; rep < 3; ++rep) {
                 CCSD_CT(6 + rep);
-                chain_layer<NH, NH>(wp + m.pw[1] + lo * (16 * NH) + 4 * kq, wp + m.pb[1] + 4 * kq, 16 * NH, true, h0, h1);
+                chain_layer<NH, NH>(wp + m.pw[1] + l4, wp + m.pb[1] + 4 * kq, true, h0, h1);
 #pragma unroll
                 for (int t = 0; t < NH; ++t) asm volatile("" :: "v"(h1[t][0]), "v"(h1[t][1]), "v"(h1[t][2]), "v"(h1[t][3]));
                 CCSD_CT(7 + rep);
@@ -534,25 +524,23 @@ CCSD_DEV void mlp_chain_tile(const MlpD& m, const float* __restrict__ wp, const 
         if (NO == 1 && m.out == 1) {
             // a single output feature: 16 of 16 MFMA rows would be padding -- dot product on the VALU instead; the lane
             // holds features 16t + 4kq + r of its row, the four kq groups are summed with two cross-lane adds
-            const float* W3 = wp + m.pw[il] + 4 * kq;
+            const float* W3 = wp + m.pw[il] + 64 * kq;      // row 0 of the packed block: lane 16 kq of in tile t
             float d = 0.f;
 #pragma unroll
             for (int t = 0; t < NH; ++t) {
-                const float4 wv = *reinterpret_cast<const float4*>(W3 + 16 * t);
+                const float4 wv = *reinterpret_cast<const float4*>(W3 + 256 * t);
                 d = fmaf(wv.x, h0[t][0], d); d = fmaf(wv.y, h0[t][1], d); d = fmaf(wv.z, h0[t][2], d); d = fmaf(wv.w, h0[t][3], d);
             }
             d += __shfl_xor(d, 16, 64);
             d += __shfl_xor(d, 32, 64);
             d += wp[m.pb[il]];
             CCSD_CT(4);
-            asm volatile("" :: "v"(pfv[0]), "v"(pfv[1]), "v"(pfv[2]), "v"(pfv[3]));     // (the touches retire here)
             if (kq == 0 && p0 + l15 < rows) epi(p0 + l15, 0, d);
             CCSD_CT(5);
             return;
         }
-        chain_layer<NH, NO>(wp + m.pw[il] + lo * (16 * NH) + 4 * kq, wp + m.pb[il] + 4 * kq, 16 * NH, false, h0, yo);
+        chain_layer<NH, NO>(wp + m.pw[il] + l4, wp + m.pb[il] + 4 * kq, false, h0, yo);
     }
-    asm volatile("" :: "v"(pfv[0]), "v"(pfv[1]), "v"(pfv[2]), "v"(pfv[3]));
     const bool rok = p0 + l15 < rows;
 #pragma unroll
     for (int to = 0; to < NO; ++to)

@@ -175,6 +175,12 @@ inline void PlanBuilder::chainify(MlpD& m, unsigned allowed) {
         m.pb[i] = pcur; pcur += op;
     }
 }
+// Position of W[o][k] inside a chain linear's packed block: MFMA A-fragment order [out tile][in tile][lane][4] with
+// lane = 16 ((k & 15) >> 2) + (o & 15) -- the float4 a lane feeds to four consecutive k-steps; one wave-level load is 1 KB
+// contiguous (eight full cache lines; the row-major copy cost sixteen half-used ones per load)
+static inline __host__ __device__ int ccsd_chain_widx(int o, int k, int ip) {
+    return (((o >> 4) * (ip >> 4) + (k >> 4)) * 64 + (((k & 15) >> 2) << 4) + (o & 15)) * 4 + (k & 3);
+}
 // zero-padded copies of a chain MLP's linears (torch layout [out][in]) into the packed buffer
 static inline void ccsd_pack_mlp(const MlpD& m, const float* w, float* packed) {
     if (!m.chain) return;
@@ -182,7 +188,7 @@ static inline void ccsd_pack_mlp(const MlpD& m, const float* w, float* packed) {
     for (int i = 0; i < m.n; ++i) {
         const int in = i == 0 ? m.in : m.hid, out = i == m.n - 1 ? m.out : m.hid, ip = 16 * (i == 0 ? sh[0] : sh[1]);
         for (int o = 0; o < out; ++o) {
-            for (int k = 0; k < in; ++k) packed[m.pw[i] + o * ip + k] = w[m.w[i] + o * in + k];
+            for (int k = 0; k < in; ++k) packed[m.pw[i] + ccsd_chain_widx(o, k, ip)] = w[m.w[i] + o * in + k];
             packed[m.pb[i] + o] = w[m.b[i] + o];
         }
     }

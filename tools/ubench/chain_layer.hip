@@ -19,14 +19,14 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ wp, float* ou
     if ((int)(threadIdx.x >> 6) >= nactive) { __syncthreads(); return; }
     chain_f32x4 h0[4], h1[4];
     for (int t = 0; t < 4; ++t) for (int j = 0; j < 4; ++j) h0[t][j] = 0.01f * (lane + t + j);
-    const float* W = wp + (size_t)l15 * 64 + 4 * kq;
+    const float* W = wp + 4 * lane;
     const float* Bv = wp + 4096 + 4 * kq;
     float4 wv[4][4];
     if (MODE == 2) for (int to = 0; to < 4; ++to) for (int t = 0; t < 4; ++t) wv[to][t] = *reinterpret_cast<const float4*>(W + (size_t)(16 * to) * 64 + 16 * t);
     const long long t0 = (long long)__builtin_readcyclecounter();
     for (int r = 0; r < REP; ++r) {
-        if (MODE == 0) chain_layer<4, 4>(W, Bv, 64, true, h0, h1);
-        if (MODE == 3) chain_layer<4, 4>(W, Bv, 64, false, h0, h1);
+        if (MODE == 0) chain_layer<4, 4>(W, Bv, true, h0, h1);
+        if (MODE == 3) chain_layer<4, 4>(W, Bv, false, h0, h1);
         if (MODE == 1 || MODE == 2) {
             if (MODE == 1) {
 #pragma unroll
