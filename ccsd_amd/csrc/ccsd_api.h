@@ -17,7 +17,7 @@ static inline int xa_variant(const PlanD& p) {
     bool conv_mlp = false;
     for (int l = 0; l < p.a_L; ++l) conv_mlp = conv_mlp || p.al[l].conv_mlp;
     if (p.x_gmh) for (int l = 0; l < p.x_depth; ++l) conv_mlp = conv_mlp || p.gl[l].conv_mlp;
-    if (conv_mlp || (p.hb_L && p.x_gmh)) return XA_GEN;
+    if (conv_mlp || (p.hb_L && p.x_gmh) || p.h_L > 2) return XA_GEN;
     return p.hb_L ? XA_HB : p.x_gmh ? XA_GMH : XA_PLAIN;
 }
 static inline const void* xa_kernel(const PlanD& p) {
@@ -287,7 +287,7 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
         }
         ccsd_pack_mlp(pl->h.a_fin, weights, packed.data());
         for (int l = 0; l < pl->h.h_L; ++l) {   // Wcat^T of the hodge projections for k_r2
-            const HodgeLayerD& h = pl->h.hl[l];
+            const HodgeLayerD& h = ccsd_hl(pl->h, l);
             const int Kp = (K + 31) & ~31;
             for (int k = 0; k < K; ++k)
                 for (int n = 0; n < h.wc; ++n) packed[(size_t)h.wcatT + (size_t)n * Kp + k] = weights[(size_t)h.wcat + (size_t)k * h.wc + n];
@@ -319,6 +319,10 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
             pl->fused_r2 = 1; pl->r2_ldk = ldk; pl->r2_ldh = ldh; pl->r2_lds = fl * 4;
         }
     }
+    if (pl->h.h_L > 2 && !pl->fused_r2) {
+        ccsd_plan_destroy(pl);
+        return set_err(CCSD_ERR_UNSUPPORTED, "more than two HodgeAdjAttentionLayers need the fused rank-2 kernel (E <= 64, cnum <= 2, hidden widths <= 16)");
+    }
 #ifndef CCSD_EMU
     if ((size_t)pl->h.xa_lds_floats * 4 > 64 * 1024)
         PC(rt_set_max_dyn_smem(xa_kernel(pl->h), (size_t)pl->h.xa_lds_floats * 4));
@@ -348,8 +352,8 @@ static Workspace carve_ws(const ccsd_plan* pl, int B, void* base) {
     const size_t E = p.E, K = p.K;
     w.H = (float*)take(p.is_cc ? (size_t)B * E * E * 4 * (p.f_cnum > 2 ? p.f_cnum - 1 : 1) : 0);   // H, H^2, ... (cnum > 2: one slab per power)
     w.P0 = (float*)take(p.h_L > 0 ? (size_t)B * E * p.hl[0].wc * 4 : 0);
-    w.P1 = (float*)take(p.h_L > 1 ? (size_t)B * E * p.hl[1].wc * 4 : 0);
-    w.U1 = (float*)take(p.h_L > 1 ? (size_t)B * p.hl[1].wc * 4 : 0);
+    w.P1 = (float*)take(p.h_L > 1 ? (size_t)B * E * p.h_pw * 4 : 0);
+    w.U1 = (float*)take(p.h_L > 1 ? (size_t)B * p.h_pw * 4 : 0);
     w.acoef = (float*)take(p.h_L > 1 ? (size_t)B * p.a_cinit * E * 4 : 0);
     w.net_x = (float*)take((size_t)B * p.N * p.F * 4);
     w.net_adj = (float*)take((size_t)B * p.N * p.N * 4);
@@ -410,10 +414,22 @@ static int launch_h(const ccsd_plan* pl, int B, const float* rank2, Workspace& w
     }
     return CCSD_OK;
 }
+struct RankEpi;
+static int launch_r2(const ccsd_plan* pl, int B, const float* rank2, const float* adj, const float* flags, int want_p,
+                     RankEpi& ep, NoiseArgs& na, Workspace& w, void* stream, const CorrFuse* cf);
 // hodge projections for ScoreNetworkA_CC from (adj, rank2)
 static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* rank2, Workspace& w, void* stream) {
     const PlanD& p = pl->h;
     if (p.h_L < 1) return CCSD_OK;
+    if (p.h_L > 2) {
+        // more than two hodge layers: k_xa's general layer loop consumes the factors only the fused rank-2 kernel produces
+        // (plan creation guarantees it exists); its ScoreNetworkF output lands in the net_r scratch, which every caller
+        // of launch_p overwrites afterwards
+        RankEpi ep{};
+        ep.mode = MODE_SCORE; ep.sscale = 0.f; ep.out = w.net_r;
+        NoiseArgs na0{};
+        return launch_r2(pl, B, rank2, adj, nullptr, 1, ep, na0, w, stream, nullptr);
+    }
     w.p1_raw = 0;
     const int rows = B * p.E;
     {

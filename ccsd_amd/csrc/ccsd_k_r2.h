@@ -172,7 +172,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     const HodgeLayerD& h1 = p.hl[1];
     const bool doP0 = ra.want_p && p.h_L > 0, doP1 = hodge2;
     const bool lin1 = doP1 && h0.mval.n == 1;      // rank2' affine in rank2: fold it around the GEMM
-    const int wc0 = doP0 ? h0.wc : 0, wc1 = doP1 ? h1.wc : 0;
+    const int wc0 = doP0 ? h0.wc : 0, wc1 = doP1 ? p.h_pw : 0;   // (layers >= 1: one concatenated projection, PlanD::h_pw)
 
     // ---- phase 1: H = F F^T (upper-triangle tiles, mirrored), P_0 = F Wcat_0, P_1 = rank2' Wcat_1.
     // One 16x16 output tile over the full K per task; a wave runs two tasks interleaved (independent MFMA
@@ -199,8 +199,12 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
         }
         for (int n = 0; n < wc1; ++n) {
             float acc = 0.f, un = 0.f;
+            int ll = 1;                                        // layer of concatenated column n (padding columns: zero)
+            while (ll + 1 < p.h_L && n >= p.h_poff[ll + 1]) ++ll;
+            const HodgeLayerD& hn = ccsd_hl(p, ll);
+            const int nl = n - p.h_poff[ll];
             for (int kk = 0; kk < K; ++kk) {
-                const float frk = (float)sFrb[kk], wv = w[h1.wcat + (size_t)kk * wc1 + n];
+                const float frk = (float)sFrb[kk], wv = nl < hn.wc ? w[hn.wcat + (size_t)kk * hn.wc + nl] : 0.f;
                 float a;
                 if (lin1) a = sF[m * ldk + kk] * frk;
                 else {

@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
             float* s_hw = sm + p.o_hw;         // zero-padded mlp_attention weight blocks of both hodge layers
             stage_mlp_blocks(p.hl[0].matt, w, s_hw);
             if (p.h_L > 1) stage_mlp_blocks(p.hl[1].matt, w, s_hw + p.hw_stride);
+            if (VAR == XA_GEN) for (int l = 2; l < p.h_L; ++l) stage_mlp_blocks(ccsd_hl(p, l).matt, w, s_hw + l * p.hw_stride);
             const HodgeLayerD& h0 = p.hl[0];
             const int qw0 = 2 * h0.adim;
             const FastDiv dqw0(qw0), dEqw0(E * qw0);
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                         if (o < h0.cout) { const float tv = tanh_f(out[o] * fh * fh); s_hd[(p.a_cinit + o) * E + e] = tv + tv; }
                 }
                 __syncthreads();
-            } else {
+            } else if (VAR != XA_GEN || p.h_L == 2) {
                 // dense E x E attention of every channel, mlp_attention, mask, tanh, + transpose (hodge_attention.py:315-320):
                 // one thread per unordered pair (e <= e2) from the pair table, both halves stored
                 const HodgeLayerD& h1 = p.hl[1];
@@ -484,6 +485,140 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                         if (o < h1.cout) { const float tv = tanh_f(out[o] * fh * fh); s_hd[(p.a_cinit + h0.cout + o) * E + e] = tv + tv; }
                 }
                 __syncthreads();
+            } else if constexpr (VAR == XA_GEN) {
+                // ---- three or four HodgeAdjAttentionLayers (num_linears_h == 1): the general layer loop.
+                // Layer l >= 1 sees the dense hodge adjacency H^l [cin_l][E][E] (the previous layer's output) and the rank-2
+                // features R_l = the l-fold mlp_value image of rank2 (hodge_attention.py:322-323):
+                //   R_1 = fl fr (s o F + b_0),   R_{j+1} = fl fr (sum_c w^j_c H^j_c R_j + b_j)      (V_c = H_c R, :98)
+                // Only P_l = R_l Wcat_l is ever needed.  With Q_l = (F o fr) Wcat_l and u_l = fr Wcat_l from k_r2:
+                //   X_1 = fl (s Q_l + b_0 u_l),   X_{j+1} = fl (M_j X_j + b_j u_l),  M_j = sum_c w^j_c H^j_c,   P_l = X_l
+                // -- a chain of l - 1 small (E x E)(E x wc_l) products on MFMA; the M_j of the layers passed stay in LDS.
+                const int npair = E * (E + 1) / 2, mtE = (E + 15) >> 4, ksE = (E + 3) >> 2;
+                float* bufA = s_h1m;
+                float* bufB = sm + p.o_h2m;
+                float* s_M = sm + p.o_hM;
+                float* sX0 = sm + p.o_hX;
+                float* s_deg = sm + p.o_deg;
+                auto edge_fl = [&](int e) { return s_flags[edge_i(e)] * s_flags[edge_j(e)]; };
+                // dense attention of a layer from its Q|K rows in s_hq -> Hout [cout][E][E] (+ diagonal -> s_hd)
+                auto dense_att = [&](const HodgeLayerD& h, const float* hw, float* Hout, int hd0) {
+                    const int qw = 2 * h.adim;
+                    const float rnc = 1.0f / (float)h.nchunk;
+                    for (int t = tid; t < npair; t += nth) {
+                        const int e = xa.hpairs[2 * t], e2 = xa.hpairs[2 * t + 1];
+                        float in[CCSD_SMALLW], out[CCSD_SMALLW];
+#pragma unroll
+                        for (int c = 0; c < CCSD_SMALLW; ++c) {
+                            float v = 0.f;
+                            if (c < h.cin) {
+                                const float* q1 = s_hq + (c * E + e) * qw;
+                                const float* q2 = s_hq + (c * E + e2) * qw;
+                                const float s1 = attn_logits(q1, q2 + h.adim, h.nchunk, h.dsplit, rks);
+                                const float s2 = attn_logits(q2, q1 + h.adim, h.nchunk, h.dsplit, rks);
+                                v = (s1 * rnc + s2 * rnc) * 0.5f;
+                            }
+                            in[c] = v;
+                        }
+                        small_mlp_lds<CCSD_SMALLW>(hw, h.matt.n, in, out);
+                        const float fh = edge_fl(e), fh2 = edge_fl(e2);
+#pragma unroll
+                        for (int o = 0; o < CCSD_SMALLW; ++o)
+                            if (o < h.cout) {
+                                const float tv = tanh_f(out[o] * fh * fh2);
+                                Hout[o * E * E + e * E + e2] = tv + tv;
+                                Hout[o * E * E + e2 * E + e] = tv + tv;
+                                if (e == e2) s_hd[(hd0 + o) * E + e] = tv + tv;
+                            }
+                    }
+                };
+                dense_att(h0, s_hw, bufA, p.a_cinit);
+                __syncthreads();
+                float* Hin = bufA;
+                float* Hnext = bufB;
+                int hd0 = p.a_cinit + h0.cout;
+                for (int l = 1; l < p.h_L; ++l) {
+                    const HodgeLayerD& h = ccsd_hl(p, l);
+                    const int qw = 2 * h.adim, wc = h.wc, ntw = (wc + 15) >> 4, ntq = (qw + 15) >> 4;
+                    const float* Qb = xa.P1 + (size_t)b * E * p.h_pw + p.h_poff[l];     // rows of stride h_pw
+                    const float* ub = xa.U1 + (size_t)b * p.h_pw + p.h_poff[l];
+                    for (int t = tid; t < h.cin * E; t += nth) {                        // D^-1/2 of every input channel
+                        int c, e;
+                        dE.divmod(t, c, e);
+                        const float* Hc = Hin + (size_t)c * E * E + e;                  // symmetric: walk the column
+                        float sdeg = 0.f;
+                        for (int e2 = 0; e2 < E; ++e2) sdeg += Hc[e2 * E];
+                        s_deg[t] = 1.0f / sqrtf(fmaxf(sdeg, 1.f));
+                    }
+                    if (l + 1 < p.h_L)                                                  // M_l, for the layers still to come
+                        for (int t = tid; t < E * E; t += nth) {
+                            float m = 0.f;
+                            for (int c = 0; c < h.cin; ++c) m = fmaf(w[h.mval.w[0] + c], Hin[(size_t)c * E * E + t], m);
+                            s_M[(l - 1) * E * E + t] = m;
+                        }
+                    for (int t = tid; t < E * wc; t += nth) {                           // X_1
+                        const int e = t / wc, n = t - e * wc;
+                        sX0[t] = fmaf(s_p1c[e], Qb[(size_t)e * p.h_pw + n], s_p1c[E + e] * ub[n]);
+                    }
+                    __syncthreads();
+                    float* X = sX0;
+                    float* Xn = sX0 + E * wc;
+                    for (int j = 1; j < l; ++j) {                                       // X_{j+1} = fl (M_j X_j + b_j u_l)
+                        const float* Mj = s_M + (j - 1) * E * E;
+                        const float bj = w[ccsd_hl(p, j).mval.b[0]];
+                        for (int task = wave_id; task < mtE * ntw; task += n_waves) {
+                            const int rt = task / ntw, ct = task - rt * ntw;
+                            wave_tile(16 * rt, 16 * ct, ksE,
+                                      [&](int e, int k) { const float v = Mj[(e < E ? e : E - 1) * E + (k < E ? k : E - 1)]; return (e < E && k < E) ? v : 0.f; },
+                                      [&](int k, int n) { const float v = X[(k < E ? k : E - 1) * wc + (n < wc ? n : wc - 1)]; return (k < E && n < wc) ? v : 0.f; },
+                                      [&](int e, int n, float acc) { if (e < E && n < wc) Xn[e * wc + n] = edge_fl(e) * fmaf(bj, ub[n], acc); });
+                        }
+                        __syncthreads();
+                        float* tx = X; X = Xn; Xn = tx;
+                    }
+                    // Q|K of the layer: per channel Y = D H D X_c + b  (hodge_layers.py:185-193)
+                    for (int task = wave_id; task < h.cin * mtE * ntq; task += n_waves) {
+                        const int c = task / (mtE * ntq), rem = task % (mtE * ntq), rt = rem / ntq, ct = rem % ntq;
+                        const float* Hc = Hin + (size_t)c * E * E;
+                        const float* dg = s_deg + c * E;
+                        wave_tile(16 * rt, 16 * ct, ksE,
+                                  [&](int e, int k) { const float v = Hc[(e < E ? e : E - 1) * E + (k < E ? k : E - 1)]; return (e < E && k < E) ? v : 0.f; },
+                                  [&](int k, int d) {
+                                      const int kc = k < E ? k : E - 1, dc = d < qw ? d : qw - 1;
+                                      const float v = dg[kc] * X[kc * wc + c * qw + dc];
+                                      return (k < E && d < qw) ? v : 0.f;
+                                  },
+                                  [&](int e, int d, float acc) {
+                                      if (e < E && d < qw) s_hq[(c * E + e) * qw + d] = fmaf(dg[e], acc, w[h.bcat + c * qw + d]);
+                                  });
+                    }
+                    __syncthreads();
+                    const float* hw = s_hw + l * p.hw_stride;
+                    if (l + 1 < p.h_L) {
+                        dense_att(h, hw, Hnext, hd0);
+                        float* th = Hin; Hin = Hnext; Hnext = th;
+                    } else {
+                        // the last layer: only the diagonal of its output is used (hodgedual_to_adj, cc_utils.py:1571)
+                        for (int e = tid; e < E; e += nth) {
+                            float in[CCSD_SMALLW], out[CCSD_SMALLW];
+#pragma unroll
+                            for (int c = 0; c < CCSD_SMALLW; ++c) {
+                                float sacc = 0.f;
+                                if (c < h.cin) {
+                                    const float* q = s_hq + (c * E + e) * qw;
+                                    sacc = attn_logits(q, q + h.adim, h.nchunk, h.dsplit, rks) * (1.0f / (float)h.nchunk);
+                                }
+                                in[c] = sacc;
+                            }
+                            small_mlp_lds<CCSD_SMALLW>(hw, h.matt.n, in, out);
+                            const float fh = edge_fl(e);
+#pragma unroll
+                            for (int o = 0; o < CCSD_SMALLW; ++o)
+                                if (o < h.cout) { const float tv = tanh_f(out[o] * fh * fh); s_hd[(hd0 + o) * E + e] = tv + tv; }
+                        }
+                    }
+                    __syncthreads();
+                    hd0 += h.cout;
+                }
             }
             stamp(xa.dbg, 20);
             // hodgedual_to_adj (cc_utils.py:1552-1588): scatter the diagonals behind the graph channels

@@ -8,7 +8,8 @@
 
 #define CCSD_MAXLIN 4     // linears per MLP
 #define CCSD_MAXL 8       // attention layers / GCN depth
-#define CCSD_MAXHL 2      // hodge layers handled by the HIP path
+#define CCSD_MAXHL 2      // hodge layers in the hot part of the plan (PlanD::hl); CCSD_MAXHLX more behind it (PlanD::hlx)
+#define CCSD_MAXHLX 2
 #define CCSD_MAXFL 4      // HodgeNetworkLayers in ScoreNetworkF
 #define CCSD_MAXCN 4      // channels [F, HF, H^2 F, H^3 F] of ScoreNetworkF's input (cnum, cc_utils.py:961-979)
 #define CCSD_SMALLW 8     // widest per-thread MLP in the hodge branch
@@ -104,11 +105,18 @@ struct PlanD {
     HodgeBaseD hb[CCSD_MAXHL];
     int o_hbw;                    // k_xa LDS: mlp_hodge weight blocks of both layers (2 * CCSD_MAXLIN * (16*16+16) floats)
     int o_hbg, o_hbd, hb_rows;    // k_xa LDS: hidden rows of layer 0 [cin][E][hid]; diagonals of layer 1's blocks [cin][E]; rows per chunk
+    // HodgeAdjAttentionLayers 2.. (num_layers_h > 2; k_xa<., XA_GEN>), and the layout of the projections k_r2 hands over for
+    // layers >= 1: P1 = [E][h_pw] with layer l's wc_l columns at h_poff[l] (each earlier layer padded to 16), U1 = [h_pw]
+    HodgeLayerD hlx[CCSD_MAXHLX];
+    int h_pw, h_poff[CCSD_MAXHL + CCSD_MAXHLX];
+    int o_h2m, o_hM, o_hX;        // k_xa LDS (h_L > 2): second dense hodge buffer; M_j = sum_c w_c H_c of layers 1..h_L-2; two [E][wc] buffers
     // ScoreNetworkX_GMH (x_gmh = 1): x_depth AttentionLayers gl[] on g_cinit adjacency powers, g_nch channels in all
     int x_gmh, g_cinit, g_nch;
     AttnLayerD gl[CCSD_MAXL];
     float f_betas[CCSD_MAXCN];    // affine ScoreNetworkF with cnum > 2: coefficient of H^j F, j = 1 .. cnum - 1 (f_betas[1] == f_beta)
 };
+static inline __host__ __device__ const HodgeLayerD& ccsd_hl(const PlanD& p, int l) { return l < CCSD_MAXHL ? p.hl[l] : p.hlx[l - CCSD_MAXHL]; }
+static inline HodgeLayerD& ccsd_hl_mut(PlanD& p, int l) { return l < CCSD_MAXHL ? p.hl[l] : p.hlx[l - CCSD_MAXHL]; }
 
 #ifndef CCSD_DEVICE_ONLY
 #include <math.h>
@@ -309,7 +317,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     p->h_L = 0; p->a_nch_hodge = 0; p->hb_L = 0;
     if (c->a_is_cc_net == 2) {
         if (!c->is_cc) { pb.fail(CCSD_ERR_INVALID, "ScoreNetworkA_Base_CC is only for combinatorial complexes"); return 0; }
-        if (c->h_num_layers < 1 || c->h_num_layers > CCSD_MAXHL) {
+        if (c->h_num_layers < 1 || c->h_num_layers > 2) {
             pb.fail(CCSD_ERR_UNSUPPORTED, "HIP path supports 1 or 2 HodgeBaselineLayers"); return 0; }
         p->hb_L = c->h_num_layers;
         int hch = c->a_c_init;
@@ -336,12 +344,12 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
         if (hf != hch) { pb.fail(CCSD_ERR_INVALID, "hodge channel count inconsistent (num_layers_h==1 needs c_hid_h==c_final_h)"); return 0; }
     } else if (c->a_is_cc_net) {
         if (!c->is_cc) { pb.fail(CCSD_ERR_INVALID, "ScoreNetworkA_CC is only for combinatorial complexes"); return 0; }
-        if (c->h_num_layers < 1 || c->h_num_layers > CCSD_MAXHL) {
-            pb.fail(CCSD_ERR_UNSUPPORTED, "HIP path supports 1 or 2 HodgeAdjAttentionLayers"); return 0; }
+        if (c->h_num_layers < 1 || c->h_num_layers > CCSD_MAXHL + CCSD_MAXHLX) {
+            pb.fail(CCSD_ERR_UNSUPPORTED, "HIP path supports 1 to 4 HodgeAdjAttentionLayers"); return 0; }
         p->h_L = c->h_num_layers;
         int hch = c->a_c_init;
         for (int l = 0; l < p->h_L; ++l) {
-            HodgeLayerD& h = p->hl[l];
+            HodgeLayerD& h = ccsd_hl_mut(*p, l);
             const bool first = (l == 0), last = (l == p->h_L - 1) && !first;
             h.cin = first ? c->a_c_init : c->h_c_hid;
             h.cout = last ? c->h_c_final : c->h_c_hid;
@@ -363,6 +371,17 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
         p->a_nch_hodge = hch;
         int hf = c->h_c_hid * (p->h_L - 1) + c->h_c_final + c->a_c_init;
         if (hf != hch) { pb.fail(CCSD_ERR_INVALID, "hodge channel count inconsistent (num_layers_h==1 needs c_hid_h==c_final_h)"); return 0; }
+        // the transposed copies Wcat_l^T of layers >= 1 are consecutive [pad16(wc_l)][Kp] blocks: k_r2 treats them as ONE
+        // projection of h_pw columns
+        p->h_pw = 0;
+        for (int l = 1; l < p->h_L; ++l) {
+            p->h_poff[l] = p->h_pw;
+            if (ccsd_hl(*p, l).wcatT != ccsd_hl(*p, 1).wcatT + p->h_pw * ((K + 31) & ~31)) { pb.fail(CCSD_ERR_RUNTIME, "Wcat^T blocks not consecutive"); return 0; }
+            p->h_pw += l == p->h_L - 1 ? ccsd_hl(*p, l).wc : pad16(ccsd_hl(*p, l).wc);
+        }
+        if (p->h_L > 2)
+            for (int l = 0; l < p->h_L - 1; ++l)
+                if (ccsd_hl(*p, l).mval.n != 1) { pb.fail(CCSD_ERR_UNSUPPORTED, "more than two HodgeAdjAttentionLayers need num_linears_h == 1"); return 0; }
     }
     p->a_fdim = p->a_nch_graph + p->a_nch_hodge;
     p->a_fin = pb.mlp(3, p->a_fdim, 2 * p->a_fdim, 1);
@@ -422,8 +441,8 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     const int NNpad = (NN + 15) / 16 * 16;
     int hq_floats = 0, h1m_floats = 0;
     if (p->h_L) {
-        for (int l = 0; l < p->h_L; ++l) { int v = p->hl[l].cin * E * 2 * p->hl[l].adim; if (v > hq_floats) hq_floats = v; }
-        if (p->h_L > 1) h1m_floats = p->hl[0].cout * E * E;
+        for (int l = 0; l < p->h_L; ++l) { int v = ccsd_hl(*p, l).cin * E * 2 * ccsd_hl(*p, l).adim; if (v > hq_floats) hq_floats = v; }
+        for (int l = 0; l + 1 < p->h_L; ++l) { int v = ccsd_hl(*p, l).cout * E * E; if (v > h1m_floats) h1m_floats = v; }
         if (E > NN) { pb.fail(CCSD_ERR_UNSUPPORTED, "E > N*N"); return 0; }
     }
     // weight staging: largest section (X-network, one AttentionLayer, final MLP); only when it is small
@@ -436,7 +455,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     const int budgets_b[NCAND] = {40960, 53 * 1024, 79 * 1024, 152 * 1024};
     const int stage_on[NCAND] = {0, 0, 0, 0};
     int hw_n = 1;
-    for (int l = 0; l < p->h_L; ++l) if (p->hl[l].matt.n > hw_n) hw_n = p->hl[l].matt.n;
+    for (int l = 0; l < p->h_L; ++l) if (ccsd_hl(*p, l).matt.n > hw_n) hw_n = ccsd_hl(*p, l).matt.n;
     auto ld_of = [](int rows) { int r = (rows + 15) / 16 * 16; if (r % 32 == 0) r += 8; return r; };   // 2-way conflicts at worst
     int best_total = -1;
     const char* skip = getenv("CCSD_XA_PASS");
@@ -492,8 +511,19 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
                     if (p->h_L > 1 && p->hl[1].cin * E > mchid * p->ldn) p->o_deg = carve(p->hl[1].cin * E);
                 }
                 p->o_hd = carve(p->a_nch_hodge * E + (p->h_L > 1 ? 2 * E : 0));   // + [s fl | b fl] of P_1's composition (k_xa)
-                p->o_hw = carve(2 * hw_n * 72);
+                p->o_hw = carve((p->h_L > 2 ? p->h_L : 2) * hw_n * 72);
                 p->hw_stride = hw_n * 72;
+                if (p->h_L > 2) {
+                    int degmax = 0, wcmax = 0;
+                    for (int l = 1; l < p->h_L; ++l) {
+                        if (ccsd_hl(*p, l).cin * E > degmax) degmax = ccsd_hl(*p, l).cin * E;
+                        if (ccsd_hl(*p, l).wc > wcmax) wcmax = ccsd_hl(*p, l).wc;
+                    }
+                    p->o_deg = carve(degmax);
+                    p->o_h2m = carve(h1m_floats);
+                    p->o_hM = carve((p->h_L - 2) * E * E);
+                    p->o_hX = carve(2 * E * wcmax);
+                }
             }
             int hb_rmin = 0;
             if (p->hb_L) {

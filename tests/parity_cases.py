@@ -638,3 +638,56 @@ def case_kat_cnum(lib, device):
         x = torch.zeros(B, N, 2, device=device)
         adj = torch.zeros(B, N, N, device=device)
         assert_close(eng.score(2, x, adj, rank2, flags), g[f"{tag}/out"], f"kat cnum {tag}")
+
+
+def case_kat_hodge_layers(lib, device):
+    """ScoreNetworkA_CC with three / four HodgeAdjAttentionLayers (num_layers_h = 3, 4; num_linears_h = 1) against the reference
+    constructor's outputs (no shipped checkpoint has more than two): k_r2 hands over the adjacency-independent factors of every
+    later layer's projection, k_xa<., XA_GEN> runs the general layer loop.  E = 10, 15 and the qm9_CC geometry E = 36, K = 466.
+    Also through the model object at the seam, and a two-inner-step Langevin corrector (the projections then come from the base
+    rank2 through launch_p's route) against the oracle."""
+    from oracle import ccsd_oracle as O
+
+    g = load_golden("kat_hodge_layers.npz")
+    meta = json.loads(str(g["meta"]))
+    for tag, params in meta.items():
+        flags, x, adj, rank2 = (torch.from_numpy(g[f"{tag}/{k}"]).to(device) for k in ("flags", "x", "adj", "rank2"))
+        sd = {k[len(tag) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}/w/")}
+        N, Fd = params["max_node_num"], params["max_feat_num"]
+        eng = PCEngine(None, None, params, sd, None, None, N=N, F=Fd, is_cc=True, d_min=params["d_min"], d_max=params["d_max"],
+                       device=device, lib=lib)
+        assert_close(eng.score(1, x, adj, rank2, flags), g[f"{tag}/out"], f"kat hodge layers {tag}")
+        m = loader.load_model_from_ckpt(params, sd, device)
+        assert_close(m(x, adj, rank2, flags, lib=lib), g[f"{tag}/out"], f"kat hodge layers {tag} (model object)")
+    # a sampler: Reverse + Langevin with two inner corrector steps (the second iteration's A-network sees (x_0, adj_cur, rank2_0):
+    # its projections come from the base rank2 through launch_p's route), two scales, host noise, against the oracle; the X and
+    # F networks are the small reference-built ones of kat_small_models (same geometry: N = 5, F = 10, d 3..4)
+    tag = "L3_n5"
+    pa = meta[tag]
+    sda = {k[len(tag) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}/w/")}
+    gs = load_golden("kat_small_models.npz")
+    ms = json.loads(str(gs["meta"]))
+    sds = lambda t: {k[len(t) + 3:]: torch.from_numpy(gs[k]) for k in gs.files if k.startswith(f"{t}/w/")}
+    prm = {"x": ms["x"], "adj": pa, "rank2": ms["rank2"]}
+    wts = {"x": sds("x"), "adj": sda, "rank2": sds("rank2")}
+    names = ["x", "adj", "rank2"]
+    N, Fd, d_min, d_max, B = 5, 10, 3, 4, 3
+    flags = torch.from_numpy(g[f"{tag}/flags"])
+    sde_cfg = dict(type="VE", beta_min=0.1, beta_max=1.0, num_scales=2)
+    kw = dict(shape_x=(B, N, Fd), shape_adj=(B, N, N), predictor="Reverse", corrector="Langevin", snr=0.2, scale_eps=0.7,
+              n_steps=2, probability_flow=False, continuous=True, denoise=True, eps=1e-4, is_cc=True,
+              shape_rank2=(B, *rank2_dim(N, d_min, d_max)), d_min=d_min, d_max=d_max)
+    models = [loader.load_model_from_ckpt(prm[p], wts[p], device) for p in names]
+    fn = solver.get_pc_sampler(device=device, rng="torch_cpu", lib=lib, sde_x=loader.load_sde(sde_cfg), sde_adj=loader.load_sde(sde_cfg),
+                               sde_rank2=loader.load_sde(sde_cfg), **kw)
+    torch.manual_seed(77)
+    got = fn(*models, flags.to(device))
+    wo = {p: {k: v.clone().requires_grad_(True) for k, v in wts[p].items()} for p in names}
+    nets = [(lambda x_, a_, r_, f_, p=p: O.run_network(prm[p], wo[p], x_, a_, r_, f_)) for p in names]
+    ofn = O.get_pc_sampler(n_diff_steps=2, keep_traj=False, sde_x=O.load_sde(sde_cfg), sde_adj=O.load_sde(sde_cfg),
+                           sde_rank2=O.load_sde(sde_cfg), **kw)
+    torch.manual_seed(77)
+    with torch.no_grad():
+        want = ofn(*nets, flags)
+    for p, g_, w_ in zip(names, got, want):
+        assert_close(g_, w_, f"three hodge layers, Reverse + Langevin n_steps=2, {p}")

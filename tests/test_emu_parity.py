@@ -134,3 +134,7 @@ def test_one_step_vs_oracle_edge_batches(lib):
     """Single-complex batch; a batch holding an empty graph, a 1-node and a 2-node graph (no rank-2 cell fits)."""
     pc.case_one_step_vs_oracle_large("ccsd_qm9_CC", lib, DEV, 1, [7], "Reverse", "Langevin", 0.2, 0.7)
     pc.case_one_step_vs_oracle_large("ccsd_qm9_CC", lib, DEV, 5, [9, 0, 1, 2, 3], "Euler", "Langevin", 0.2, 0.7, seed=8)
+
+
+def test_kat_hodge_layers_three_and_four(lib):
+    pc.case_kat_hodge_layers(lib, DEV)

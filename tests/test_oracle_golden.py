@@ -240,6 +240,17 @@ def test_kat_cnum_more_hodge_powers():
         _close(out.numpy(), g[f"{tag}/out"], tag)
 
 
+def test_kat_hodge_layers_three_and_four():
+    g = load_golden("kat_hodge_layers.npz")
+    meta = json.loads(str(g["meta"]))
+    for tag, params in meta.items():
+        flags, x, adj, rank2 = (torch.from_numpy(g[f"{tag}/{k}"]) for k in ("flags", "x", "adj", "rank2"))
+        w = {k[len(tag) + 3:]: torch.from_numpy(g[k]).requires_grad_(True) for k in g.files if k.startswith(f"{tag}/w/")}
+        with torch.no_grad():
+            out = O.run_network(params, w, x, adj, rank2, flags)
+        _close(out.numpy(), g[f"{tag}/out"], tag)
+
+
 def test_zinc5b_substitute_networks_and_sampler():
     """SURVEY 8(d) substitute 5b (N = 38 CC, d_min = d_max = 3, zinc250k_CC.yaml hyper-parameters, reference-initialised
     weights): forwards and a 3-scale sampler run."""

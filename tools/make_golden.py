@@ -497,6 +497,44 @@ def kat_cnum():
     print("kat_cnum", {k: (v.shape, float(np.abs(v).max())) for k, v in out.items() if k.endswith("/out")})
 
 
+def kat_hodge_layers():
+    """ScoreNetworkA_CC with three and four HodgeAdjAttentionLayers (num_layers_h = 3, 4; num_linears_h = 1), built by the
+    reference's constructor: no shipped checkpoint has more than two.  N = 5 (E = 10, K = 15; the geometry of kat_small_models, whose
+    X / F networks complete a sampler in the tests), N = 6 (E = 15) and the qm9_CC
+    geometry N = 9, d 3..9 (E = 36, K = 466)."""
+    from ccsd.src.models.ScoreNetwork_A_CC import ScoreNetworkA_CC
+
+    out, meta = {}, {}
+    base = dict(nhid=4, num_layers=2, num_linears=2, c_init=2, c_hid=2, c_final=2, adim=2, num_heads=2, conv="GCN",
+                conv_hodge="HCN", use_bn=False, is_cc=True, num_linears_h=1)
+    cases = {
+        "L3_n5": (5, 10, 3, 4, dict(nhid_h=2, num_layers_h=3, c_hid_h=2, c_final_h=2, adim_h=2, num_heads_h=2), [5, 4, 3]),
+        "L4_n6": (6, 2, 3, 4, dict(nhid_h=4, num_layers_h=4, c_hid_h=3, c_final_h=2, adim_h=4, num_heads_h=2), [6, 4]),
+        "L3_n9": (9, 4, 3, 9, dict(nhid_h=4, num_layers_h=3, c_hid_h=4, c_final_h=2, adim_h=4, num_heads_h=2), [9, 6]),
+    }
+    torch.manual_seed(1717)
+    for tag, (N, Fd, dmin, dmax, hp, counts) in cases.items():
+        prm = dict(base, **hp, max_feat_num=Fd, max_node_num=N, d_min=dmin, d_max=dmax)
+        m = ScoreNetworkA_CC(**prm)
+        for k, p_ in m.named_parameters():
+            if k.endswith("bias"):
+                p_.data.normal_(0, 0.2)
+        m.eval()
+        B = len(counts)
+        flags = make_flags(B, N, counts)
+        x, adj, rank2 = masked_state(57, B, N, Fd, True, dmin, dmax, flags, 0.5)
+        for k, v in (("flags", flags), ("x", x), ("adj", adj), ("rank2", rank2)):
+            out[f"{tag}/{k}"] = v.numpy()
+        with torch.no_grad():
+            for k, v in m.state_dict().items():
+                out[f"{tag}/w/{k}"] = v.numpy()
+            out[f"{tag}/out"] = m(x, adj, rank2, flags).numpy()
+        meta[tag] = dict(prm, model_type="ScoreNetworkA_CC")
+    out["meta"] = json.dumps(meta)
+    np.savez_compressed(os.path.join(GOLD, "kat_hodge_layers.npz"), **out)
+    print("kat_hodge_layers", {k: (v.shape, float(np.abs(v).max())) for k, v in out.items() if k.endswith("/out")})
+
+
 def reference_variant_status():
     """What the reference itself does with the two config switches no shipped config sets: use_bn=True (layers.py:219-224,
     262-275: BatchNorm1d(hidden) applied to (B, N, hidden) / (B, N, N, hidden) activations) and conv_hodge="MLP"
@@ -638,6 +676,8 @@ def main():
         kat_zinc5b()
     if not only or "cnum" in only:
         kat_cnum()
+    if not only or "hlayers" in only:
+        kat_hodge_layers()
     if not only or "gmh" in only:
         kat_gmh_models()
     if not only or "base" in only:
