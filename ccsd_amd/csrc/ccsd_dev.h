@@ -508,18 +508,6 @@ CCSD_DEV void mlp_chain_tile(const MlpD& m, const float* __restrict__ wp, const 
             for (int t = 0; t < NH; ++t) h0[t] = h1[t];
         }
         CCSD_CT(3);
-#if defined(CCSD_BARRIER_PROF) && !defined(CCSD_EMU)
-        if (m.n > 2) {   // diagnostic: the middle linear three more times through ONE copy of its code (first pass: cold I-cache)
-#pragma unroll 1
-            for (int rep = 0; rep < 3; ++rep) {
-                CCSD_CT(6 + rep);
-                chain_layer<NH, NH>(wp + m.pw[1] + l4, wp + m.pb[1] + 4 * kq, true, h0, h1);
-#pragma unroll
-                for (int t = 0; t < NH; ++t) asm volatile("" :: "v"(h1[t][0]), "v"(h1[t][1]), "v"(h1[t][2]), "v"(h1[t][3]));
-                CCSD_CT(7 + rep);
-            }
-        }
-#endif
         const int il = m.n - 1;
         if (NO == 1 && m.out == 1) {
             // a single output feature: 16 of 16 MFMA rows would be padding -- dot product on the VALU instead; the lane

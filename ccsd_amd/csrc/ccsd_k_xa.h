@@ -258,6 +258,36 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
             }
             __syncthreads();
         }
+        // Hodge branch, early part: what depends only on the adjacency powers and the weights is staged here, in regions of
+        // their own, so that its L2 round trips overlap the attention stack's first phase instead of opening the hodge branch
+        if (VAR != XA_HB && p.h_L > 0) {
+            float* s_hd = sm + p.o_hd;
+            float* s_hw = sm + p.o_hw;
+            float* s_p1c = s_hd + p.a_nch_hodge * E;
+            const HodgeLayerD& h0 = p.hl[0];
+            stage_mlp_blocks(p.hl[0].matt, w, s_hw);
+            if (p.h_L > 1) stage_mlp_blocks(p.hl[1].matt, w, s_hw + p.hw_stride);
+            if (VAR == XA_GEN) for (int l = 2; l < p.h_L; ++l) stage_mlp_blocks(ccsd_hl(p, l).matt, w, s_hw + l * p.hw_stride);
+            // adj_to_hodgedual (cc_utils.py:1525-1536): diagonal hodge adjacency = upper triangle of the adjacency powers;
+            // DenseHCNConv on a diagonal matrix (hodge_layers.py:185-193) is a row scaling
+            for (int t = tid; t < p.a_cinit * E; t += nth) {
+                int c, e;
+                dE.divmod(t, c, e);
+                s_hd[t] = s_chan[c * NN + pair_off(e)];
+            }
+            // P_1[e] = fl[e] (s[e] Q_1[e] + b u_1) with s[e] = sum_c w_c a_c[e] (linear mlp_value of the first layer,
+            // hodge_attention.py:322-323; a_c = the diagonal hodge adjacency) when k_r2 delivered the raw factors Q_1, u_1:
+            // per edge [fl s | fl b]
+            if (p.h_L > 1 && xa.p1_raw) {
+                const float mvb0 = w[h0.mval.b[0]];
+                for (int e = tid; e < E; e += nth) {
+                    float sc = 0.f;
+                    for (int c = 0; c < h0.cin; ++c) sc = fmaf(w[h0.mval.w[0] + c], s_chan[c * NN + pair_off(e)], sc);
+                    const float fl = s_flags[edge_i(e)] * s_flags[edge_j(e)];
+                    s_p1c[e] = fl * sc; s_p1c[E + e] = fl * mvb0;
+                }
+            }
+        }
 #define ATTN_LAYERS p.al
 #define ATTN_NL p.a_L
 #define ATTN_TAP(l) (void)0
@@ -275,33 +305,12 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
             const float kscale = (float)sqrt((double)p.K);  // hodge_attention.py:118,122: / sqrt(out_dim), out_dim = K
             const float rks = 1.0f / kscale;
             float* s_hw = sm + p.o_hw;         // zero-padded mlp_attention weight blocks of both hodge layers
-            stage_mlp_blocks(p.hl[0].matt, w, s_hw);
-            if (p.h_L > 1) stage_mlp_blocks(p.hl[1].matt, w, s_hw + p.hw_stride);
-            if (VAR == XA_GEN) for (int l = 2; l < p.h_L; ++l) stage_mlp_blocks(ccsd_hl(p, l).matt, w, s_hw + l * p.hw_stride);
+            // (the mlp_attention weight blocks, the diagonal hodge adjacency and P_1's per-edge factors were staged behind pow_tensor)
             const HodgeLayerD& h0 = p.hl[0];
             const int qw0 = 2 * h0.adim;
             const FastDiv dqw0(qw0), dEqw0(E * qw0);
             const float* P0b = xa.P0 + (size_t)b * E * h0.wc;
-            // adj_to_hodgedual (cc_utils.py:1525-1536): diagonal hodge adjacency = upper triangle of the adjacency powers;
-            // DenseHCNConv on a diagonal matrix (hodge_layers.py:185-193) is a row scaling
-            for (int t = tid; t < p.a_cinit * E; t += nth) {
-                int c, e;
-                dE.divmod(t, c, e);
-                s_hd[t] = s_chan[c * NN + pair_off(e)];
-            }
-            // P_1[e] = fl[e] (s[e] Q_1[e] + b u_1) with s[e] = sum_c w_c a_c[e] (linear mlp_value of the first layer,
-            // hodge_attention.py:322-323; a_c = the diagonal hodge adjacency) when k_r2 delivered the raw factors Q_1, u_1:
-            // per edge [fl s | fl b]
             float* s_p1c = s_hd + p.a_nch_hodge * E;
-            if (p.h_L > 1 && xa.p1_raw) {
-                const float mvb0 = w[h0.mval.b[0]];
-                for (int e = tid; e < E; e += nth) {
-                    float sc = 0.f;
-                    for (int c = 0; c < h0.cin; ++c) sc = fmaf(w[h0.mval.w[0] + c], s_chan[c * NN + pair_off(e)], sc);
-                    const float fl = s_flags[edge_i(e)] * s_flags[edge_j(e)];
-                    s_p1c[e] = fl * sc; s_p1c[E + e] = fl * mvb0;
-                }
-            }
             for (int t = tid; t < h0.cin * E * qw0; t += nth) {
                 int c, r, e, d;
                 dEqw0.divmod(t, c, r);

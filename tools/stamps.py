@@ -66,16 +66,4 @@ if os.environ.get("STAMPS_BARRIERS"):
     for k in range(nb):
         print(f"  {k:3d} {dur[k]:9.0f}   " + " ".join(f"{busy[w, k]:7.0f}" for w in range(4)) + f"   at {np.median(rel[:, k] - start):8.0f}")
     ct = dfull[B + 255, :16].astype(np.int64)
-    print("last mlp_chain_tile of workgroup 0, wave 0 (entry, gather issued, layer 1, middle layers, last layer, epilogue):", [int(ct[i + 1] - ct[i]) for i in range(5)])
-    print("  middle linear repeated through one copy of its code (diagnostic; first pass = cold I-cache):", [int(ct[7 + i] - ct[6 + i]) for i in range(3)])
-    print("  layer 1: multi_channel MFMA task (wave 3):", int(ct[11] - ct[10]), " pair loop (wave 3):", int(ct[12] - ct[11]), " pair loop (wave 0):", int(ct[14] - ct[13]))
-    hw = dfull[B + 192:B + 192 + (min(B, 1024) + 15) // 16].reshape(-1, 4)[:min(B, 1024)]
-    simd = (hw >> 4) & 3
-    cu = ((hw >> 8) & 15) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5)
-    print("SIMD of waves 0..3, first 12 workgroups:", simd[:12].tolist())
-    print("workgroups whose waves sit on SIMDs 0,1,2,3 in order:", int((simd == np.arange(4)[None, :]).all(axis=1).sum()), "of", len(simd),
-          "; all four on distinct SIMDs:", int((np.sort(simd, axis=1) == np.arange(4)[None, :]).all(axis=1).sum()))
-    groups = {}
-    for bb in range(len(cu)):
-        groups.setdefault((bb % 8, int(cu[bb, 0])), []).append(bb)
-    print("workgroups sharing (b % 8, CU id) -- first 6 groups:", [v for _, v in sorted(groups.items())[:6]])
+    print("hodge branch head, workgroup 0 wave 0: stage mlp blocks, s_hd fill, s_p1c, s_hq fill (until the barrier):", [int(ct[i + 1] - ct[i]) for i in range(6, 10)])
