@@ -38,6 +38,10 @@ __device__ long long g_ct[16];
 CCSD_DEV void stamp(long long* dbg, int slot) {
 #ifndef CCSD_EMU
     if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 64 + slot] = (long long)__builtin_readcyclecounter();
+    // slot 0 / the kernel's last slot also leave the constant 100 MHz counter two slots from the end of the kernel's half-row:
+    // shader clock = cycles / real time (tools/stamps.py)
+    if (dbg && threadIdx.x == 0 && slot == 0) dbg[(size_t)blockIdx.x * 64 + 30] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (dbg && threadIdx.x == 0 && (slot == 5 || slot == 14)) dbg[(size_t)blockIdx.x * 64 + 31] = (long long)__builtin_amdgcn_s_memrealtime();
 #else
     (void)dbg; (void)slot;
 #endif

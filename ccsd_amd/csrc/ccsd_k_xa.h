@@ -855,7 +855,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
     if ((tid & 63) == 0 && blockIdx.x < 4096) {
         long long* r = g_bar + (size_t)blockIdx.x * 16 + (tid >> 6);
         if (xa.dbg) xa.dbg[(size_t)blockIdx.x * 64 + 26 + (tid >> 6)] = r[0];     // slots 26..29: barrier cycles of waves 0..3
-        if (xa.dbg && tid == 0) xa.dbg[(size_t)blockIdx.x * 64 + 30] = r[8];      // slot 30: barriers passed
+        if (xa.dbg && tid == 0) xa.dbg[(size_t)blockIdx.x * 64 + 21] = r[8];      // slot 21: barriers passed
         // rows gridDim.x + 4 b + wave of the stamp buffer (the caller allocates gridDim.x + 256 rows): arrival clocks per barrier
         if (xa.dbg && blockIdx.x < 64 && (tid >> 6) < 4)
             for (int k = 0; k < 64; ++k)

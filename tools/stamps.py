@@ -18,7 +18,7 @@ eng = PCEngine(meta["params_x"], parts["x"], meta["params_adj"], parts["adj"], m
 flags = (bench.hist_flags(B, 9, bench.QM9_HIST) if Nn == 9 else bench.hist_flags(B, Nn, {Nn: 3, Nn - 2: 2, Nn - 5: 1})).cuda()
 st, sc, rs = eng.alloc_state(B), eng.alloc_state(B), eng.alloc_state(B)
 eng.init_state(flags, st, None, 1, 0)
-eng.run(flags, st, sc, rs, 1, 0, 0, 3)
+eng.run(flags, st, sc, rs, 1, 0, 0, int(os.environ.get("STAMPS_WARM_STEPS", "3")))      # (sustained-load clocks: STAMPS_WARM_STEPS=300)
 dbg = torch.zeros(B + 256, 64, dtype=torch.int64, device="cuda")   # (+256 rows: barrier arrival tables of the diagnostic build)
 eng.lib.check(eng.lib.ccsd_debug_stamps(eng.handle, C.c_void_p(dbg.data_ptr())))
 eng.predictor(5, st, flags, None, 1, 0, sc, None)
@@ -45,6 +45,11 @@ hs = [12, 16, 17, 18, 19, 20, 13]
 print("hodge: fill/hq0, dense pairs, deg, MFMA proj, diag att, scatter:", [int(np.median(x[:, hs[i + 1]] - x[:, hs[i]])) for i in range(6)])
 print("final MLP: chain (wave 0)", int(np.median(x[:, 11] - x[:, 13])), " wait barrier", int(np.median(x[:, 15] - x[:, 11])), " epilogue", int(np.median(x[:, 14] - x[:, 15])))
 print("k_r2 first-start to last-end cycles:", span, " k_xa:", x[:, 14].max() - x[:, 0].min())
+for nm, v, s0, s1 in (("k_r2", d[:, :32], 0, 5), ("k_xa", x, 0, 14)):
+    ok = v[:, s0] > 0
+    cyc = float(v[ok, s1].max() - v[ok, s0].min())
+    rt = float(v[ok, 31].max() - v[ok, 30].min()) / 100.0        # us (100 MHz counter)
+    print(f"{nm}: span {cyc:.0f} cycles = {rt:.1f} us of real time -> shader clock {cyc / rt / 1000:.2f} GHz; per-workgroup median {np.median(v[:, s1] - v[:, s0]):.0f} cycles")
 if os.environ.get("STAMPS_CKPT", "").endswith("Base_CC"):
     hb = [12, 16, 17, 18, 19, 20, 21, 13]
     print("baseline hodge: stage+hidden0, (to chunk 0), fill S, mlp_hodge chain, hidden rows + diag of layer 1, remaining chunks, head+scatter:",
@@ -53,9 +58,9 @@ print("layer 1, first channel group: bias fill + dinv, gcn tiles (+barrier), att
 print("layer 1 rest: edge MLP chain + node linear (+barrier), symmetrise/tanh:", [int(np.median(x[:, b] - x[:, a])) for a, b in ((24, 6), (6, 7))])
 if os.environ.get("STAMPS_BARRIERS"):
     life = x[:, 14] - x[:, 0]
-    print("k_xa barriers passed (wave 0):", int(np.median(x[:, 30])), " share of life inside __syncthreads(), waves 0..3:",
+    print("k_xa barriers passed (wave 0):", int(np.median(x[:, 21])), " share of life inside __syncthreads(), waves 0..3:",
           [round(float(np.median(x[:, 26 + k] / life)), 3) for k in range(4)])
-    nb = int(np.median(x[:, 30]))
+    nb = int(np.median(x[:, 21]))
     arr = dfull[B:B + 256].reshape(64, 4, 64)[:, :, :nb].astype(np.float64)     # [workgroup][wave][barrier]
     rel = arr.max(axis=1)                                                       # release ~ last arrival
     start = x[:64, 0].astype(np.float64)
