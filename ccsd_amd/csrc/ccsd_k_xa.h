@@ -64,6 +64,87 @@ CCSD_DEV void gcn_dinv(const float* a, float* dinv, int nc, int N) {
     }
 }
 
+// ScoreNetworkX (ScoreNetwork_X.py:102-132) by ONE wave, in three stages without a workgroup barrier between them (PlanD::x_late):
+// stage 0 = D^-1/2 + the GCN layers, stage 1 = the head MLP chain, stage 2 = mask + epilogue.  k_xa runs the stages on its last
+// wave inside the barrier intervals of the A-network's three edge-MLP chains, where that wave has no tile (E <= 48: three
+// 16-pair tiles for four waves) -- the X-network then costs the launch nothing but its input load.  Inputs: the (corrected) x and
+// adj in s_x / s_adj; everything else lives in the region at o_lx.  Returns this lane's (sum net^2, sum z^2) of the norms pass.
+struct XLateOut { float n2, z2; };
+CCSD_DEV void xlate_wave_sync() {
+#ifndef CCSD_EMU
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the wave's LDS writes before its (other lanes') LDS reads
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
+CCSD_DEV XLateOut xnet_late_stage(int stage, const PlanD& p, const float* __restrict__ w, const float* __restrict__ wp, float* sm,
+                                  const XaArgs& xa, const NoiseArgs& na, int b) {
+    XLateOut r{0.f, 0.f};
+    const int N = p.N, F = p.F, ldn = p.ldn, H = p.x_nhid;
+#ifdef CCSD_EMU
+    const int lane = 0, wsz = 1;
+#else
+    const int lane = threadIdx.x & 63, wsz = 64;
+#endif
+    const float* s_flags = sm + p.o_flags;
+    const float* s_x = sm + p.o_x;
+    const float* s_adj = sm + p.o_adj;
+    float* s_xcat = sm + p.o_lx;
+    float* s_h1 = s_xcat + p.x_fdim * ldn;
+    float* s_dinv = s_h1 + (F > 4 ? F : 4) * ldn;
+    if (stage == 0) {
+        for (int i = lane; i < N; i += wsz) {
+            float sdeg = 0.f;
+            for (int j = 0; j < N; ++j) sdeg += (i == j) ? 1.f : s_adj[i * N + j];
+            s_dinv[i] = 1.0f / sqrtf(fmaxf(sdeg, 1.f));
+        }
+        for (int t = lane; t < N * F; t += wsz) { const int i = t / F, f = t - i * F; s_xcat[f * ldn + i] = s_x[t]; }
+        xlate_wave_sync();
+        for (int l = 0; l < p.x_depth; ++l) {
+            const int fin = l ? H : F;
+            const float* src = s_xcat + (l ? (F + (l - 1) * H) : 0) * ldn;
+            const float* W = w + p.x_gw[l];
+            const float* B = w + p.x_gb[l];
+            float* dst = s_xcat + (F + l * H) * ldn;
+            for (int ct = 0; ct < (H + 15) >> 4; ++ct)
+                gcn_tile_n<true>(src, ldn, fin, N, s_adj, s_dinv, 16 * ct, H,
+                                 [&](int k, int col) { return W[k * H + col]; }, [&](int col) { return B[col]; },
+                                 [&](int i, int col, float v) { dst[col * ldn + i] = tanh_f(v); });
+            xlate_wave_sync();
+        }
+    } else if (stage == 1) {
+        const MlpD& m = p.x_fin;
+        auto epx = [&](int row, int f, float v) { s_h1[f * ldn + row] = v; };
+        auto ident = [](int rr) { return rr; };
+        for (int tile = 0; tile < (N + 15) >> 4; ++tile) {
+            if (m.chain == 2) mlp_chain_tile<2, 3, 1>(m, wp, s_xcat, ldn, s_xcat, m.in, 16 * tile, N, ident, epx);
+            else mlp_chain_tile<3, 6, 1>(m, wp, s_xcat, ldn, s_xcat, m.in, 16 * tile, N, ident, epx);
+        }
+        xlate_wave_sync();
+    } else {
+        for (int t = lane; t < N * F; t += wsz) {
+            const int i = t / F, f = t - i * F;
+            const float fl = s_flags[i];
+            const float net = s_h1[f * ldn + i] * fl;                   // mask_x, graph_utils.py:37
+            const size_t gi = (size_t)b * N * F + t;
+            if (xa.mode == MODE_SCORE) {
+                xa.out_x[gi] = xa.ss_x * net;
+            } else {
+                const float z = raw_noise_x(na, b, t, N * F) * fl;       // gen_noise(sym=False)
+                if (xa.mode == MODE_NORMS) {
+                    xa.out_x[gi] = net;
+                    r.n2 = fmaf(net, net, r.n2);
+                    r.z2 = fmaf(z, z, r.z2);
+                } else {
+                    const float mean = fmaf(xa.pa_x, s_x[t], xa.pb_x * net);
+                    if (xa.mean_x) xa.mean_x[gi] = mean;
+                    xa.out_x[gi] = fmaf(xa.pc_x, z, mean);
+                }
+            }
+        }
+    }
+    return r;
+}
+
 // GCH: the channel stack (every AttentionLayer's adjacency channels, the final MLP's input) does not fit LDS
 // (zinc250k, N = 38: 266 KB) and lives in a per-graph slab of the workspace instead; a workgroup's waves share one
 // CU and its L1, so __syncthreads() orders those global accesses exactly like the LDS ones.
@@ -97,6 +178,14 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
     float nx_net = 0.f, nx_z = 0.f, na_net = 0.f, na_z = 0.f;
 
     // ================= ScoreNetworkX (ScoreNetwork_X.py:102-132) =================
+    // (see xnet_late_stage) both networks on the same inputs, plan permitting: only the input load + fused corrector stay here
+    const bool x_late = VAR == XA_PLAIN && !GCH && p.x_late && xa.do_x && xa.do_a && xa.xA == xa.xX && xa.adjA == xa.adjX;
+    if (x_late) {
+        for (int i = tid; i < N * F; i += nth) s_x[i] = xa.xX[(size_t)b * N * F + i];
+        for (int i = tid; i < NN; i += nth) s_adj[i] = xa.adjX[(size_t)b * NN + i];
+        if (xa.cf.on) { __syncthreads(); corr_apply_xa(xa.cf, na, b, N, F, s_x, s_adj, s_flags); }
+        __syncthreads();
+    } else
     if (xa.do_x) {
         float* s_xcat = sm + p.o_xcat;
         float* s_h1 = sm + p.o_h1;
@@ -148,10 +237,12 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
 #define ATTN_LAYERS p.gl
 #define ATTN_NL p.x_depth
 #define ATTN_TAP(l) gmh_tap(l)
+#define ATTN_IDLE(l) (void)0
 #include "ccsd_attn_stack.inc"
 #undef ATTN_LAYERS
 #undef ATTN_NL
 #undef ATTN_TAP
+#undef ATTN_IDLE
         } else {
         gcn_dinv(s_adj, s_dinv, 1, N);
         for (int t = tid; t < N * F; t += nth) { int i, f; dF.divmod(t, i, f); s_xcat[f * ldn + i] = s_x[t]; }
@@ -291,10 +382,16 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
 #define ATTN_LAYERS p.al
 #define ATTN_NL p.a_L
 #define ATTN_TAP(l) (void)0
+#define ATTN_IDLE(l)                                                                                  \
+    if (x_late && (l) < 3 && wave_id == n_waves - 1) {                                                \
+        const XLateOut xr = xnet_late_stage((l), p, w, wp, sm, xa, na, b);                            \
+        nx_net += xr.n2; nx_z += xr.z2;                                                               \
+    }
 #include "ccsd_attn_stack.inc"
 #undef ATTN_LAYERS
 #undef ATTN_NL
 #undef ATTN_TAP
+#undef ATTN_IDLE
 
         stamp(xa.dbg, 12);
         // ---- hodge branch of ScoreNetworkA_CC (ScoreNetwork_A_CC.py:295-316)

@@ -109,6 +109,7 @@ struct PlanD {
     // layers >= 1: P1 = [E][h_pw] with layer l's wc_l columns at h_poff[l] (each earlier layer padded to 16), U1 = [h_pw]
     HodgeLayerD hlx[CCSD_MAXHLX];
     int h_pw, h_poff[CCSD_MAXHL + CCSD_MAXHLX];
+    int x_late, o_lx;             // ScoreNetworkX in the idle wave of the A-network's MLP-chain intervals (k_xa); its own LDS region
     int o_h2m, o_hM, o_hX;        // k_xa LDS (h_L > 2): second dense hodge buffer; M_j = sum_c w_c H_c of layers 1..h_L-2; two [E][wc] buffers
     // ScoreNetworkX_GMH (x_gmh = 1): x_depth AttentionLayers gl[] on g_cinit adjacency powers, g_nch channels in all
     int x_gmh, g_cinit, g_nch;
@@ -564,6 +565,17 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             if (p->x_gmh) p->x_lds_floats = o;
             best_total = o;
         }
+    }
+    // ScoreNetworkX late (k_xa): one wave runs it in three stages inside the A-network's edge-MLP intervals, where that wave has
+    // no tile.  Needs: the plain networks, a chained head, three AttentionLayers, at most three 16-pair tiles (E <= 48), node
+    // tiles of 16, and room for its own [x_fdim + max(F, 4)][ldn] + 16 floats inside the budget the layout already fits.
+    p->x_late = 0; p->o_lx = 0;
+    if (best_total > 0 && !p->x_gmh && !p->hb_L && !p->chan_global && p->x_fin.chain && p->a_L >= 3 && N <= 16 && E <= 48 &&
+        p->al[0].mlp.chain && p->al[1].mlp.chain && p->al[2].mlp.chain && getenv("CCSD_NO_XLATE") == nullptr) {
+        const int lx = (p->x_fdim + (F > 4 ? F : 4)) * p->ldn + 16;
+        int cap = 160 * 1024 / 4;
+        for (int q = NCAND - 1; q >= 0; --q) if (best_total * 4 <= budgets_b[q]) cap = budgets_b[q] / 4;
+        if (best_total + lx <= cap) { p->x_late = 1; p->o_lx = best_total; best_total += lx; p->xa_lds_floats = best_total; if (p->x_gmh) p->x_lds_floats = best_total; }
     }
     if (getenv("CCSD_VERBOSE"))
         fprintf(stderr, "[ccsd] k_xa LDS %d B (cg=%d pch=%d/%d pchp=%d/%d stage=%d floats, channel stack in %s)\n", best_total * 4, p->cg, p->pch, p->ldp, p->pchp, p->ldpp, p->wst_floats, p->chan_global ? "HBM" : "LDS");
