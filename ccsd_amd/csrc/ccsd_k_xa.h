@@ -64,10 +64,11 @@ CCSD_DEV void gcn_dinv(const float* a, float* dinv, int nc, int N) {
     }
 }
 
-// ScoreNetworkX (ScoreNetwork_X.py:102-132) by ONE wave, in three stages without a workgroup barrier between them (PlanD::x_late):
-// stage 0 = D^-1/2 + the GCN layers, stage 1 = the head MLP chain, stage 2 = mask + epilogue.  k_xa runs the stages on its last
-// wave inside the barrier intervals of the A-network's three edge-MLP chains, where that wave has no tile (E <= 48: three
-// 16-pair tiles for four waves) -- the X-network then costs the launch nothing but its input load.  Inputs: the (corrected) x and
+// ScoreNetworkX (ScoreNetwork_X.py:102-132) by ONE wave, in four stages without a workgroup barrier inside them (PlanD::x_late):
+// stage 0 = D^-1/2 + the first GCN layer, 1 = the other GCN layers, 2 = the head MLP chain, 3 = mask + epilogue.  k_xa runs them on
+// its last wave inside the barrier intervals in which that wave has no tile -- the edge-MLP chains of AttentionLayers 0 and 1, the
+// final MLP chain (E <= 48: three 16-pair tiles for four waves) and the A-network's epilogue -- so that the X-network costs the
+// launch little more than its input load (barrier table: profiles/r02_b_k_xa_barrier_intervals.txt).  Inputs: the (corrected) x and
 // adj in s_x / s_adj; everything else lives in the region at o_lx.  Returns this lane's (sum net^2, sum z^2) of the norms pass.
 struct XLateOut { float n2, z2; };
 CCSD_DEV void xlate_wave_sync() {
@@ -99,7 +100,9 @@ CCSD_DEV XLateOut xnet_late_stage(int stage, const PlanD& p, const float* __rest
         }
         for (int t = lane; t < N * F; t += wsz) { const int i = t / F, f = t - i * F; s_xcat[f * ldn + i] = s_x[t]; }
         xlate_wave_sync();
-        for (int l = 0; l < p.x_depth; ++l) {
+    }
+    if (stage == 0 || stage == 1) {
+        for (int l = stage ? 1 : 0; l < (stage ? p.x_depth : 1); ++l) {
             const int fin = l ? H : F;
             const float* src = s_xcat + (l ? (F + (l - 1) * H) : 0) * ldn;
             const float* W = w + p.x_gw[l];
@@ -111,7 +114,7 @@ CCSD_DEV XLateOut xnet_late_stage(int stage, const PlanD& p, const float* __rest
                                  [&](int i, int col, float v) { dst[col * ldn + i] = tanh_f(v); });
             xlate_wave_sync();
         }
-    } else if (stage == 1) {
+    } else if (stage == 2) {
         const MlpD& m = p.x_fin;
         auto epx = [&](int row, int f, float v) { s_h1[f * ldn + row] = v; };
         auto ident = [](int rr) { return rr; };
@@ -383,10 +386,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
 #define ATTN_NL p.a_L
 #define ATTN_TAP(l) (void)0
 #define ATTN_IDLE(l)                                                                                  \
-    if (x_late && (l) < 3 && wave_id == n_waves - 1) {                                                \
-        const XLateOut xr = xnet_late_stage((l), p, w, wp, sm, xa, na, b);                            \
-        nx_net += xr.n2; nx_z += xr.z2;                                                               \
-    }
+    if (x_late && (l) < 2 && wave_id == n_waves - 1) (void)xnet_late_stage((l), p, w, wp, sm, xa, na, b);
 #include "ccsd_attn_stack.inc"
 #undef ATTN_LAYERS
 #undef ATTN_NL
@@ -912,6 +912,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                 else if (m.chain == 4) mlp_chain<3, 5, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
                 else if (m.chain == 5) mlp_chain<3, 6, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
                 else mlp_chain<4, 7, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
+                if (x_late && wave_id == n_waves - 1) (void)xnet_late_stage(2, p, w, wp, sm, xa, na, b);
                 stamp(xa.dbg, 11);
             } else {
                 block_linear<1>(f0, ldf, s_chan + p0, NN, s_chan + p0, m.in, wf + m.w[0], wf + m.b[0], m.in, m.hid, rows);
@@ -943,6 +944,10 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                         xa.out_a[gi] = fmaf(xa.pc_a, z, mean);
                     }
                 }
+            }
+            if (x_late && wave_id == n_waves - 1) {
+                const XLateOut xr = xnet_late_stage(3, p, w, wp, sm, xa, na, b);
+                nx_net += xr.n2; nx_z += xr.z2;
             }
             __syncthreads();
         }

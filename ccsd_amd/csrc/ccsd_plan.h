@@ -566,12 +566,12 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             best_total = o;
         }
     }
-    // ScoreNetworkX late (k_xa): one wave runs it in three stages inside the A-network's edge-MLP intervals, where that wave has
-    // no tile.  Needs: the plain networks, a chained head, three AttentionLayers, at most three 16-pair tiles (E <= 48), node
+    // ScoreNetworkX late (k_xa): one wave runs it in stages inside the A-network's MLP-chain intervals, where that wave has
+    // no tile.  Needs: the plain networks, chained MLPs, two AttentionLayers, at most three 16-pair tiles (E <= 48), node
     // tiles of 16, and room for its own [x_fdim + max(F, 4)][ldn] + 16 floats inside the budget the layout already fits.
     p->x_late = 0; p->o_lx = 0;
-    if (best_total > 0 && !p->x_gmh && !p->hb_L && !p->chan_global && p->x_fin.chain && p->a_L >= 3 && N <= 16 && E <= 48 &&
-        p->al[0].mlp.chain && p->al[1].mlp.chain && p->al[2].mlp.chain && getenv("CCSD_NO_XLATE") == nullptr) {
+    if (best_total > 0 && !p->x_gmh && !p->hb_L && !p->chan_global && p->x_fin.chain && p->a_fin.chain && p->a_L >= 2 && N <= 16 && E <= 48 &&
+        p->al[0].mlp.chain && p->al[1].mlp.chain && getenv("CCSD_NO_XLATE") == nullptr) {
         const int lx = (p->x_fdim + (F > 4 ? F : 4)) * p->ldn + 16;
         int cap = 160 * 1024 / 4;
         for (int q = NCAND - 1; q >= 0; --q) if (best_total * 4 <= budgets_b[q]) cap = budgets_b[q] / 4;
