@@ -488,6 +488,48 @@ CCSD_DEV void mlp_chain_tile(const MlpD& m, const float* __restrict__ wp, const 
     const int l15 = lane & 15, kq = lane >> 4;
     const int prow = rowoff((p0 + l15 < rows) ? p0 + l15 : rows - 1);      // clamped: rows beyond `rows` are never stored
     const int in = m.in;
+    if constexpr (NI == 1 && NH == 1 && NO == 1) {
+        // The 16-wide MLP (the AttentionLayers' edge MLP): one float4 of weights and one of biases per linear and lane.  All of them
+        // are requested before the inputs are gathered -- otherwise every linear waits for its own plan-field scalar load and L2
+        // round trip (6.2 k cycles per tile for twelve MFMAs; barrier table, profiles/r02_b_k_xa_barrier_intervals.txt).
+        if (m.n <= 3) {
+            float4 wq[3], bq[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int ii = i < m.n ? i : m.n - 1;
+                wq[i] = *reinterpret_cast<const float4*>(wp + m.pw[ii] + 4 * lane);
+                bq[i] = *reinterpret_cast<const float4*>(wp + m.pb[ii] + 4 * kq);
+            }
+            chain_f32x4 a;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * kq + j;
+                const int kc = k < in ? k : in - 1;
+                const float* src = kc < ksplit ? X + kc * ldx : X2 + (kc - ksplit) * ldx;
+                a[j] = src[prow];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (i < m.n) {
+                    chain_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[i].x, a[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[i].y, a[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[i].z, a[2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[i].w, a[3], acc, 0, 0, 0);
+                    acc[0] += bq[i].x; acc[1] += bq[i].y; acc[2] += bq[i].z; acc[3] += bq[i].w;
+                    if (i < m.n - 1) { acc[0] = elu1_sel(acc[0]); acc[1] = elu1_sel(acc[1]); acc[2] = elu1_sel(acc[2]); acc[3] = elu1_sel(acc[3]); }
+                    a = acc;
+                }
+            }
+            const bool rok1 = p0 + l15 < rows;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 4 * kq + r;
+                if (f < m.out && rok1) epi(p0 + l15, f, a[r]);
+            }
+            return;
+        }
+    }
     chain_f32x4 xin[NI], h0[NH], h1[NH], yo[NO];
 #pragma unroll
     for (int t = 0; t < NI; ++t) {

@@ -71,4 +71,4 @@ if os.environ.get("STAMPS_BARRIERS"):
     for k in range(nb):
         print(f"  {k:3d} {dur[k]:9.0f}   " + " ".join(f"{busy[w, k]:7.0f}" for w in range(4)) + f"   at {np.median(rel[:, k] - start):8.0f}")
     ct = dfull[B + 255, :16].astype(np.int64)
-    print("hodge branch head, workgroup 0 wave 0: stage mlp blocks, s_hd fill, s_p1c, s_hq fill (until the barrier):", [int(ct[i + 1] - ct[i]) for i in range(6, 10)])
+    print("layer 1 edge-MLP interval, workgroup 0 wave 0: chain tile (entry, gather, linear 1, middle, last + epilogue), node MLP second Linear:", [int(ct[i + 1] - ct[i]) for i in range(0, 5)], int(ct[7] - ct[6]), int(ct[8] - ct[7]))
