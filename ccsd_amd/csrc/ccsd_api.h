@@ -639,7 +639,7 @@ static int corrector_norms(ccsd_plan* pl, int B, int step, int it, const ccsd_st
         ep.mode = MODE_NORMS; ep.out = w.net_r; ep.part = w.part;
         if ((st = launch_hf(pl, B, cur->rank2, ep, na, w, stream))) return st;
     }
-    CCSD_LAUNCH(k_normsum, dim3(1), dim3(CCSD_NTHREADS), 0, stream, (const float*)w.norm2, (const float*)w.part, B, ntiles,
+    CCSD_LAUNCH(k_normsum, dim3(1), dim3(CCSD_NTHREADS == 1 ? 1 : (B > 512 ? 1024 : B > 256 ? 512 : 256)), 0, stream, (const float*)w.norm2, (const float*)w.part, B, ntiles,
                 p.is_cc, sums);
     LAUNCH_CHECK();
     return CCSD_OK;

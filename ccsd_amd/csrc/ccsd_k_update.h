@@ -9,27 +9,46 @@
 // ---------------------------------------------------------------------------------------------
 __global__ void k_normsum(const float* __restrict__ norm2, const float* __restrict__ part, int B, int ntiles,
                           int is_cc, float* __restrict__ sums) {
-    __shared__ float red[64];
+    // up to 1024 threads: one sample per thread and one L2 round trip for B <= 1024; the six sums are reduced together (wave
+    // butterflies, one barrier, a fixed-order pass over the waves) -- the launch sits between the norms pass and the predictor
+    // kernels of every PC step, so its latency is on the step's critical path
+    __shared__ float red[16 * 6];
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        acc[0] += sqrtf(norm2[b * 4 + 0]);
-        acc[1] += sqrtf(norm2[b * 4 + 1]);
-        acc[3] += sqrtf(norm2[b * 4 + 2]);
-        acc[4] += sqrtf(norm2[b * 4 + 3]);
+        const float4 n4 = *reinterpret_cast<const float4*>(norm2 + (size_t)b * 4);
+        acc[0] += sqrtf(n4.x);
+        acc[1] += sqrtf(n4.y);
+        acc[3] += sqrtf(n4.z);
+        acc[4] += sqrtf(n4.w);
         if (is_cc) {
             float sn = 0.f, sz = 0.f;
             for (int t = 0; t < ntiles; ++t) {
-                sn += part[((size_t)b * ntiles + t) * 2 + 0];
-                sz += part[((size_t)b * ntiles + t) * 2 + 1];
+                const float* p2 = part + ((size_t)b * ntiles + t) * 2;
+                sn += p2[0];
+                sz += p2[1];
             }
             acc[2] += sqrtf(sn);
             acc[5] += sqrtf(sz);
         }
     }
+#ifdef CCSD_EMU
+    for (int i = 0; i < 6; ++i) sums[i] = acc[i];
+#else
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
-        const float t = block_sum(acc[i], red);
-        if (threadIdx.x == 0) sums[i] = t;
+        float v = acc[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[wave * 6 + i] = v;
     }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float t = 0.f;
+        for (int w = 0; w < nw; ++w) t += red[w * 6 + threadIdx.x];
+        sums[threadIdx.x] = t;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
