@@ -121,6 +121,13 @@ def test_one_step_vs_oracle_qm9_b64(lib):
                                      "Reverse", "Langevin", 0.2, 0.7)
 
 
+def test_one_step_vs_oracle_qm9_full_batch(lib):
+    """The BASELINE batch itself (B = 1024: four co-resident workgroups per CU in k_xa, two rounds of k_r2, ScoreNetworkX on the
+    idle wave) for one full PC step against the oracle on the same draws -- not only through size-independent properties."""
+    pc.case_one_step_vs_oracle_large("ccsd_qm9_CC", lib, DEV, 1024, [9, 9, 8, 9, 7, 9, 9, 6, 9, 5, 9, 9, 4, 9, 8, 9, 3, 9, 7, 2, 9, 1],
+                                     "Reverse", "Langevin", 0.2, 0.7, seed=11)
+
+
 def test_one_step_vs_oracle_community_small_cc_b4(lib):
     pc.case_one_step_vs_oracle_large("ccsd_community_small_CC", lib, DEV, 4, [20, 12, 16, 18], "Euler", "Langevin", 0.05, 0.7)
 
