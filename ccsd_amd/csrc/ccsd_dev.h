@@ -259,8 +259,8 @@ CCSD_DEV void small_mlp(const MlpD& m, const float* __restrict__ w, const float*
 // LDS: block q of an MLP = [8][8] weights (row = output) + [8] biases (72 floats).  All lanes read the same
 // addresses (LDS broadcast); padded rows/columns contribute exact zeros.
 #define CCSD_HWBLK 72
-CCSD_DEV void stage_mlp_blocks(const MlpD& m, const float* __restrict__ w, float* blk) {
-    for (int t = threadIdx.x; t < m.n * CCSD_HWBLK; t += blockDim.x) {
+CCSD_DEV void stage_mlp_blocks(const MlpD& m, const float* __restrict__ w, float* blk, int t0, int ts) {
+    for (int t = t0; t < m.n * CCSD_HWBLK; t += ts) {
         const int q = t / CCSD_HWBLK, r = t % CCSD_HWBLK;
         const int ni = mlp_in(m, q), no = mlp_out(m, q);
         float v = 0.f;

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_gemm_p(const float* __restrict__ rank2,
     const float* Wc = W + wcat_off;
     TileAcc acc;
     tile_zero(acc);
-    if (layer == 1) { stage_mlp_blocks(mval, W, s_mv); __syncthreads(); }
+    if (layer == 1) { stage_mlp_blocks(mval, W, s_mv, (int)threadIdx.x, (int)blockDim.x); __syncthreads(); }
     for (int k0 = 0; k0 < K; k0 += T_BK) {
         for (int idx = threadIdx.x; idx < T_BM * T_BK; idx += blockDim.x) {
             const int r = idx / T_BK, kk = idx % T_BK, k = k0 + kk, row = m0 + r;

@@ -352,19 +352,21 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
             }
             __syncthreads();
         }
-        // Hodge branch, early part: what depends only on the adjacency powers and the weights is staged here, in regions of
-        // their own, so that its L2 round trips overlap the attention stack's first phase instead of opening the hodge branch
-        if (VAR != XA_HB && p.h_L > 0) {
+        // Hodge branch, early part: what depends only on the adjacency powers and the weights -- the mlp_attention weight blocks, the
+        // diagonal hodge adjacency, P_1's per-edge factors -- is staged in regions of its own, by the threads t0, t0 + ts, ...:
+        // by the last wave inside the third AttentionLayer's edge-MLP interval when that wave is idle there (the late
+        // ScoreNetworkX's conditions + three layers), else by everybody right here
+        auto hodge_early = [&](int t0, int ts) {
             float* s_hd = sm + p.o_hd;
             float* s_hw = sm + p.o_hw;
             float* s_p1c = s_hd + p.a_nch_hodge * E;
             const HodgeLayerD& h0 = p.hl[0];
-            stage_mlp_blocks(p.hl[0].matt, w, s_hw);
-            if (p.h_L > 1) stage_mlp_blocks(p.hl[1].matt, w, s_hw + p.hw_stride);
-            if (VAR == XA_GEN) for (int l = 2; l < p.h_L; ++l) stage_mlp_blocks(ccsd_hl(p, l).matt, w, s_hw + l * p.hw_stride);
+            stage_mlp_blocks(p.hl[0].matt, w, s_hw, t0, ts);
+            if (p.h_L > 1) stage_mlp_blocks(p.hl[1].matt, w, s_hw + p.hw_stride, t0, ts);
+            if (VAR == XA_GEN) for (int l = 2; l < p.h_L; ++l) stage_mlp_blocks(ccsd_hl(p, l).matt, w, s_hw + l * p.hw_stride, t0, ts);
             // adj_to_hodgedual (cc_utils.py:1525-1536): diagonal hodge adjacency = upper triangle of the adjacency powers;
             // DenseHCNConv on a diagonal matrix (hodge_layers.py:185-193) is a row scaling
-            for (int t = tid; t < p.a_cinit * E; t += nth) {
+            for (int t = t0; t < p.a_cinit * E; t += ts) {
                 int c, e;
                 dE.divmod(t, c, e);
                 s_hd[t] = s_chan[c * NN + pair_off(e)];
@@ -374,19 +376,23 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
             // per edge [fl s | fl b]
             if (p.h_L > 1 && xa.p1_raw) {
                 const float mvb0 = w[h0.mval.b[0]];
-                for (int e = tid; e < E; e += nth) {
+                for (int e = t0; e < E; e += ts) {
                     float sc = 0.f;
                     for (int c = 0; c < h0.cin; ++c) sc = fmaf(w[h0.mval.w[0] + c], s_chan[c * NN + pair_off(e)], sc);
                     const float fl = s_flags[edge_i(e)] * s_flags[edge_j(e)];
                     s_p1c[e] = fl * sc; s_p1c[E + e] = fl * mvb0;
                 }
             }
-        }
+        };
+        const bool hodge_on = VAR != XA_HB && p.h_L > 0;
+        const bool hodge_idle = hodge_on && x_late && p.a_L >= 3;
+        if (hodge_on && !hodge_idle) hodge_early(tid, nth);
 #define ATTN_LAYERS p.al
 #define ATTN_NL p.a_L
 #define ATTN_TAP(l) (void)0
 #define ATTN_IDLE(l)                                                                                  \
-    if (x_late && (l) < 2 && wave_id == n_waves - 1) (void)xnet_late_stage((l), p, w, wp, sm, xa, na, b);
+    if (x_late && (l) < 2 && wave_id == n_waves - 1) (void)xnet_late_stage((l), p, w, wp, sm, xa, na, b);   \
+    if (hodge_idle && (l) == 2 && wave_id == n_waves - 1) hodge_early(tid - wave_id * (nth / n_waves), nth / n_waves);
 #include "ccsd_attn_stack.inc"
 #undef ATTN_LAYERS
 #undef ATTN_NL
