@@ -579,9 +579,25 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                 __syncthreads();
                 stamp(xa.dbg, 19);
                 const bool w4_1 = mlp_maxw(h1.matt) <= 4 && h1.cin <= 4;
-                for (int e = tid; e < E; e += nth) {
+#ifndef CCSD_EMU
+                // one lane per (edge, channel), 8 lanes per edge: the channel's attention logit, then the edge's lane 0 collects the
+                // eight and runs mlp_attention (one lane per edge walked the channels one after the other: 7.6 k cycles of a single
+                // wave while the other three waited)
+                for (int t0 = tid; t0 < ((8 * E + 63) & ~63); t0 += nth) {
+                    const int e = t0 >> 3, c = t0 & 7;
+                    float sacc = 0.f;
+                    if (e < E && c < h1.cin) {
+                        const float* q = s_hq + (c * E + e) * qw1;
+                        sacc = attn_logits(q, q + h1.adim, h1.nchunk, h1.dsplit, rks) * (1.0f / (float)h1.nchunk);
+                    }
                     float in[CCSD_SMALLW], out[CCSD_SMALLW];
 #pragma unroll
+                    for (int k = 0; k < CCSD_SMALLW; ++k) in[k] = __shfl(sacc, ((tid & 63) & ~7) + k, 64);
+                    if (c != 0 || e >= E) continue;
+                    if (w4_1) small_mlp_lds<4>(s_hw + p.hw_stride, h1.matt.n, in, out); else small_mlp_lds<CCSD_SMALLW>(s_hw + p.hw_stride, h1.matt.n, in, out);
+#else
+                for (int e = tid; e < E; e += nth) {
+                    float in[CCSD_SMALLW], out[CCSD_SMALLW];
                     for (int c = 0; c < CCSD_SMALLW; ++c) {
                         float sacc = 0.f;
                         if (c < h1.cin) {
@@ -591,6 +607,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                         in[c] = sacc;
                     }
                     if (w4_1) small_mlp_lds<4>(s_hw + p.hw_stride, h1.matt.n, in, out); else small_mlp_lds<CCSD_SMALLW>(s_hw + p.hw_stride, h1.matt.n, in, out);
+#endif
                     const float fh = s_flags[edge_i(e)] * s_flags[edge_j(e)];
 #pragma unroll
                     for (int o = 0; o < CCSD_SMALLW; ++o)
@@ -951,7 +968,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                     }
                 }
             }
-            if (x_late && wave_id == n_waves - 1) {
+            if (x_late && wave_id == (n_waves > 1 ? n_waves - 2 : 0)) {      // (the wave with the least of the A-network's epilogue)
                 const XLateOut xr = xnet_late_stage(3, p, w, wp, sm, xa, na, b);
                 nx_net += xr.n2; nx_z += xr.z2;
             }
