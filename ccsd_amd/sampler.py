@@ -75,17 +75,29 @@ def init_flags(obj_counts, config, batch_size: Optional[int] = None, is_cc: bool
 
 
 class Sampler:
-    """One class for the four reference samplers: `is_cc` and the dataset name select the behaviour."""
+    """Common body of the four reference samplers.  The subclasses below carry the reference's per-class differences:
+    `IS_MOL` (molecule datasets: one sampling round of sample.n_samples, quantize_mol + relabelling) and `APPLIES_EMA`
+    (Sampler_Graph / Sampler_CC copy the EMA weights into the models when sample.use_ema is set, sampler.py:177-186, 458-471;
+    Sampler_mol_Graph / Sampler_mol_CC never look at the switch, sampler.py:684-1240).  Instantiated directly, the class
+    picks both from the dataset name."""
+
+    IS_MOL: Optional[bool] = None
+    APPLIES_EMA: Optional[bool] = None
 
     def __init__(self, config) -> None:
         self.config = config if isinstance(config, AttrDict) else AttrDict(config)
         self.is_cc = bool(_get(self.config, "is_cc", False))
-        self.is_mol = _get(_get(self.config, "data"), "data") in ("QM9", "ZINC250k")
+        self.is_mol = self.IS_MOL if self.IS_MOL is not None else _get(_get(self.config, "data"), "data") in ("QM9", "ZINC250k")
+        self.applies_ema = self.APPLIES_EMA if self.APPLIES_EMA is not None else not self.is_mol
         self.device = loader.load_device()
         self.device0 = loader._device_id(self.device)
         sample = _get(self.config, "sample")
-        self.n_samples = _get(sample, "n_samples", None) if self.is_mol else None
+        # every class: sample.n_samples, else the SAMPLING config's data.batch_size, else None (sampler.py:116-118, 393-395, 705-707)
+        self.n_samples = _get(sample, "n_samples", _get(_get(self.config, "data"), "batch_size", None))
         self.divide_batch = _get(sample, "divide_batch", 1) or 1
+        # diff_traj has one consumer, the plotting code behind general_config.plotly_fig (sampler.py:329, 644, 983, 1402): it is
+        # recorded exactly when that switch is on (SURVEY.md section 7); `extra["keep_traj"]` overrides
+        self.keep_traj = bool(_get(_get(self.config, "general_config", {}), "plotly_fig", False))
         self.extra = {}          # forwarded to get_pc_sampler / S4_solver (rng, seed, keep_traj, group, lib, ...)
 
     def __repr__(self) -> str:
@@ -98,7 +110,7 @@ class Sampler:
         self.configt = self.ckpt_dict["config"]
         loader.load_seed(_get(cfg, "seed", 42))
         parts = ["x", "adj"] + (["rank2"] if self.is_cc else [])
-        use_ema = bool(_get(_get(cfg, "sample"), "use_ema", False))
+        use_ema = self.applies_ema and bool(_get(_get(cfg, "sample"), "use_ema", False))
         self.models = []
         for p in parts:
             sd = dict(self.ckpt_dict[f"{p}_state_dict"])
@@ -111,7 +123,7 @@ class Sampler:
         data = _get(cfg, "data")
         self.sampling_fn = loader.load_sampling_fn(self.configt, _get(cfg, "sampler"), _get(cfg, "sample"), self.device,
                                                    is_cc=self.is_cc, d_min=_get(data, "d_min"), d_max=_get(data, "d_max"),
-                                                   divide_batch=self.divide_batch, **self.extra)
+                                                   divide_batch=self.divide_batch, **dict({"keep_traj": self.keep_traj}, **self.extra))
         counts, self.n_test = train_node_counts(self.configt, with_test_size=True)
         if counts is None:
             with open(_COUNTS) as f:
@@ -129,27 +141,30 @@ class Sampler:
             self.node_counts = node_counts
         loader.load_seed(_get(_get(cfg, "sample"), "seed", 42))
         datat = _get(self.configt, "data")
+        # flags per chunk: n_samples // divide_batch, or the training batch size when no n_samples is configured
+        # (sampler.py:210-214, 498-502, 794-796, 1185-1187; init_flags' default, cc_utils.py:901-902)
+        qty = self.n_samples // self.divide_batch if self.n_samples is not None else None
         if self.is_mol:
-            qty = self.n_samples // self.divide_batch                        # sampler.py:1185-1187
             n_rounds = 1
         else:
-            qty = None
             bs = _get(datat, "batch_size")
-            n_rounds = rounds if rounds is not None else max(1, math.ceil(self.n_test / bs))   # sampler.py:488-490
-            if self.divide_batch > 1:
-                qty = bs // self.divide_batch
+            n_rounds = rounds if rounds is not None else max(1, math.ceil(self.n_test / bs))   # sampler.py:200-202, 488-490
         t0 = time.perf_counter()
         outs: List[List[torch.Tensor]] = []
         flags_all = []
+        diff_traj = []
         for _ in range(n_rounds):
             parts = None
             for _d in range(self.divide_batch):
                 fl = init_flags(self.node_counts, self.configt, qty, is_cc=self.is_cc).to(self.device0)
                 res = self.sampling_fn(*self.models, fl)
                 nt = 3 if self.is_cc else 2
+                if parts is None:
+                    diff_traj = res[-1]        # the first chunk's trajectory of the (last) round is the one kept (sampler.py:220, 511)
                 parts = list(res[:nt]) if parts is None else [torch.cat((a, b), dim=0) for a, b in zip(parts, res[:nt])]
                 flags_all.append(fl)
             outs.append(parts)
+        self.diff_traj = diff_traj
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         sampling_time = time.perf_counter() - t0
@@ -186,19 +201,19 @@ class Sampler:
 
 # the reference's four class names (sampler.py:92, 369, 684, 1061) and its factory (sampler.py:1438-1468)
 class Sampler_Graph(Sampler):
-    pass
+    IS_MOL, APPLIES_EMA = False, True
 
 
 class Sampler_CC(Sampler):
-    pass
+    IS_MOL, APPLIES_EMA = False, True
 
 
 class Sampler_mol_Graph(Sampler):
-    pass
+    IS_MOL, APPLIES_EMA = True, False
 
 
 class Sampler_mol_CC(Sampler):
-    pass
+    IS_MOL, APPLIES_EMA = True, False
 
 
 def get_sampler_from_config(config) -> Sampler:

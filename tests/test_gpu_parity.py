@@ -256,6 +256,7 @@ def test_ccsd_api_yaml_surface_on_gpu(lib, tmp_path):
     assert abs(corr.item()) < 0.05, f"divide_batch chunks are correlated: {corr.item():.3f}"
     out, c = H.run_harness(tmp_path, lib, None, "sample_enzymes_small_CC", H.ENZYMES_YAML, max_steps=10, rounds=1)
     assert out["adj"].shape[1:] == (12, 12) and torch.isfinite(out["rank2"]).all()
+    H.check_flags_against_reference_golden(out, "ENZYMES_small", 42, 64)      # (f)2: the reference's own init_flags
 
 
 def test_kat_hodge_layers_three_and_four(lib):

@@ -54,6 +54,40 @@ def test_init_flags_follows_the_numpy_stream():
     assert S.init_flags(counts, cfgt, 5).shape == (5, 20)
 
 
+def test_init_flags_matches_the_reference_golden():
+    """(f)2 pinned by the reference: tests/golden/g7_init_flags.npz holds init_flags(train_graph_list, config, batch) of the
+    reference (cc_utils.py:883-914) on its own load_data(get_list=True) split of the four shipped graph datasets, for several
+    numpy seeds and batch sizes (tools/make_golden.py::g7_init_flags).  The product reproduces the flags bit for bit from the
+    shipped node counts and leaves the numpy stream at the same position."""
+    from tests.helpers import load_golden
+
+    g = load_golden("g7_init_flags.npz")
+    meta = json.loads(str(g["meta"]))
+    assert set(meta) == {"community_small", "ego_small", "ENZYMES_small", "grid_small"}
+    for name, m in meta.items():
+        for is_cc in (False, True):          # the *_CC datasets are the same graphs in the same order (cc_utils.py:909-913)
+            cfgt = AttrDict({"data": {"data": name + ("_CC" if is_cc else ""), "max_node_num": m["max_node_num"], "batch_size": 24,
+                                      "test_split": 0.2}})
+            counts, n_test = S.train_node_counts(cfgt, with_test_size=True)
+            assert len(counts) == m["n_train"] and n_test == m["n_test"]
+            for case in m["cases"]:
+                np.random.seed(case["seed"])
+                fl = S.init_flags(counts, cfgt, case["batch"], is_cc=is_cc)
+                assert fl.dtype == torch.float32
+                assert torch.equal(fl, torch.from_numpy(g[case["key"]])), (name, case)
+                assert int(np.random.randint(0, 1 << 30)) == case["next_randint"], "numpy stream position differs"
+
+
+def check_flags_against_reference_golden(out, dataset, seed, batch):
+    """out["flags"] of a harness run against the reference's own init_flags for the same numpy seed (g7_init_flags.npz): the
+    first chunk of the first sampling round is drawn right after load_seed(sample.seed) (sampler.py:198-218)."""
+    from tests.helpers import load_golden
+
+    g = load_golden("g7_init_flags.npz")
+    want = torch.from_numpy(g[f"{dataset}/s{seed}_b{batch}"])
+    assert torch.equal(out["flags"][:batch].cpu(), want), f"init_flags of {dataset} differs from the reference's"
+
+
 def run_harness(tmp_path, lib, device_patch, name, cfg, max_steps, **kw):
     write_cfg(tmp_path, name, cfg)
     c = CCSD("sample", name + ".yaml", folder=str(tmp_path), seed=42)
@@ -94,6 +128,7 @@ def test_ccsd_sample_enzymes_s4_ema_yaml(tmp_path):
     B = c.sampler.configt.data.batch_size
     assert out["adj"].shape == (B, 12, 12) and out["rank2"].shape[0] == B
     assert set(out["adj_int"].unique().tolist()) <= {0, 1}
+    check_flags_against_reference_golden(out, "ENZYMES_small", 42, 64)
     ema = c.sampler.ckpt_dict["ema_adj"]
     sd = c.sampler.models[1].state_dict()
     k = next(iter(ema))
@@ -120,3 +155,38 @@ def test_harness_identical_seed_vs_oracle(tmp_path):
     from tests.emu_util import emu_library
 
     pc.case_harness_vs_oracle(emu_library(), tmp_path, "sample_qm9_CC_parity", QM9_CC_YAML, "ccsd_qm9_CC", max_steps=3)
+
+
+def test_mol_samplers_ignore_use_ema(tmp_path):
+    """Sampler_mol_Graph / Sampler_mol_CC never read sample.use_ema (the reference's classes contain no EMA code at all,
+    sampler.py:684-1240), Sampler_Graph / Sampler_CC copy the EMA weights (sampler.py:177-186, 458-471): a molecule YAML with
+    use_ema: True gives the samples of the plain run."""
+    from tests.emu_util import emu_library
+
+    plain, _ = run_harness(tmp_path, emu_library(), None, "sample_qm9_CC", QM9_CC_YAML, max_steps=2)
+    cfg = dict(QM9_CC_YAML, sample=dict(QM9_CC_YAML["sample"], use_ema=True))
+    ema, c = run_harness(tmp_path, emu_library(), None, "sample_qm9_CC_ema", cfg, max_steps=2)
+    assert type(c.sampler).__name__ == "Sampler_mol_CC" and not c.sampler.applies_ema
+    for k in ("x", "adj", "rank2", "adj_int"):
+        assert torch.equal(plain[k], ema[k]), k
+    k = next(iter(c.sampler.ckpt_dict["adj_state_dict"]))
+    assert torch.equal(c.sampler.models[1].state_dict()[k].cpu(), c.sampler.ckpt_dict["adj_state_dict"][k])
+    assert S.Sampler_CC.APPLIES_EMA and S.Sampler_Graph.APPLIES_EMA and not S.Sampler_mol_Graph.APPLIES_EMA
+
+
+def test_plotly_fig_switches_diff_traj(tmp_path):
+    """diff_traj is recorded exactly when general_config.plotly_fig is on -- its only consumer is the plotting code behind that
+    switch (sampler.py:329, 644, 983, 1402); one [x[0], adj[0], rank2[0]] entry per executed PC step
+    (solver.py:1150-1157), the first divide_batch chunk's trajectory (sampler.py:1195)."""
+    from tests.emu_util import emu_library
+
+    out, c = run_harness(tmp_path, emu_library(), None, "sample_qm9_CC", QM9_CC_YAML, max_steps=2)
+    assert c.sampler.keep_traj is False and c.sampler.diff_traj == []
+    with open(tmp_path / "config" / "general_config.yaml", "w") as f:
+        yaml.safe_dump({"plotly_fig": True, "print_initial": False}, f)
+    out, c = run_harness(tmp_path, emu_library(), None, "sample_qm9_CC", QM9_CC_YAML, max_steps=2)
+    assert c.sampler.keep_traj is True
+    traj = c.sampler.diff_traj
+    assert len(traj) == 2 and [tuple(t.shape) for t in traj[0]] == [(9, 4), (9, 9), (36, 466)]
+    # the last entry holds sample 0 of the first chunk's returned (denoised) tensors
+    assert torch.equal(traj[-1][1].cpu(), out["adj"][0].cpu()) and torch.equal(traj[-1][2].cpu(), out["rank2"][0].cpu())

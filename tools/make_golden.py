@@ -220,6 +220,33 @@ def g6_masks():
     np.savez_compressed(os.path.join(GOLD, "g6_masks_utils.npz"), **out)
 
 
+def g7_init_flags():
+    """(f)2: `init_flags` of the reference on the shipped graph datasets (cc_utils.py:883-914 with is_cc=False: graphs_to_tensor +
+    np.random.randint over the train split + node_flags, graph_utils.py:62-77), fed by the reference's own
+    load_data(config, get_list=True) (data_loader.py:64-88).  One numpy seed per (dataset, batch).  The *_CC pickles hold
+    toponetx objects and cannot be read here; the CC branch takes node_flags of the complexes' adjacency (cc_utils.py:909-913),
+    i.e. of the same graphs in the same file order, so the graph-dataset flags pin both samplers."""
+    from ccsd.src.utils.data_loader import dataloader as ref_dataloader
+
+    out = {}
+    meta = {}
+    for name, N in (("community_small", 20), ("ego_small", 18), ("ENZYMES_small", 12), ("grid_small", 49)):
+        cfg = refshim.EasyDict({"folder": refshim.REFERENCE_ROOT,
+                                "data": {"data": name, "dir": "data", "batch_size": 24, "test_split": 0.2, "max_node_num": N}})
+        train, test = ref_dataloader(cfg, get_graph_list=True)
+        meta[name] = {"max_node_num": N, "n_train": len(train), "n_test": len(test), "cases": []}
+        for seed, batch in ((12, None), (42, 7), (42, 64), (42, 128), (2024, 129)):
+            np.random.seed(seed)
+            fl = ref_cc.init_flags(train, cfg, batch)
+            after = int(np.random.randint(0, 1 << 30))          # the stream position the call leaves behind
+            key = f"{name}/s{seed}_b{batch or 0}"
+            out[key] = fl.numpy().astype(np.float32)
+            meta[name]["cases"].append({"seed": seed, "batch": batch, "key": key, "next_randint": after})
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(GOLD, "g7_init_flags.npz"), **out)
+    print("wrote g7_init_flags", {k: v["n_train"] for k, v in meta.items()})
+
+
 def g5_pc_runs(name, ck, is_cc, B, counts, sampler_cfg, cases, seed, min_dist=0.0):
     """Wrapper: when `min_dist` is given, the seed is advanced (by 100) until every case's final adjacency stays at least
     that far from every quantisation threshold, so that the bit-exact integer comparison has a margin."""
@@ -616,6 +643,8 @@ def main():
         g3_sde_tables()
     if not only or "g6" in only:
         g6_masks()
+    if not only or "g7" in only:
+        g7_init_flags()
     if not only or "kat" in only:
         kat_small_models()
     if not only or "g1" in only:
