@@ -68,8 +68,15 @@ WORKLOADS = {
 # Kernels of the step (profiles/README.md).  k_xa evaluates ScoreNetworkX + ScoreNetworkA(_CC) once per launch (fp32 MFMA /
 # issue bound); the rank-2 side (ScoreNetworkF + hodge projections) reads rank2 (E*K fp32) once and writes it once per
 # half-step (HBM bound): fused k_r2 when the block fits LDS (qm9_CC), k_gemm_h + k_gemm_p + k_hf_score otherwise.
-KERNEL_BOUND = {"k_xa": "mfma", "k_r2": "hbm", "k_hf_score": "hbm", "k_gemm_h": "mfma", "k_gemm_p": "mfma", "k_langevin_apply": "hbm",
+# `bound` of a roofline object: kernels that have both an algorithmic byte count and an as-written FLOP count (k_r2, k_hf_score)
+# report BOTH fractions and take the larger one as the binding roofline; the entry here is the fallback when only
+# one of the two figures exists.  Neither roofline is what actually limits k_r2 / k_xa: they are bound by vector-instruction
+# issue (on gfx950 an fp32 MFMA and VALU work share the SIMD's vector pipe), reported as `issue_frac`.
+KERNEL_BOUND = {"k_xa": "mfma", "k_r2": "mfma", "k_hf_score": "hbm", "k_gemm_h": "mfma", "k_gemm_p": "mfma", "k_langevin_apply": "hbm",
                 "k_s4_apply": "hbm"}
+KERNEL_LIMITER = {"k_r2": "vector-instruction issue: fp32 MFMA (32 cycles each) and VALU (2 cycles each) share one pipe per SIMD",
+                  "k_xa": "latency of one graph's critical path (barrier intervals), then vector-instruction issue"}
+N_SIMDS, MAX_CLOCK_HZ = 1024, 2.4e9                       # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md chip table
 KERNEL_NAMES = ["k_xa", "k_r2", "k_hf_score", "k_gemm_h", "k_gemm_p", "k_langevin_apply", "k_s4_apply"]
 PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r02_pmc.json", "r01_pmc_traffic.json")]   # newest first
 KERNEL_SOURCES = [os.path.join(ROOT, "ccsd_amd", "csrc", f) for f in ("ccsd_dev.h", "ccsd_rank2_common.h", "ccsd_k_rank2.h", "ccsd_k_r2.h", "ccsd_k_xa.h", "ccsd_k_update.h", "ccsd_attn_stack.inc", "ccsd_plan.h", "ccsd_api.h")]
@@ -191,8 +198,32 @@ def cpu_baseline(wname: str, B: int, budget_s: float = 25.0):
     make(steps)(*nets, flags)
     dt = (time.perf_counter() - t0) / steps
     log(f"cpu_baseline: {dt:.2f} s / PC step")
-    return {"value": B / (dt * 1000.0), "unit": "complexes/s at 1000 PC steps", "cores": threads, "kind": "port",
-            "sample": f"oracle (torch CPU, {threads} threads), {wname} B={B}, {steps} PC steps after 1 warm-up step, scaled to 1000 steps"}
+    out = {"value": B / (dt * 1000.0), "unit": "complexes/s at 1000 PC steps", "cores": threads, "kind": "port",
+           "sample": f"oracle (torch CPU, {threads} threads), {wname} B={B}, {steps} PC steps after 1 warm-up step, scaled to 1000 steps"}
+    cert = cpu_baseline_cert()
+    if cert:          # how the oracle's wall time relates to the real reference's (measured in the build container, tools/certify_cpu_baseline.py)
+        r = cert["oracle_over_reference_time"]
+        out["reference_time_ratio"] = r
+        out["reference_equivalent_value"] = out["value"] * r
+        out["certificate"] = cert["_file"]
+        out["sample"] += (f"; the oracle is bit-identical to the reference and takes {r:.2f}x the reference's wall time "
+                          f"({cert['workload']}; {cert['_file']}): the reference itself would run at ~{out['value'] * r:.3f} complexes/s here")
+    return out
+
+
+def cpu_baseline_cert():
+    """Newest profiles/rNN_cpu_baseline_cert.json (written by tools/certify_cpu_baseline.py in the build container)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_baseline_cert.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+    except Exception:
+        return None
+    d["_file"] = os.path.relpath(files[-1], ROOT)
+    return d
 
 
 def kernel_work(wname: str, kname: str, E: int, K: int):
@@ -202,7 +233,8 @@ def kernel_work(wname: str, kname: str, E: int, K: int):
         f = None if wl["flop_x"] is None else wl["flop_x"] + wl["flop_a"]
         return f, None, "dense-as-written GEMM FLOPs of ScoreNetworkX + ScoreNetworkA(_CC) (SURVEY 8a)"
     if kname in ("k_r2", "k_hf_score"):
-        return wl["flop_f"], 2 * E * K * 4, "read + write of rank2 (E*K fp32 each)"
+        return wl["flop_f"], 2 * E * K * 4, ("FLOPs: dense-as-written GEMM FLOPs of ScoreNetworkF (SURVEY 8a); bytes: read + write of rank2 "
+                                             "(E*K fp32 each)")
     if kname in ("k_langevin_apply", "k_s4_apply"):
         return None, 3 * E * K * 4, "read state + raw score, write state (rank2 dominates)"
     if kname == "k_gemm_p" and wl.get("wc"):
@@ -221,8 +253,14 @@ def roofline_obj(wname, kname, kt, B, dt, E, K):
     flops, nbytes, what = kernel_work(wname, kname, E, K)
     pmc = pmc_counters(wname, kname)
     bound = KERNEL_BOUND[kname]
+    hbm_frac = nbytes * B / avg_s / 1e9 / PEAK_HBM_GBPS if nbytes else None
+    mfma_frac = flops * B / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS if flops else None
+    if hbm_frac is not None and mfma_frac is not None:     # both figures exist: the binding roofline is the larger fraction
+        bound = "mfma" if mfma_frac >= hbm_frac else "hbm"
     o = {"kernel": kname, "bound": bound, "launches": total, "launches_timed": sampled, "avg_launch_us": avg_s * 1e6,
-         "share_of_step": total * avg_s / dt, "traffic": None}
+         "share_of_step": total * avg_s / dt, "traffic": None, "hbm_frac": hbm_frac, "mfma_frac_as_written": mfma_frac}
+    if kname in KERNEL_LIMITER:
+        o["limiter"] = KERNEL_LIMITER[kname]
     if pmc:
         c = pmc["counters"]
         o["traffic"] = c.get("hbm_bytes_per_launch")
@@ -233,6 +271,13 @@ def roofline_obj(wname, kname, kt, B, dt, E, K):
             ex = mf * MFMA_FLOP / avg_s / 1e12
             o["executed_mfma_tflops"] = ex
             o["executed_frac"] = ex / PEAK_F32_MFMA_TFLOPS       # what the matrix pipe actually did (dead GEMMs skipped, padding included)
+            va = c.get("SQ_INSTS_VALU")
+            if va:
+                # vector-issue cycles per launch: 32 per fp32 16x16x4 MFMA + 2 per other VALU wave-instruction (SQ_INSTS_VALU counts
+                # the MFMAs too), over what 1024 SIMDs offer at the 2.4 GHz maximum clock in the launch's time
+                cyc = mf * 32.0 + max(va - mf, 0.0) * 2.0
+                o["issue_cycles_per_launch"] = cyc
+                o["issue_frac"] = cyc / (N_SIMDS * MAX_CLOCK_HZ * avg_s)
     if bound == "mfma" and flops:
         a = flops * B / avg_s / 1e12
         o.update(achieved=a, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=a / PEAK_F32_MFMA_TFLOPS,
@@ -360,15 +405,31 @@ def _main(real_stdout):
         # every n-th launch: dense bracketing costs ~6 % of the step.  Short runs bracket more densely so that the roofline
         # object always has samples.
         eng.profile_stride(args.event_stride if args.steps >= 200 else 3 if args.steps >= 20 else 1)
+    if world > 1:
+        sampling_fn.timing, sampling_fn.gather_seconds = True, 0.0   # split [local loop | final all-gather] per rank (diagnostic)
     sync()
     t0 = time.perf_counter()
     outs = run(args.steps)
+    if dev != "cpu":
+        torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0                              # this rank's own time, before it waits for the others
     sync()
     dt = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
+        mine = torch.tensor([dt_local, sampling_fn.gather_seconds], device=dev, dtype=torch.float64)
+        allr = torch.empty(world, 2, device=dev, dtype=torch.float64)
+        if mine.is_cuda:
+            dist.all_gather_into_tensor(allr, mine)
+        else:
+            dist.all_gather(list(allr.unbind(0)), mine)
+        per_rank = [{"rank": r, "ms_per_step": (allr[r, 0].item() - allr[r, 1].item()) * 1e3 / args.steps,
+                     "all_gather_ms": allr[r, 1].item() * 1e3, "region_ms": allr[r, 0].item() * 1e3} for r in range(world)]
+        log(f"rank {rank}: local loop {(dt_local - sampling_fn.gather_seconds) * 1e3 / args.steps:.4f} ms/step, final all-gather "
+            f"{sampling_fn.gather_seconds * 1e3:.2f} ms")
     log(f"timed region: {args.steps} steps in {dt:.3f} s")
     ktimes = {}
     if not args.no_kernel_events:
@@ -400,6 +461,8 @@ def _main(real_stdout):
             "roofline": roofline_obj(wname, dominant, ktimes[dominant], B, dt, E, K) if dominant else None,
             "cpu_baseline": None,
         }
+        if per_rank is not None:     # per-rank split of the timed region: PC-step time without the final all-gather, and the all-gather
+            line["per_rank"] = per_rank
         if args.emulate:
             line["data"] = "EMULATION (host CPU, test of the launcher path only): " + line["data"]
         for k in live[1:]:

@@ -13,7 +13,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(HERE, "libccsd_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_WEIGHTS, ERR_RUNTIME, ERR_WORKSPACE = range(6)
 SDE_VP, SDE_VE, SDE_SUBVP = 0, 1, 2
 PRED_EULER, PRED_REVERSE, PRED_S4 = 0, 1, 2
@@ -24,7 +24,9 @@ EXPORTS = [
     "ccsd_plan_create", "ccsd_plan_destroy", "ccsd_weight_count", "ccsd_rank2_dims", "ccsd_workspace_bytes",
     "ccsd_last_error", "ccsd_score", "ccsd_init_state", "ccsd_corrector_norms", "ccsd_corrector_apply",
     "ccsd_predictor", "ccsd_s4_apply", "ccsd_sampler_run", "ccsd_quantize", "ccsd_rank2_cells", "ccsd_profile_kernel", "ccsd_profile_stride", "ccsd_profile_read", "ccsd_profile_launches", "ccsd_debug_stamps",
+    "ccsd_noise_draws", "ccsd_plan_query",
 ]
+QUERIES = {"fused_r2": 0, "xa_variant": 1, "r2_lds_bytes": 2, "xa_lds_bytes": 3, "fused_loop": 4}
 KERNEL_IDS = {"k_xa": 0, "k_gemm_p": 1, "k_hf_score": 2, "k_gemm_h": 3, "k_langevin_apply": 4, "k_r2": 5, "k_s4_apply": 6}
 
 
@@ -123,6 +125,10 @@ class Library:
         L.ccsd_profile_launches.restype = C.c_int
         L.ccsd_debug_stamps.argtypes = [vp, vp]
         L.ccsd_debug_stamps.restype = C.c_int
+        L.ccsd_noise_draws.argtypes = [vp, i32, vp, u64, i64, i32, i32, P(State), vp]
+        L.ccsd_noise_draws.restype = C.c_int
+        L.ccsd_plan_query.argtypes = [vp, i32, P(i64)]
+        L.ccsd_plan_query.restype = C.c_int
 
     def __getattr__(self, name):
         return getattr(self.c, name)

@@ -117,12 +117,16 @@ static inline void r2_shape(const ccsd_plan* pl, int* MT, int* RS, bool* aff, bo
         if (aff_ && !gen1_) { X(MT_, RS_, true, false); } else if (aff_) { X(MT_, RS_, true, true); } \
         else if (!gen1_) { X(MT_, 0, false, false); } else { X(MT_, 0, false, true); } \
     }
+// non-affine ScoreNetworkF: RS is always 0 (r2_shape), every MT has its instance (CCSD_R2_GEN)
+#define R2_CASE_GEN(MT_, X) \
+    if (!aff_ && mt_ == MT_) { if (!gen1_) { X(MT_, 0, false, false); } else { X(MT_, 0, false, true); } }
 #define R2_DISPATCH(pl_, X) \
     do { \
         int mt_, rs_; bool aff_, gen1_; \
         r2_shape(pl_, &mt_, &rs_, &aff_, &gen1_); \
         /* E = N (N - 1) / 2 <= 64, i.e. E in {1, 3, 6, 10, 15, 21, 28, 36, 45, 55}: the (MT, RS) pairs that occur */ \
-        R2_CASE(1, 0, X) else R2_CASE(1, 1, X) else R2_CASE(1, 2, X) else R2_CASE(1, 3, X) \
+        R2_CASE_GEN(1, X) else R2_CASE_GEN(2, X) else R2_CASE_GEN(3, X) else R2_CASE_GEN(4, X) \
+        else R2_CASE(1, 0, X) else R2_CASE(1, 1, X) else R2_CASE(1, 2, X) else R2_CASE(1, 3, X) \
         else R2_CASE(2, 2, X) else R2_CASE(2, 3, X) else R2_CASE(3, 0, X) else R2_CASE(3, 1, X) else R2_CASE(4, 2, X) \
     } while (0)
 static inline const void* r2_kernel(const ccsd_plan* pl) {
@@ -549,6 +553,9 @@ static NoiseArgs make_noise(const ccsd_noise_t* n, uint64_t seed, int64_t off, u
     return na;
 }
 
+// does ccsd_sampler_run fuse the Langevin corrector's apply pass into the predictor launches of this plan?
+static inline bool fused_apply_ok(const ccsd_plan* pl) { return pl->fused_r2 && !pl->opt_no_fused_apply; }
+
 // ---------------- API ----------------
 extern "C" int ccsd_score(ccsd_plan_t* pl, int32_t target, int32_t B, const ccsd_state_t* in, const float* flags,
                           float sscale, float* out, void* workspace, size_t ws_bytes, void* stream) {
@@ -578,18 +585,20 @@ extern "C" int ccsd_score(ccsd_plan_t* pl, int32_t target, int32_t B, const ccsd
     return set_err(CCSD_ERR_UNSUPPORTED, "Object not yet supported. Select from [x, adj, rank2].");
 }
 
-extern "C" int ccsd_init_state(ccsd_plan_t* pl, int32_t B, const float* flags, const ccsd_noise_t* prior, uint64_t seed,
-                               int64_t sample_offset, ccsd_state_t* state, void* stream) {
+// masked draws of one draw base into `state` (k_init_state): the prior for base 0, the noise of a half-step otherwise
+static int draws_to_state(ccsd_plan* pl, int32_t B, const float* flags, const ccsd_noise_t* raw, uint64_t seed, int64_t sample_offset,
+                          unsigned int base, ccsd_state_t* state, void* stream) {
     if (!pl || B < 1 || !flags) return set_err(CCSD_ERR_INVALID, "bad argument");
     int st = check_state(pl, state, "state");
     if (st) return st;
     const PlanD& p = pl->h;
     // this call takes no workspace: the off-bit table lives in a plan-owned buffer that only ever grows, so the call stays
-    // asynchronous on `stream` (launches that use the buffer are ordered on it; a plan is reentrant per handle only)
+    // asynchronous on `stream`.  A plan is reentrant per handle only and its calls belong on ONE stream (include/ccsd_hip.h):
+    // when the buffer has to grow, the whole device is drained first, whatever stream an earlier call used
     if (pl->init_off_cap < (size_t)B) {
         if (pl->init_off) {
 #ifndef CCSD_EMU
-            (void)hipStreamSynchronize((hipStream_t)stream);     // an earlier init on this stream may still read the old buffer
+            (void)hipDeviceSynchronize();
 #endif
             (void)rt_free(pl->init_off);
             pl->init_off = nullptr; pl->init_off_cap = 0;
@@ -599,12 +608,42 @@ extern "C" int ccsd_init_state(ccsd_plan_t* pl, int32_t B, const float* flags, c
     }
     unsigned long long* offbits = pl->init_off;
     CCSD_LAUNCH(k_flagbits, dim3(grid_for(B, 256)), dim3(CCSD_NTHREADS), 0, stream, flags, offbits, B, p.N);
-    NoiseArgs na = make_noise(prior, seed, sample_offset, 0);
+    NoiseArgs na = make_noise(raw, seed, sample_offset, base);
     const long long total = (long long)B * (p.N * p.F + p.N * p.N) + (p.is_cc ? (long long)B * ((p.E + 3) / 4) * p.K : 0);
     CCSD_LAUNCH(k_init_state, dim3(grid_for(total, 256)), dim3(CCSD_NTHREADS), 0, stream, state->x, state->adj, state->rank2,
                 flags, na, (const unsigned long long*)offbits, (const unsigned char*)pl->edges,
                 (const unsigned long long*)pl->cells, B, p.N, p.F, p.E, p.K, p.is_cc);
     LAUNCH_CHECK();
+    return CCSD_OK;
+}
+
+extern "C" int ccsd_init_state(ccsd_plan_t* pl, int32_t B, const float* flags, const ccsd_noise_t* prior, uint64_t seed,
+                               int64_t sample_offset, ccsd_state_t* state, void* stream) {
+    return draws_to_state(pl, B, flags, prior, seed, sample_offset, 0, state, stream);
+}
+
+extern "C" int ccsd_noise_draws(ccsd_plan_t* pl, int32_t B, const float* flags, uint64_t seed, int64_t sample_offset, int32_t step,
+                                int32_t phase, ccsd_state_t* out, void* stream) {
+    if (!pl) return set_err(CCSD_ERR_INVALID, "NULL plan");
+    const int per_step = pl->cfg.predictor == CCSD_PRED_S4 ? 3 : pl->cfg.n_corr_steps + 1;
+    if (step < 0 || step >= pl->cfg.diff_steps || phase < 0 || phase >= per_step) return set_err(CCSD_ERR_INVALID, "step / phase out of range");
+    return draws_to_state(pl, B, flags, nullptr, seed, sample_offset, draw_base(pl, step, phase), out, stream);
+}
+
+extern "C" int ccsd_plan_query(const ccsd_plan_t* pl, int32_t what, int64_t* value) {
+    if (!pl || !value) return set_err(CCSD_ERR_INVALID, "NULL argument");
+    switch (what) {
+        case CCSD_QUERY_FUSED_R2: *value = pl->fused_r2; break;
+        case CCSD_QUERY_XA_VARIANT: *value = xa_variant(pl->h); break;
+        case CCSD_QUERY_R2_LDS_BYTES: *value = (int64_t)pl->r2_lds; break;
+        case CCSD_QUERY_XA_LDS_BYTES: *value = (int64_t)pl->h.xa_lds_floats * 4; break;
+        case CCSD_QUERY_FUSED_LOOP: {   // ccsd_sampler_run fuses the Langevin apply into the predictor launches
+            const bool s4 = pl->cfg.predictor == CCSD_PRED_S4;
+            *value = (!s4 && pl->cfg.corrector == CCSD_CORR_LANGEVIN && pl->cfg.n_corr_steps == 1 && fused_apply_ok(pl)) ? 1 : 0;
+            break;
+        }
+        default: return set_err(CCSD_ERR_INVALID, "unknown query");
+    }
     return CCSD_OK;
 }
 
@@ -817,7 +856,7 @@ extern "C" int ccsd_sampler_run(ccsd_plan_t* pl, int32_t B, const float* flags, 
             if ((st = s4_apply(pl, B, step, &a, flags, nullptr, nullptr, nullptr, seed, sample_offset, w.sums, &b,
                                want_mean ? result : nullptr, w, stream))) return st;
             ccsd_state_t t = a; a = b; b = t;
-        } else if (lang && pl->fused_r2 && !pl->opt_no_fused_apply) {
+        } else if (lang && fused_apply_ok(pl)) {
             // a -> [norms pass] ; [apply fused into the predictor kernels] -> b ; swap roles
             if ((st = corrector_norms(pl, B, step, 0, &a, &a, flags, nullptr, seed, sample_offset, w.sums, w, stream))) return st;
             if ((st = predictor(pl, B, step, &a, flags, nullptr, seed, sample_offset, &b, want_mean ? result : nullptr, w, stream, w.sums))) return st;

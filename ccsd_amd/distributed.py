@@ -36,10 +36,11 @@ import torch.distributed as dist
 from . import loader
 
 
-def init(backend: Optional[str] = None) -> Tuple[int, int, str]:
+def init(backend: Optional[str] = None, force_group: bool = False, timeout_s: Optional[float] = None) -> Tuple[int, int, str]:
     """Join the process group described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (set by
     torch.distributed.run or by `launch_workers`).  Returns (rank, world, device).  backend: "nccl" (= RCCL on ROCm) when a GPU
-    is visible, else "gloo"."""
+    is visible, else "gloo".  A single process normally needs no group; `force_group` creates the 1-rank group anyway (the
+    RCCL code path -- init with device_id, all-gather / all-reduce on device tensors -- is then exercised on one GPU)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -47,19 +48,27 @@ def init(backend: Optional[str] = None) -> Tuple[int, int, str]:
     device = f"cuda:{local}" if gpu else "cpu"
     if gpu:
         torch.cuda.set_device(local)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
         be = backend or ("nccl" if gpu else "gloo")
+        kw = {}
+        if timeout_s is not None:
+            import datetime
+
+            kw["timeout"] = datetime.timedelta(seconds=timeout_s)
         if be == "nccl":
-            dist.init_process_group(be, rank=rank, world_size=world, device_id=torch.device(device))
+            dist.init_process_group(be, rank=rank, world_size=world, device_id=torch.device(device), **kw)
         else:
-            dist.init_process_group(be, rank=rank, world_size=world)
+            dist.init_process_group(be, rank=rank, world_size=world, **kw)
     return rank, world, device
 
 
-def all_gather_samples(tensors: Sequence[Optional[torch.Tensor]], group=None) -> List[Optional[torch.Tensor]]:
-    """Final sample collection: every rank contributes its shard (dim 0) and receives the whole batch."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+def all_gather_samples(tensors: Sequence[Optional[torch.Tensor]], group=None, force: bool = False) -> List[Optional[torch.Tensor]]:
+    """Final sample collection: every rank contributes its shard (dim 0) and receives the whole batch.  A 1-rank group is a
+    no-op unless `force` (which runs the collective anyway: the RCCL path on a single GPU)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return list(tensors)
     world = dist.get_world_size(group)
     out: List[Optional[torch.Tensor]] = []
@@ -103,9 +112,23 @@ def load_sampling_fn_sharded(config_train, config_module, config_sample, device,
             raise ValueError(f"init_flags must hold the whole batch of {total}, got {flags.shape[0]}")
         res = inner(*models, flags[rank * local:(rank + 1) * local])
         nt = len(res) - 2
-        return (*all_gather_samples(res[:nt], group), res[nt], res[nt + 1])
+        if not sampling_fn.timing:
+            return (*all_gather_samples(res[:nt], group), res[nt], res[nt + 1])
+        # diagnostic split of the call: [local loop | final all-gather], device-synchronised on both sides
+        import time
+
+        cuda = res[0].is_cuda
+        if cuda:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        full = all_gather_samples(res[:nt], group)
+        if cuda:
+            torch.cuda.synchronize()
+        sampling_fn.gather_seconds += time.perf_counter() - t0
+        return (*full, res[nt], res[nt + 1])
 
     sampling_fn.local_batch, sampling_fn.inner = local, inner
+    sampling_fn.timing, sampling_fn.gather_seconds = False, 0.0      # bench.py --gpus N: time the final all-gather separately
     return sampling_fn
 
 

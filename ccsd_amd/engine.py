@@ -135,6 +135,20 @@ class PCEngine:
         self.lib.check(self.lib.ccsd_init_state(self.handle, B, _ptr(flags), self._noise(prior, B), seed, sample_offset,
                                                 C.byref(st), self._stream()))
 
+    def noise_draws(self, flags, step: int, phase: int, out, seed: int = 0, sample_offset: int = 0):
+        """The masked Philox noise of half-step (step, phase) as the kernels consume it (ccsd_noise_draws): phase 0..n_steps-1
+        = corrector inner iterations, n_steps = predictor; S4: 0, 1, 2.  `out` = [x, adj, rank2] tensors of the state's shapes."""
+        B = flags.shape[0]
+        so = self._state(*out, B, "out")
+        self.lib.check(self.lib.ccsd_noise_draws(self.handle, B, _ptr(flags), seed, sample_offset, int(step), int(phase),
+                                                 C.byref(so), self._stream()))
+
+    def query(self, what: str) -> int:
+        """Which kernels the plan selected (ccsd_plan_query): "fused_r2", "xa_variant", "r2_lds_bytes", "xa_lds_bytes", "fused_loop"."""
+        v = C.c_int64(0)
+        self.lib.check(self.lib.ccsd_plan_query(self.handle, _lib.QUERIES[what], C.byref(v)))
+        return v.value
+
     def corrector_norms(self, step, it, base, cur, flags, noise, seed, sample_offset, sums):
         B = flags.shape[0]
         sb, sc = self._state(*base, B, "base"), self._state(*cur, B, "cur")

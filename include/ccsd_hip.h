@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CCSD_ABI_VERSION 4
+#define CCSD_ABI_VERSION 5
 
 /* status codes; the Python shim re-raises the reference's exception types */
 enum {
@@ -137,9 +137,31 @@ typedef struct {
 int ccsd_score(ccsd_plan_t* plan, int32_t target, int32_t B, const ccsd_state_t* in, const float* flags_dev,
                float sscale, float* out_dev, void* workspace, size_t workspace_bytes, void* stream);
 
-/* state <- masked prior.  prior==NULL: Philox draws (draw index 0..2); else mask the given raw draws. */
+/* state <- masked prior.  prior==NULL: Philox draws (draw index 0..2); else mask the given raw draws.
+ * Takes no workspace: its off-bit table lives in a plan-owned buffer.  Like every call on a plan it is reentrant per handle
+ * only, and all calls on one plan belong on ONE stream (the buffer is shared between calls; when it has to grow the call
+ * synchronises the device). */
 int ccsd_init_state(ccsd_plan_t* plan, int32_t B, const float* flags_dev, const ccsd_noise_t* prior,
                     uint64_t seed, int64_t sample_offset, ccsd_state_t* state, void* stream);
+
+/* The masked noise of one half-step exactly as the kernels of ccsd_sampler_run / the step calls consume it with NULL noise
+ * pointers: out->{x, adj, rank2} <- gen_noise / gen_noise_rank2 (graph_utils.py:158-178, cc_utils.py:594-615) of the Philox
+ * draws keyed by (seed, sample_offset + b, draw index of (step, phase)).  phase: 0 .. n_steps-1 = the Langevin corrector's
+ * inner iterations, n_steps = the predictor (S4 plans: 0, 1, 2 = the three draws of a step).  Test / audit hook: feeding
+ * these tensors to a CPU run of the reference algorithm as its noise stream makes the production loop (in-kernel noise,
+ * fused corrector apply) comparable with it value for value.  Same generator code as the kernels (philox_normal4). */
+int ccsd_noise_draws(ccsd_plan_t* plan, int32_t B, const float* flags_dev, uint64_t seed, int64_t sample_offset,
+                     int32_t step, int32_t phase, ccsd_state_t* out, void* stream);
+
+/* Which kernels a plan selected (host-side facts, no device work). */
+enum {
+    CCSD_QUERY_FUSED_R2 = 0,      /* 1: the LDS-resident fused rank-2 kernel k_r2 serves the rank-2 side; 0: the tiled kernels */
+    CCSD_QUERY_XA_VARIANT = 1,    /* instantiation of the graph-network kernel k_xa: 0 plain, 1 HodgeBaseline, 2 X_GMH, 3 general */
+    CCSD_QUERY_R2_LDS_BYTES = 2,
+    CCSD_QUERY_XA_LDS_BYTES = 3,
+    CCSD_QUERY_FUSED_LOOP = 4     /* 1: ccsd_sampler_run fuses the Langevin apply into the predictor launches */
+};
+int ccsd_plan_query(const ccsd_plan_t* plan, int32_t what, int64_t* value);
 
 /* Langevin corrector, phase 1: evaluate the three scores (all correctors see the same pre-corrector
  * state `base`, solver.py:1129-1137; with n_steps > 1 each target's own tensor is taken from `cur`, its

@@ -417,6 +417,88 @@ def case_one_step_vs_oracle_large(name, lib, device, B, counts, predictor, corre
         assert_close(g_, w_, f"{name} B={B} one step {p}")
 
 
+def case_production_loop_vs_oracle(name, lib, device, B, counts, steps, predictor, corrector, snr, seps, seed=5, expect_fused=None):
+    """The PRODUCTION loop -- one ccsd_sampler_run call: in-kernel Philox noise, the Langevin apply fused into the predictor
+    kernels' prologues where the plan supports it -- against the oracle, value for value.  ccsd_noise_draws exports the masked
+    draws the kernels consume for every (step, half-step); the oracle replays them as its noise stream (RecordedNoise) from the
+    same prior.  Also: the Python-driven step-wise loop (ccsd_corrector_norms + ccsd_corrector_apply + ccsd_predictor, the path
+    the golden cases exercise) must reproduce the single call bit for bit.  (solver.py:1123-1147.)"""
+    assert corrector == "Langevin"
+    meta, parts = load_ckpt_np(name)
+    cfg, is_cc = meta["config"], meta["is_cc"]
+    N, Fd = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
+    names = ["x", "adj"] + (["rank2"] if is_cc else [])
+    nt = len(names)
+    flags = make_flags(B, N, counts)
+    kw = dict(shape_x=(B, N, Fd), shape_adj=(B, N, N), predictor=predictor, corrector=corrector, snr=snr, scale_eps=seps,
+              n_steps=1, probability_flow=False, continuous=True, denoise=True, eps=1e-4)
+    if is_cc:
+        d_min, d_max = cfg["data"]["d_min"], cfg["data"]["d_max"]
+        kw.update(is_cc=True, shape_rank2=(B, *rank2_dim(N, d_min, d_max)), d_min=d_min, d_max=d_max)
+    sd = [loader.load_sde(cfg["sde"][p]) for p in names]
+    ms = [loader.load_model_from_ckpt(meta[f"params_{p}"], parts[p], device) for p in names]
+    skw = dict(sde_x=sd[0], sde_adj=sd[1])
+    if is_cc:
+        skw["sde_rank2"] = sd[2]
+    dflags = flags.to(device)
+    fn = solver.get_pc_sampler(device=device, rng="philox", seed=seed, max_steps=steps, lib=lib, **skw, **kw)
+    got = fn(*ms, dflags)
+    eng = fn.engine()
+    if expect_fused is not None:
+        assert eng.query("fused_loop") == int(expect_fused), "the plan did not take the expected loop form"
+    # step-wise driver == the single C call, bit for bit, at this batch
+    fn_s = solver.get_pc_sampler(device=device, rng="philox", seed=seed, max_steps=steps, lib=lib, group=_FakeGroup(), **skw, **kw)
+    got_s = fn_s(*ms, dflags)
+    for p, a, b in zip(names, got[:nt], got_s[:nt]):
+        assert torch.equal(a, b), f"{name} B={B}: step-wise loop != ccsd_sampler_run for {p}"
+    # the draws the kernels consumed
+    buf = eng.alloc_state(B)
+    eng.init_state(dflags, buf, None, seed, 0)
+    prior = [t.cpu().clone() for t in buf[:nt]]
+    draws = []
+    for step in range(steps):
+        for phase in (0, 1):                       # corrector (inner iteration 0), predictor
+            eng.noise_draws(dflags, step, phase, buf, seed, 0)
+            draws += [t.cpu().clone() for t in buf[:nt]]
+    assert not torch.equal(draws[0], draws[nt]) and not torch.equal(draws[0], prior[0])
+    so = [O.load_sde(cfg["sde"][p]) for p in names]
+    okw = dict(sde_x=so[0], sde_adj=so[1])
+    if is_cc:
+        okw["sde_rank2"] = so[2]
+        nets = [(lambda x, a, r, f, p=p: O.run_network(meta[f"params_{p}"], parts[p], x, a, r, f)) for p in names]
+    else:
+        nets = [(lambda x, a, f, p=p: O.run_network(meta[f"params_{p}"], parts[p], x, a, None, f)) for p in names]
+    rec = O.RecordedNoise(draws)
+    ofn = O.get_pc_sampler(n_diff_steps=steps, keep_traj=False, noise=rec, prior=prior, **okw, **kw)
+    want = ofn(*nets, flags)
+    assert rec.i == len(draws), "the oracle consumed a different number of draws"
+    for p, g_, w_ in zip(names, got, want):
+        assert_close(g_, w_, f"{name} B={B} production loop, {steps} steps, {p}")
+
+
+def case_fused_r2_nonaffine_shapes(lib, device):
+    """Non-affine ScoreNetworkF (2-linear HodgeNetworkLayers / 2-layer head: the reference-built nets of kat_small_models, whose
+    weights do not depend on N) at N = 7, 8, 11 -- E = 21, 28, 55, i.e. two and four 16-row tiles: the plan must select the
+    fused LDS-resident kernel k_r2 for them (ccsd_plan_query), and its score must match the oracle."""
+    gs = load_golden("kat_small_models.npz")
+    ms = json.loads(str(gs["meta"]))
+    sd = {k[len("rank2") + 3:]: torch.from_numpy(gs[k]) for k in gs.files if k.startswith("rank2/w/")}
+    for N, B in ((7, 3), (8, 2), (11, 2)):
+        params = dict(ms["rank2"], max_node_num=N)
+        d_min, d_max = params["d_min"], params["d_max"]
+        eng = PCEngine(None, None, None, None, params, sd, N=N, F=2, is_cc=True, d_min=d_min, d_max=d_max, device=device, lib=lib)
+        assert eng.query("fused_r2") == 1, f"N={N}: non-affine ScoreNetworkF fell back to the tiled rank-2 kernels"
+        flags = make_flags(B, N, [N, N - 2, 3])
+        _, _, rank2 = masked_state(40 + N, B, N, 2, True, d_min, d_max, flags)
+        x = torch.zeros(B, N, 2)
+        adj = torch.zeros(B, N, N)
+        w = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        with torch.no_grad():
+            want = O.run_network(params, w, x, adj, rank2, flags)
+        got = eng.score(2, x.to(device), adj.to(device), rank2.to(device), flags.to(device))
+        assert_close(got, want, f"non-affine ScoreNetworkF, N={N} (k_r2)")
+
+
 def case_error_behaviour(lib, device):
     """Same exception types as the reference for the same mistakes (SURVEY.md section 8b 'Errors')."""
     import pytest

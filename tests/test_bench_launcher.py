@@ -28,6 +28,11 @@ def test_bench_self_launches_two_ranks_on_the_emulation():
     assert line["value"] > 0 and abs(line["value"] - 8 / line["ms_per_step"]) < 1e-9
     for key in ("metric", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline", "cpu_baseline"):
         assert key in line
+    # per-rank split of the timed region (diagnosis of a scaling curve): PC-step time without the all-gather, and the all-gather
+    pr = line["per_rank"]
+    assert [r_["rank"] for r_ in pr] == [0, 1]
+    for r_ in pr:
+        assert r_["ms_per_step"] > 0 and r_["all_gather_ms"] >= 0 and r_["region_ms"] <= line["ms_per_step"] * line["steps"] * 1.001
 
 
 def test_bench_worker_failure_is_reported():

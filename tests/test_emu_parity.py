@@ -138,3 +138,15 @@ def test_one_step_vs_oracle_edge_batches(lib):
 
 def test_kat_hodge_layers_three_and_four(lib):
     pc.case_kat_hodge_layers(lib, DEV)
+
+
+def test_production_loop_vs_oracle(lib):
+    """ccsd_sampler_run (Philox in the kernels, fused Langevin apply) against the oracle fed with the exported draws; the GPU
+    twin runs the BASELINE batch."""
+    pc.case_production_loop_vs_oracle("ccsd_qm9_CC", lib, DEV, 5, [9, 7, 8, 0, 4], 2, "Reverse", "Langevin", 0.2, 0.7, expect_fused=True)
+    pc.case_production_loop_vs_oracle("gdss_community_small", lib, DEV, 3, [20, 12, 16], 2, "Euler", "Langevin", 0.05, 0.7,
+                                      expect_fused=False)
+
+
+def test_fused_r2_serves_nonaffine_shapes(lib):
+    pc.case_fused_r2_nonaffine_shapes(lib, DEV)

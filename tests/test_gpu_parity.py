@@ -261,3 +261,71 @@ def test_ccsd_api_yaml_surface_on_gpu(lib, tmp_path):
 
 def test_kat_hodge_layers_three_and_four(lib):
     pc.case_kat_hodge_layers(lib, DEV)
+
+
+def test_production_loop_vs_oracle_qm9_full_batch(lib):
+    """What bench.py times, at the BASELINE batch (B = 1024, realistic node-count mix): ccsd_sampler_run with in-kernel Philox
+    and the Langevin apply fused into the predictor launches, three PC steps, against the oracle replaying the exported
+    draws -- plus bit equality with the step-wise loop at the same batch."""
+    pc.case_production_loop_vs_oracle("ccsd_qm9_CC", lib, DEV, 1024, [9, 9, 8, 9, 7, 9, 9, 6, 9, 5, 9, 9, 4, 9, 8, 9, 3, 9, 7, 2, 9, 1],
+                                      3, "Reverse", "Langevin", 0.2, 0.7, seed=17, expect_fused=True)
+
+
+def test_production_loop_vs_oracle_tiled_path(lib):
+    """The same for the tiled rank-2 kernels (community_small_CC: E = 190, K = 1140) and for a graph-only checkpoint."""
+    pc.case_production_loop_vs_oracle("ccsd_community_small_CC", lib, DEV, 6, [20, 12, 16, 18, 14, 20], 3, "Euler", "Langevin", 0.05, 0.7,
+                                      seed=19)
+    pc.case_production_loop_vs_oracle("gdss_community_small", lib, DEV, 16, [20, 12, 16, 18, 14], 3, "Euler", "Langevin", 0.05, 0.7,
+                                      seed=23)
+
+
+def test_fused_r2_serves_nonaffine_shapes(lib):
+    pc.case_fused_r2_nonaffine_shapes(lib, DEV)
+
+
+def test_rccl_single_rank_group(lib):
+    """First contact with RCCL on one GPU: the code an 8-GPU run takes -- init_process_group("nccl", device_id=...) in
+    ccsd_amd.distributed.init, all_gather_into_tensor on device tensors in all_gather_samples, the 6-float all-reduce of the
+    exact mode inside the step-wise loop -- executed on a 1-rank group (world_size 1 exercises the same calls; only the
+    transport between ranks stays untested).  The sharded closure with exact=True must reproduce the plain closure bit for bit."""
+    import os
+
+    import torch.distributed as dist
+
+    from ccsd_amd import distributed, loader
+    from tests.helpers import load_ckpt_np
+
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    os.environ.setdefault("LOCAL_RANK", "0")
+    rank, world, dev = distributed.init(force_group=True, timeout_s=120)
+    try:
+        assert (rank, world, dev) == (0, 1, DEV) and dist.get_backend() == "nccl"
+        ts = [torch.arange(24, device=DEV, dtype=torch.float32).view(4, 6), None, torch.randn(4, 3, 5, device=DEV)]
+        out = distributed.all_gather_samples(ts, force=True)              # dist.all_gather_into_tensor over RCCL
+        assert out[1] is None and torch.equal(out[0], ts[0]) and torch.equal(out[2], ts[2]) and out[0].data_ptr() != ts[0].data_ptr()
+        sums = torch.arange(8, device=DEV, dtype=torch.float32)
+        dist.all_reduce(sums)
+        assert torch.equal(sums.cpu(), torch.arange(8, dtype=torch.float32))
+        # the sharded seam on the 1-rank group, exact mode (all-reduce of the norm sums every corrector half-step, step-wise loop)
+        meta, parts = load_ckpt_np("ccsd_qm9_CC")
+        cfgt = loader.AttrDict(meta["config"])
+        B = 16
+        module = dict(predictor="Reverse", corrector="Langevin", snr=0.2, scale_eps=0.7, n_steps=1)
+        sample = dict(n_samples=B, probability_flow=False, noise_removal=True, eps=1e-4)
+        names = ["x", "adj", "rank2"]
+        ms = [loader.load_model_from_ckpt(meta[f"params_{p}"], parts[p], DEV) for p in names]
+        from tests.helpers import make_flags
+
+        flags = make_flags(B, 9, [9, 8, 9, 7, 5]).to(DEV)
+        kw = dict(is_cc=True, d_min=3, d_max=9, rng="philox", seed=3, max_steps=3, lib=lib)
+        sharded = distributed.load_sampling_fn_sharded(cfgt, module, sample, DEV, exact=True, **kw)
+        assert hasattr(sharded, "inner"), "the 1-rank group did not take the sharded route"
+        plain = loader.load_sampling_fn(cfgt, module, sample, DEV, **kw)
+        a, b = sharded(*ms, flags), plain(*ms, flags)
+        for p, u, v in zip(names, a[:3], b[:3]):
+            assert torch.equal(u, v), f"1-rank exact mode != single-process run for {p}"
+    finally:
+        dist.destroy_process_group()
