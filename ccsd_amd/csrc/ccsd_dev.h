@@ -85,6 +85,25 @@ struct FastDiv {
 
 template <bool V> struct BoolTag { static constexpr bool v = V; };
 
+#ifndef CCSD_EMU
+// gfx950 lane swaps between the four 16-lane rows r0..r3 of a wave (one VALU instruction each):
+//   lane_swap16(a, b): a <- [a.r0, b.r0, a.r2, b.r2], b <- [a.r1, b.r1, a.r3, b.r3]   (odd rows of a <-> even rows of b)
+//   lane_swap32(a, b): a <- [a.r0, a.r1, b.r0, b.r1], b <- [a.r2, a.r3, b.r2, b.r3]   (upper half of a <-> lower half of b)
+// Inline asm on purpose: hipcc (ROCm 7.2) compiles `r[0] + r[1]` of __builtin_amdgcn_permlane{16,32}_swap as `r[0] + r[0]`
+// (tools/ubench/permlane_swap.hip shows both forms).  s_nop 1: the instruction may not read a VGPR a VALU wrote in the two
+// preceding slots (the compiler emits the same padding for the builtin).
+CCSD_DEV void lane_swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+CCSD_DEV void lane_swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+// sum over the four rows, result in every row
+CCSD_DEV float rows_allsum(float x) {
+    float y = x;
+    lane_swap16(x, y);
+    x += y; y = x;
+    lane_swap32(x, y);
+    return x + y;
+}
+#endif
+
 struct NoiseArgs {
     const float* zx;
     const float* zadj;

@@ -1,6 +1,6 @@
 // ccsd_instances.h -- the instantiations of the two big kernel templates.  CCSD_INST expands to `template` in the
-// translation unit that owns an instance (ccsd_r2.hip, ccsd_xa.hip) and to `extern template` in ccsd_hip.hip (the C ABI, which
-// launches them): three units compile in parallel, each kernel is compiled once.  Keep in step with R2_DISPATCH / launch_xa.
+// translation unit that owns an instance (ccsd_r2*.hip, ccsd_xa.hip) and to `extern template` in ccsd_hip.hip (the C ABI, which
+// launches them): the units compile in parallel, each kernel is compiled once.  Keep in step with R2_DISPATCH / launch_xa.
 #define CCSD_R2_SIG (const PlanD* __restrict__, const float* __restrict__, const unsigned char* __restrict__, \
                      const unsigned long long* __restrict__, R2Args, RankEpi, NoiseArgs)
 #define CCSD_R2_ONE(MT_, RS_) \
@@ -9,9 +9,18 @@
 #define CCSD_R2_GEN(MT_) \
     CCSD_INST __global__ void k_r2<MT_, 0, false, false> CCSD_R2_SIG; \
     CCSD_INST __global__ void k_r2<MT_, 0, false, true> CCSD_R2_SIG;
-#ifdef CCSD_INST_R2
-CCSD_R2_ONE(1, 0) CCSD_R2_ONE(1, 1) CCSD_R2_ONE(1, 2) CCSD_R2_ONE(1, 3) CCSD_R2_ONE(2, 2) CCSD_R2_ONE(2, 3) CCSD_R2_ONE(3, 0)
-CCSD_R2_ONE(3, 1) CCSD_R2_ONE(4, 2)
+// k_r2 is instantiated in four units (ccsd_r2.hip: the qm9 geometry E = 36; ccsd_r2b.hip / ccsd_r2c.hip: the other affine
+// shapes; ccsd_r2d.hip: the non-affine ScoreNetworkF path) so that the units compile in parallel
+#ifdef CCSD_INST_R2_A
+CCSD_R2_ONE(3, 1)
+#endif
+#ifdef CCSD_INST_R2_B
+CCSD_R2_ONE(3, 0) CCSD_R2_ONE(4, 2) CCSD_R2_ONE(2, 2) CCSD_R2_ONE(2, 3)
+#endif
+#ifdef CCSD_INST_R2_C
+CCSD_R2_ONE(1, 0) CCSD_R2_ONE(1, 1) CCSD_R2_ONE(1, 2) CCSD_R2_ONE(1, 3)
+#endif
+#ifdef CCSD_INST_R2_D
 CCSD_R2_GEN(1) CCSD_R2_GEN(2) CCSD_R2_GEN(3) CCSD_R2_GEN(4)
 #endif
 #define CCSD_XA_SIG (const PlanD* __restrict__, const float* __restrict__, const unsigned char* __restrict__, XaArgs, NoiseArgs)

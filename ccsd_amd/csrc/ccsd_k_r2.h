@@ -19,6 +19,14 @@ struct R2Args {
 // 16-wide blocks of the contraction index (0: the last block is taken whole, zero padded -- E mod 16 == 0 or > 12);
 // AFFINE: ScoreNetworkF folds to alpha F + beta HF + gamma; GEN1: general (non-affine) mlp_value in the hodge branch.
 // Compile-time so that the common variant carries no general-path code.
+//
+// Row strips (ST, the qm9 geometry E = 36 = 2 x 16 + 4): on gfx950 an fp32 MFMA runs at the fp32 vector rate on the vector
+// pipe, so the padding rows of a 16-row tile cost exactly as much as useful ones -- a third row tile holding 4 of 16 rows
+// wastes a quarter of all matrix time.  With ST the last E mod 16 <= 4 rows are a 4-ROW STRIP computed by
+// v_mfma_f32_4x4x1_16B_f32 (16 independent 4x4x1 blocks per instruction, 8.8 cycles measured: tools/ubench/mfma_4x4x1.hip):
+// lane l = 16 kc + 4 cg + j takes strip row (l & 3) as A and column 4 cg + j as B of the block (column group cg, k class kc),
+// i.e. 4 rows x 16 columns x 4 k values per instruction -- the SAME operand addresses as the 16x16x4 tile code (B operand of
+// column l & 15, k slot group l >> 4), only the A row differs; the four k classes are summed with two lane swaps.
 template <int MT, int RS, bool AFFINE, bool GEN1>
 __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, const float* __restrict__ w,
                                             const unsigned char* __restrict__ edges,
@@ -43,6 +51,9 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
 #endif
     const float* Fg = ra.rank2 + (size_t)b * E * K;
     const FastDiv dK(K);
+    constexpr bool ST = AFFINE && !GEN1 && MT == 3 && RS == 1;   // E = 33..36: two full row tiles + one 4-row strip
+    constexpr int MTF = ST ? MT - 1 : MT;                 // full 16-row tiles
+    constexpr int E0 = 16 * MTF;                          // first strip row (ST)
 
     // ---- phase 0: rank2 block -> LDS; masks; adjacency powers
     stamp(ra.dbg, 0);
@@ -181,9 +192,12 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     stamp(ra.dbg, 2);
     const int ks = Kp4 >> 2;
     int nHtasks = 0;
-    const int nH = p.f_cnum == 2 ? MT * (MT + 1) / 2 : 0;
+    // task list: H full tiles (upper triangle), [H strip sets of 16 columns], P_0 full tiles, P_1 full tiles, [P_0 strip sets], [P_1 strip sets]
+    const int nHf = p.f_cnum == 2 ? MTF * (MTF + 1) / 2 : 0, nHs = (ST && p.f_cnum == 2) ? MT : 0;
+    const int nH = nHf + nHs;
     const int nt0 = doP0 ? (wc0 + 15) >> 4 : 0, nt1 = doP1 ? (wc1 + 15) >> 4 : 0;
-    const int ntask = nH + MT * nt0 + MT * nt1;
+    const int nPf = MTF * (nt0 + nt1);
+    const int ntask = nH + nPf + (ST ? nt0 + nt1 : 0);
 #ifdef CCSD_EMU
     (void)ks; (void)ntask;
     for (int m = 0; m < E; ++m) {
@@ -238,18 +252,26 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     auto run_tile = [&](int t) {
         const int lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
         int type, i, c;                                       // 0: H(i, c >= i); 1: P_0(i, c); 2: P_1(i, c)
-        if (t < nH) {
+        bool strip = false;                                   // ST: rows E0.. as one 4-row strip, c = set of 16 output columns
+        if (t < nHf) {
             type = 0; i = 0;
             int rem = t;
-            while (rem >= MT - i) { rem -= MT - i; ++i; }
+            while (rem >= MTF - i) { rem -= MTF - i; ++i; }
             c = i + rem;
-        } else if (t < nH + MT * nt0) {
+        } else if (t < nH) {
+            type = 0; i = MTF; c = t - nHf; strip = true;
+        } else if (t < nH + MTF * nt0) {
             type = 1; i = (t - nH) / nt0; c = (t - nH) % nt0;
+        } else if (t < nH + nPf) {
+            type = 2; i = (t - nH - MTF * nt0) / nt1; c = (t - nH - MTF * nt0) % nt1;
+        } else if (t < nH + nPf + nt0) {
+            type = 1; i = MTF; c = t - nH - nPf; strip = true;
         } else {
-            type = 2; i = (t - nH - MT * nt0) / nt1; c = (t - nH - MT * nt0) % nt1;
+            type = 2; i = MTF; c = t - nH - nPf - nt0; strip = true;
         }
-        const int ra_ = 16 * i + l15;
-        const float* pa = sF + (ra_ < E ? ra_ : E - 1) * ldk + 4 * kq;
+        const int ra_ = strip ? E0 + (l15 & 3) : 16 * i + l15;
+        const int arow = ra_ < E ? ra_ : E - 1;               // A row of this lane (clamped: never stored beyond E)
+        const float* pa = sF + arow * ldk + 4 * kq;
         int offB = 0;                                         // H tiles: B rows of F in LDS
         const float* wtp = WT0;                               // P tiles: column of Wcat^T in global memory
         if (type == 0) {
@@ -261,9 +283,9 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
         }
         r2_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         float upart = 0.f;
-        // the k loop, specialised on where the B operand lives (LDS / global) and on the masked-A kind
-        auto kloop = [&](auto LB, auto K1) {
-            constexpr bool lb = decltype(LB)::v, k1 = decltype(K1)::v;
+        // the k loop, specialised on where the B operand lives (LDS / global), on the masked-A kind and on the MFMA shape
+        auto kloop = [&](auto LB, auto K1, auto SR) {
+            constexpr bool lb = decltype(LB)::v, k1 = decltype(K1)::v, sr = decltype(SR)::v;
             auto ldB = [&](int blk) -> float4 {
                 if (lb) return *reinterpret_cast<const float4*>(sF + offB + 16 * blk);
                 return *reinterpret_cast<const float4*>(wtp + 16 * blk);
@@ -286,7 +308,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                     const float fr0 = (float)(f4 & 0xffu), fr1 = (float)((f4 >> 8) & 0xffu), fr2 = (float)((f4 >> 16) & 0xffu),
                                 fr3 = (float)(f4 >> 24);
                     if (GEN1) {   // general mlp_value: rank2' element-wise on the fly (hodge_attention.py:322-323)
-                        const int r = 16 * i + l15, e = r < E ? r : E - 1;
+                        const int e = arow;
                         float fv[4] = {a4.x, a4.y, a4.z, a4.w};
                         const float frv[4] = {fr0, fr1, fr2, fr3};
 #pragma unroll
@@ -300,14 +322,21 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                         a4 = make_float4(fv[0], fv[1], fv[2], fv[3]);
                     } else {
                         a4.x *= fr0; a4.y *= fr1; a4.z *= fr2; a4.w *= fr3;
-                        upart = fmaf(fr0, b4.x, fmaf(fr1, b4.y, fmaf(fr2, b4.z, fmaf(fr3, b4.w, upart))));
+                        if (!sr) upart = fmaf(fr0, b4.x, fmaf(fr1, b4.y, fmaf(fr2, b4.z, fmaf(fr3, b4.w, upart))));
                     }
                 }
                 r2_f32x4& acc = (u & 1) ? acc1 : acc0;            // block parity == slot parity (D even, block counter a multiple of D)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
+                if (sr) {                                          // 4-row strip: 16 blocks of 4x4x1 (4 column groups x 4 k classes)
+                    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.x, b4.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.y, b4.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.z, b4.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.w, b4.w, acc, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
+                }
                 if (refill) {
                     __builtin_amdgcn_sched_barrier(0);
                     const int bl = blk + D < nblk ? blk + D : nblk - 1;   // clamped: a harmless reload at the tail
@@ -326,11 +355,42 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
             for (int u = 0; u < D - 1; ++u)
                 if (blk0 + u < nblk) block(u, blk0 + u, false);
         };
-        if (type == 2) kloop(BoolTag<false>{}, BoolTag<true>{});
-        else if (type == 0) kloop(BoolTag<true>{}, BoolTag<false>{});
-        else kloop(BoolTag<false>{}, BoolTag<false>{});
-        const r2_f32x4 acc = acc0 + acc1;
+        if (ST && strip) {
+            if (type == 2) kloop(BoolTag<false>{}, BoolTag<true>{}, BoolTag<true>{});
+            else if (type == 0) kloop(BoolTag<true>{}, BoolTag<false>{}, BoolTag<true>{});
+            else kloop(BoolTag<false>{}, BoolTag<false>{}, BoolTag<true>{});
+        } else {
+            if (type == 2) kloop(BoolTag<false>{}, BoolTag<true>{}, BoolTag<false>{});
+            else if (type == 0) kloop(BoolTag<true>{}, BoolTag<false>{}, BoolTag<false>{});
+            else kloop(BoolTag<false>{}, BoolTag<false>{}, BoolTag<false>{});
+        }
+        r2_f32x4 acc = acc0 + acc1;
         const int n = 16 * c + l15;
+        if (ST && strip) {
+            // the lane holds rows E0 .. E0 + 3 of column n, summed over its k class only: add the four classes (lanes l, l ^ 16,
+            // l ^ 32, l ^ 48) -- afterwards every class holds the sums and class kq stores row E0 + kq
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float tot = rows_allsum(acc[r]);
+                v = kq == r ? tot : v;
+            }
+            const int m = E0 + kq;
+            if (type == 0) {
+                if (n < E && m < E) {
+                    const float hv = (hmask && m == n) ? 0.f : v;   // hodge_mask zeroes the diagonal (cc_utils.py:964-969)
+                    sH[m * ldh + n] = hv;
+                    sH[n * ldh + m] = hv;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) atomicAdd(&s_hdone, 1);
+            } else {
+                const int wcn = type == 1 ? wc0 : wc1;
+                float* const dstp = type == 1 ? ra.P0 : ra.P1;
+                if (n < wcn && m < E) dstp[((size_t)b * E + m) * wcn + n] = v;
+            }
+            return;
+        }
         const int mb = 16 * i + 4 * kq;
         if (type == 0) {
             if (n < E) {
@@ -451,7 +511,239 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
             }
     }
 #else
-    if constexpr (AFFINE) {
+    if constexpr (AFFINE && ST) {
+        // Affine ScoreNetworkF, E = 16 TF + (1..4) rows (qm9_CC: E = 36).  As the general affine path below, except that the
+        // last rows are a 4-row strip:
+        //  * per column tile: TF row tiles on v_mfma_f32_16x16x4_f32 (contraction index in the permuted slot order, the lane's B
+        //    operands are the F values of its own accumulator rows) + the strip rows on v_mfma_f32_4x4x1_16B_f32 with the SAME B
+        //    registers: lane (kq, l15) accumulates rows E0..E0+3 of column l15 over the contraction indices of its k class kq
+        //    (16 t + 4 kq + j and E0 + kq -- every index exactly once over the four classes);
+        //  * the strip's epilogue runs once per FOUR column tiles of the wave: a reduce-scatter over the k classes (three lane
+        //    swaps per register) leaves the finished sums of column tile j in the lanes of class j, so all 64 lanes carry four
+        //    real elements (one Philox group each) instead of a quarter-filled third row tile per column tile.
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const int wave = tid >> 6, nw = nth >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+        constexpr int TF = MT - 1;                          // full row tiles == full 16-wide blocks of the contraction index
+        const int ar0 = l15 * ldh + 4 * kq;                // A, full tiles: row l15 of row tile 0, slot group kq (rows < E0: no clamp)
+        const int srow = E0 + (l15 & 3) < E ? E0 + (l15 & 3) : E - 1;
+        const int as0 = srow * ldh + 4 * kq;               // A, strip: row E0 + (lane & 3), slot group kq
+        const int brow = 4 * kq * ldk;                     // B: row 4 kq of block 0; block t, step j: + (16 t + j) ldk
+        const unsigned vo = (unsigned)(4 * kq * K + l15);  // element offset of (row 4 kq, column l15) inside the complex's block
+        const bool cn2 = p.f_cnum == 2;
+        float* const outp = ep.out + (size_t)b * E * K;
+        auto coltile = [&](auto MODE_, auto INJ_, int tn) -> f32x4 {
+            constexpr int MODE = decltype(MODE_)::value;   // 0 score, 1 norms, 2 predictor, 3 predictor + mean output
+            constexpr bool INJ = decltype(INJ_)::value;    // host-supplied raw draws instead of Philox
+            const float s_ = MODE == 0 ? ep.sscale : MODE == 1 ? 1.f : ep.pb;
+            const float sa = s_ * p.f_alpha, sb = s_ * p.f_beta, sg = s_ * p.f_gamma;
+            const float pa = ep.pa, pc = ep.pc;
+            float* const meanp = MODE == 3 ? ep.mean + (size_t)b * E * K : nullptr;
+            const float* const zrp = INJ ? na.zr + (size_t)b * E * K : nullptr;
+            const int n = 16 * tn + l15;
+            const bool nin = n < K;
+            const int nc = nin ? n : K - 1;
+            // B operands: bv[4 t + j] = F[16 t + 4 kq + j][n] (permuted blocks), bvr[s] = F[E0 + 4 s + kq][n] (remainder)
+            float bv[4 * TF], bvr[RS];
+            const float* fb = sF + brow + nc;
+#pragma unroll
+            for (int t = 0; t < TF; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[4 * t + j] = fb[(16 * t + j) * ldk];
+#pragma unroll
+            for (int s0 = 0; s0 < RS; ++s0) {
+                const int c = E0 + 4 * s0 + kq;
+                bvr[s0] = sF[(c < E ? c : E - 1) * ldk + nc];
+            }
+            f32x4 acc[TF], sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < TF; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (cn2) {
+                int ao = ar0, so = as0;
+                asm volatile("" : "+v"(ao), "+v"(so));     // opaque per tile: the loop-invariant A loads must not be hoisted into registers
+#pragma unroll
+                for (int t = 0; t < TF; ++t) {
+                    float4 a4[TF];
+#pragma unroll
+                    for (int i = 0; i < TF; ++i) a4[i] = *reinterpret_cast<const float4*>(sH + ao + 16 * i * ldh + 16 * t);
+                    const float4 h4 = *reinterpret_cast<const float4*>(sH + so + 16 * t);
+                    // interleaved: the row tiles' chains and the strip's chain are independent of each other
+#pragma unroll
+                    for (int i = 0; i < TF; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].x, bv[4 * t + 0], acc[i], 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.x, bv[4 * t + 0], sacc, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < TF; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].y, bv[4 * t + 1], acc[i], 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.y, bv[4 * t + 1], sacc, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < TF; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].z, bv[4 * t + 2], acc[i], 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.z, bv[4 * t + 2], sacc, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < TF; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].w, bv[4 * t + 3], acc[i], 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.w, bv[4 * t + 3], sacc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int s0 = 0; s0 < RS; ++s0) {
+                    const int c = E0 + 4 * s0 + kq;        // contraction index of this lane's slot / k class
+                    const int cc = (c < E ? c : E - 1) - 4 * kq;
+#pragma unroll
+                    for (int i = 0; i < TF; ++i) {
+                        const float av = sH[ao + 16 * i * ldh + cc];
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(c < E ? av : 0.f, bvr[s0], acc[i], 0, 0, 0);
+                    }
+                    const float hv = sH[so + cc];
+                    sacc = __builtin_amdgcn_mfma_f32_4x4x1f32(c < E ? hv : 0.f, bvr[s0], sacc, 0, 0, 0);
+                }
+            }
+            if (nin) {                                     // false only for the padding columns of the last column tile
+                const float fr = (float)sFrb[n];
+                unsigned gi = vo + 16u * (unsigned)tn;
+#pragma unroll
+                for (int i = 0; i < TF; ++i) {
+                    const int e0 = 16 * i + 4 * kq;
+                    float z[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (MODE != 0) {
+                        if (INJ) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) z[r] = zrp[gi + (unsigned)(r * K)];
+                        } else {
+                            philox_normal4(na.seed, na.draw_r, na.b_off + b, (unsigned)((4 * i + kq) * K + n), z);   // one Philox group = 4 edge rows
+                        }
+                    }
+                    const float4 fl4 = *reinterpret_cast<const float4*>(sFl + e0);
+                    const float flv[4] = {fl4.x, fl4.y, fl4.z, fl4.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float f = bv[4 * i + r];
+                        const float m = flv[r] * fr;                     // flags_left * flags_right, cc_utils.py:590
+                        const float net = m * fmaf(sb, acc[i][r], fmaf(sa, f, sg));
+                        const unsigned g = gi + (unsigned)(r * K);
+                        if (MODE == 0) {
+                            outp[g] = net;
+                        } else {
+                            const float zz = z[r] * m;                   // gen_noise_rank2, cc_utils.py:613-615
+                            if (MODE == 1) {
+                                outp[g] = net;
+                                s_net = fmaf(net, net, s_net);
+                                s_z = fmaf(zz, zz, s_z);
+                            } else {
+                                const float mean = fmaf(pa, f, net);     // v_mean = pa v + pb net (pb folded into net)
+                                if (MODE == 3) meanp[g] = mean;
+                                outp[g] = fmaf(pc, zz, mean);
+                            }
+                        }
+                    }
+                    gi += 16u * (unsigned)K;
+                }
+            }
+            return sacc;
+        };
+        // strip rows of up to four column tiles tn0, tn0 + nw, ...: p_j = the k-class partials of tile j.  Reduce-scatter: after two
+        // 16-lane-row swaps and one half-wave swap the lanes of class j hold the finished sums of tile j (rows E0..E0+3, column l15).
+        auto strip_finish = [&](auto MODE_, auto INJ_, const f32x4& p0, const f32x4& p1, const f32x4& p2, const f32x4& p3, int tn0) {
+            constexpr int MODE = decltype(MODE_)::value;
+            constexpr bool INJ = decltype(INJ_)::value;
+            float hf[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = p0[r], c = p1[r], d = p2[r], e = p3[r];
+                lane_swap16(a, c);
+                const float a01 = a + c;          // rows: t0(0+1) t1(0+1) t0(2+3) t1(2+3)
+                lane_swap16(d, e);
+                const float a23 = d + e;          // rows: t2(0+1) t3(0+1) t2(2+3) t3(2+3)
+                float u = a01, v = a23;
+                lane_swap32(u, v);
+                hf[r] = u + v;                    // rows: t0 t1 t2 t3
+            }
+            const int tn = tn0 + kq * nw;
+            const int n = 16 * tn + l15;
+            if (tn < ntn && n < K) {
+                const float s_ = MODE == 0 ? ep.sscale : MODE == 1 ? 1.f : ep.pb;
+                const float sa = s_ * p.f_alpha, sb = s_ * p.f_beta, sg = s_ * p.f_gamma;
+                const float pa = ep.pa, pc = ep.pc;
+                float* const meanp = MODE == 3 ? ep.mean + (size_t)b * E * K : nullptr;
+                const float fr = (float)sFrb[n];
+                const unsigned gi = (unsigned)(E0 * K + n);
+                float z[4] = {0.f, 0.f, 0.f, 0.f};
+                if (MODE != 0) {
+                    if (INJ) {
+                        const float* const zrp = na.zr + (size_t)b * E * K;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) z[r] = E0 + r < E ? zrp[gi + (unsigned)(r * K)] : 0.f;
+                    } else {
+                        philox_normal4(na.seed, na.draw_r, na.b_off + b, (unsigned)((E0 >> 2) * K + n), z);
+                    }
+                }
+                const float4 fl4 = *reinterpret_cast<const float4*>(sFl + E0);   // sFl: 64 entries, zero beyond E
+                const float flv[4] = {fl4.x, fl4.y, fl4.z, fl4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int e = E0 + r;
+                    if (e < E) {
+                        const float f = sF[e * ldk + n];
+                        const float m = flv[r] * fr;
+                        const float net = m * fmaf(sb, hf[r], fmaf(sa, f, sg));
+                        const unsigned g = gi + (unsigned)(r * K);
+                        if (MODE == 0) {
+                            outp[g] = net;
+                        } else {
+                            const float zz = z[r] * m;
+                            if (MODE == 1) {
+                                outp[g] = net;
+                                s_net = fmaf(net, net, s_net);
+                                s_z = fmaf(zz, zz, s_z);
+                            } else {
+                                const float mean = fmaf(pa, f, net);
+                                if (MODE == 3) meanp[g] = mean;
+                                outp[g] = fmaf(pc, zz, mean);
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        typedef std::integral_constant<bool, false> NoInj;
+        typedef std::integral_constant<bool, true> Inj;
+        const bool inj = na.zr != nullptr && ep.mode != MODE_SCORE;
+        const int cmode = ep.mode == MODE_SCORE ? 0 : ep.mode == MODE_NORMS ? 1 : ep.mean == nullptr ? 2 : 3;
+        const int sel = cmode * 2 + (inj ? 1 : 0);
+        // Static schedule of a wave: its column tiles tn = wave, wave + nw, ... with its leftover phase-1 tasks in between.  The
+        // leftover list is rotated by the number of full H tiles: the waves that had the light (strip) tasks in phase 1 take the
+        // full projection tiles.  (Static, hence the per-thread accumulation order of the Langevin norms is fixed and runs are
+        // bitwise reproducible.)
+        int pt = n1 + (wave + nw - (nHf % nw)) % nw;
+        const int pslot = wave < (nw >> 1) ? 0 : 2;
+        int cnt = 0;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 sp0 = zero4, sp1 = zero4, sp2 = zero4, sp3 = zero4;
+        for (int tn = wave; tn < ntn; tn += nw, ++cnt) {
+            if (cnt == pslot && pt < ntask) { run_tile(pt); pt += nw; }
+            f32x4 sacc;
+            switch (sel) {
+                case 0: case 1: sacc = coltile(std::integral_constant<int, 0>{}, NoInj{}, tn); break;
+                case 2: sacc = coltile(std::integral_constant<int, 1>{}, NoInj{}, tn); break;
+                case 3: sacc = coltile(std::integral_constant<int, 1>{}, Inj{}, tn); break;
+                case 4: sacc = coltile(std::integral_constant<int, 2>{}, NoInj{}, tn); break;
+                case 5: sacc = coltile(std::integral_constant<int, 2>{}, Inj{}, tn); break;
+                case 6: sacc = coltile(std::integral_constant<int, 3>{}, NoInj{}, tn); break;
+                default: sacc = coltile(std::integral_constant<int, 3>{}, Inj{}, tn); break;
+            }
+            const int c4 = cnt & 3;
+            if (c4 == 0) sp0 = sacc; else if (c4 == 1) sp1 = sacc; else if (c4 == 2) sp2 = sacc; else sp3 = sacc;
+            if (c4 == 3 || tn + nw >= ntn) {
+                const int tn0 = tn - c4 * nw;
+                switch (sel) {
+                    case 0: case 1: strip_finish(std::integral_constant<int, 0>{}, NoInj{}, sp0, sp1, sp2, sp3, tn0); break;
+                    case 2: strip_finish(std::integral_constant<int, 1>{}, NoInj{}, sp0, sp1, sp2, sp3, tn0); break;
+                    case 3: strip_finish(std::integral_constant<int, 1>{}, Inj{}, sp0, sp1, sp2, sp3, tn0); break;
+                    case 4: strip_finish(std::integral_constant<int, 2>{}, NoInj{}, sp0, sp1, sp2, sp3, tn0); break;
+                    case 5: strip_finish(std::integral_constant<int, 2>{}, Inj{}, sp0, sp1, sp2, sp3, tn0); break;
+                    case 6: strip_finish(std::integral_constant<int, 3>{}, NoInj{}, sp0, sp1, sp2, sp3, tn0); break;
+                    default: strip_finish(std::integral_constant<int, 3>{}, Inj{}, sp0, sp1, sp2, sp3, tn0); break;
+                }
+                sp0 = sp1 = sp2 = sp3 = zero4;
+            }
+        }
+        for (; pt < ntask; pt += nw) run_tile(pt);
+    } else if constexpr (AFFINE) {
         // Affine ScoreNetworkF (every shipped CC checkpoint but ENZYMES): net = fl[e] fr[k] (alpha f + beta (H F) + gamma).
         // The tile loop is specialised per epilogue mode and noise source (no per-element mode branches) and organised so that
         // the epilogue needs no address arithmetic of its own:

@@ -13,8 +13,8 @@
 //   ccsd_k_xa.h      k_xa: ScoreNetworkX + ScoreNetworkA(_CC): one workgroup per graph, everything LDS-resident
 //                    (+ ccsd_attn_stack.inc: the AttentionLayer stack)
 //   ccsd_k_update.h  k_normsum, k_langevin_apply, k_s4_apply, k_init_state, k_quantize, k_rank2_cells
-// The product library is built from three translation units compiled in parallel (ccsd_hip.hip: C ABI + the small kernels;
-// ccsd_r2.hip / ccsd_xa.hip: the explicit instantiations of the two big kernel templates); the host emulation used by the
+// The product library is built from several translation units compiled in parallel (ccsd_hip.hip: C ABI + the small kernels;
+// ccsd_r2*.hip / ccsd_xa.hip: the explicit instantiations of the two big kernel templates); the host emulation used by the
 // CPU tests includes everything in one unit.  Reference file:line citations sit next to each restated formula.
 #pragma once
 #include "ccsd_dev.h"
