@@ -342,8 +342,8 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
 // ---------------- workspace ----------------
 struct Workspace {
     unsigned long long* offbits;
-    float *H, *P0, *P1, *U1, *acoef, *net_x, *net_adj, *net_r, *norm2, *part, *sums, *chan;
-    int ntiles;
+    float *H, *P0, *P1, *U1, *acoef, *net_x, *net_adj, *net_r, *norm2, *part, *sums, *chan, *zpart, *part2;
+    int ntiles, nchunk;
     int p1_raw;     // who filled P1 last: k_r2 with the raw factors (1, see k_r2) or k_gemm_p with the finished projections (0)
     size_t bytes;
 };
@@ -365,6 +365,9 @@ static Workspace carve_ws(const ccsd_plan* pl, int B, void* base) {
     w.norm2 = (float*)take((size_t)B * 4 * 4);
     w.ntiles = p.is_cc ? ((p.K + T_BN - 1) / T_BN) * ((p.E + T_BM - 1) / T_BM) : 0;
     w.part = (float*)take((size_t)B * (w.ntiles ? w.ntiles : 1) * 2 * 4);
+    w.nchunk = p.is_cc ? (int)((((size_t)p.E * p.K + 3) / 4 + CCSD_NN_CH - 1) / CCSD_NN_CH) : 0;   // k_noise_norm: chunks of flat groups per sample
+    w.zpart = (float*)take((size_t)B * (w.nchunk ? w.nchunk : 1) * 4);
+    w.part2 = (float*)take((size_t)B * 2 * 4);
     w.sums = (float*)take(64);
     w.chan = (float*)take(p.chan_global ? (size_t)B * p.chan_rows * p.N * p.N * 4 : 0);
     w.bytes = o;
@@ -545,13 +548,18 @@ static unsigned int draw_base(const ccsd_plan* pl, int step, int phase) {
     const int per_step = pl->cfg.predictor == CCSD_PRED_S4 ? 3 : pl->cfg.n_corr_steps + 1;   // S4: three draws per target per step
     return 3u + (unsigned)((step * per_step + phase) * 3);
 }
-static NoiseArgs make_noise(const ccsd_noise_t* n, uint64_t seed, int64_t off, unsigned int base) {
+static NoiseArgs make_noise(const ccsd_noise_t* n, uint64_t seed, int64_t off, unsigned int base, int flat_r = 0) {
     NoiseArgs na{};
     if (n) { na.zx = n->zx; na.zadj = n->zadj; na.zr = n->zrank2; }
     na.seed = seed; na.b_off = off;
     na.draw_x = base; na.draw_adj = base + 1; na.draw_r = base + 2;
+    na.flat_r = flat_r;
     return na;
 }
+// The Langevin corrector's rank2 draws are keyed by flat groups of four consecutive elements (NoiseArgs::flat_r): they are
+// generated where rank2 streams through registers in 16-byte pieces (k_r2's block load, k_langevin_apply, k_noise_norm).
+// Priors, predictor draws and the three draws of an S4 step keep the 4-row groups of the MFMA epilogues.
+static inline int corrector_flat(const ccsd_plan* pl) { return pl->cfg.predictor != CCSD_PRED_S4 ? 1 : 0; }
 
 // does ccsd_sampler_run fuse the Langevin corrector's apply pass into the predictor launches of this plan?
 static inline bool fused_apply_ok(const ccsd_plan* pl) { return pl->fused_r2 && !pl->opt_no_fused_apply; }
@@ -587,7 +595,7 @@ extern "C" int ccsd_score(ccsd_plan_t* pl, int32_t target, int32_t B, const ccsd
 
 // masked draws of one draw base into `state` (k_init_state): the prior for base 0, the noise of a half-step otherwise
 static int draws_to_state(ccsd_plan* pl, int32_t B, const float* flags, const ccsd_noise_t* raw, uint64_t seed, int64_t sample_offset,
-                          unsigned int base, ccsd_state_t* state, void* stream) {
+                          unsigned int base, ccsd_state_t* state, void* stream, int flat_r = 0) {
     if (!pl || B < 1 || !flags) return set_err(CCSD_ERR_INVALID, "bad argument");
     int st = check_state(pl, state, "state");
     if (st) return st;
@@ -608,8 +616,9 @@ static int draws_to_state(ccsd_plan* pl, int32_t B, const float* flags, const cc
     }
     unsigned long long* offbits = pl->init_off;
     CCSD_LAUNCH(k_flagbits, dim3(grid_for(B, 256)), dim3(CCSD_NTHREADS), 0, stream, flags, offbits, B, p.N);
-    NoiseArgs na = make_noise(raw, seed, sample_offset, base);
-    const long long total = (long long)B * (p.N * p.F + p.N * p.N) + (p.is_cc ? (long long)B * ((p.E + 3) / 4) * p.K : 0);
+    NoiseArgs na = make_noise(raw, seed, sample_offset, base, flat_r);
+    const long long total = (long long)B * (p.N * p.F + p.N * p.N) +
+                            (p.is_cc ? (flat_r ? (long long)B * (((long long)p.E * p.K + 3) / 4) : (long long)B * ((p.E + 3) / 4) * p.K) : 0);
     CCSD_LAUNCH(k_init_state, dim3(grid_for(total, 256)), dim3(CCSD_NTHREADS), 0, stream, state->x, state->adj, state->rank2,
                 flags, na, (const unsigned long long*)offbits, (const unsigned char*)pl->edges,
                 (const unsigned long long*)pl->cells, B, p.N, p.F, p.E, p.K, p.is_cc);
@@ -627,7 +636,8 @@ extern "C" int ccsd_noise_draws(ccsd_plan_t* pl, int32_t B, const float* flags, 
     if (!pl) return set_err(CCSD_ERR_INVALID, "NULL plan");
     const int per_step = pl->cfg.predictor == CCSD_PRED_S4 ? 3 : pl->cfg.n_corr_steps + 1;
     if (step < 0 || step >= pl->cfg.diff_steps || phase < 0 || phase >= per_step) return set_err(CCSD_ERR_INVALID, "step / phase out of range");
-    return draws_to_state(pl, B, flags, nullptr, seed, sample_offset, draw_base(pl, step, phase), out, stream);
+    const int flat = pl->cfg.predictor != CCSD_PRED_S4 && phase < pl->cfg.n_corr_steps && pl->cfg.corrector == CCSD_CORR_LANGEVIN;
+    return draws_to_state(pl, B, flags, nullptr, seed, sample_offset, draw_base(pl, step, phase), out, stream, flat ? corrector_flat(pl) : 0);
 }
 
 extern "C" int ccsd_plan_query(const ccsd_plan_t* pl, int32_t what, int64_t* value) {
@@ -654,7 +664,7 @@ static int corrector_norms(ccsd_plan* pl, int B, int step, int it, const ccsd_st
                            Workspace& w, void* stream) {
     const PlanD& p = pl->h;
     int st;
-    NoiseArgs na = make_noise(noise, seed, off, draw_base(pl, step, it));
+    NoiseArgs na = make_noise(noise, seed, off, draw_base(pl, step, it), corrector_flat(pl));
     // A-net sees (x_0, adj_cur, rank2_0): hodge projections from the base rank2, edge coefficients from adj_cur.
     // When the rank2 iterate is still the base state the fused kernel serves both the A-net's projections
     // and ScoreNetworkF in one pass over rank2.
@@ -678,7 +688,24 @@ static int corrector_norms(ccsd_plan* pl, int B, int step, int it, const ccsd_st
         ep.mode = MODE_NORMS; ep.out = w.net_r; ep.part = w.part;
         if ((st = launch_hf(pl, B, cur->rank2, ep, na, w, stream))) return st;
     }
-    CCSD_LAUNCH(k_normsum, dim3(1), dim3(CCSD_NTHREADS == 1 ? 1 : (B > 512 ? 1024 : B > 256 ? 512 : 256)), 0, stream, (const float*)w.norm2, (const float*)w.part, B, ntiles,
+    const float* part = w.part;
+    if (p.is_cc && !fused) {
+        // tiled path: the noise norm of a flat-keyed Philox draw comes from its own (traffic-free) kernel; the per-tile partials of
+        // k_hf_score and its chunk partials are reduced per sample first (one workgroup per sample), then over the batch
+        const bool zk = na.flat_r && !na.zr;
+        if (zk) {
+            CCSD_LAUNCH(k_noise_norm, dim3(w.nchunk, B), dim3(CCSD_NTHREADS), 0, stream, na, (const unsigned long long*)w.offbits,
+                        (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, p.E, p.K, w.zpart);
+            LAUNCH_CHECK();
+        }
+        if (zk || ntiles > 8) {
+            CCSD_LAUNCH(k_normpart, dim3(B), dim3(CCSD_NTHREADS), 0, stream, (const float*)w.part, ntiles, zk ? (const float*)w.zpart : (const float*)nullptr,
+                        w.nchunk, w.part2);
+            LAUNCH_CHECK();
+            part = w.part2; ntiles = 1;
+        }
+    }
+    CCSD_LAUNCH(k_normsum, dim3(1), dim3(CCSD_NTHREADS == 1 ? 1 : (B > 512 ? 1024 : B > 256 ? 512 : 256)), 0, stream, (const float*)w.norm2, part, B, ntiles,
                 p.is_cc, sums);
     LAUNCH_CHECK();
     return CCSD_OK;
@@ -687,7 +714,7 @@ static int corrector_apply(ccsd_plan* pl, int B, int step, int it, const ccsd_st
                            const ccsd_noise_t* noise, uint64_t seed, int64_t off, const float* sums, ccsd_state_t* out,
                            Workspace& w, void* stream) {
     const PlanD& p = pl->h;
-    NoiseArgs na = make_noise(noise, seed, off, draw_base(pl, step, it));
+    NoiseArgs na = make_noise(noise, seed, off, draw_base(pl, step, it), corrector_flat(pl));
     LangArgs a{};
     a.x = cur->x; a.adj = cur->adj; a.r = cur->rank2;
     a.nx = w.net_x; a.nadj = w.net_adj; a.nr = w.net_r;
@@ -699,7 +726,7 @@ static int corrector_apply(ccsd_plan* pl, int B, int step, int it, const ccsd_st
     }
     a.snr = p.snr; a.seps = p.seps;
     a.B = B; a.N = p.N; a.F = p.F; a.E = p.E; a.K = p.K; a.is_cc = p.is_cc;
-    const long long total = (long long)B * (p.N * p.F + p.N * p.N) + (p.is_cc ? (long long)B * ((p.E + 3) / 4) * p.K : 0);
+    const long long total = (long long)B * (p.N * p.F + p.N * p.N) + (p.is_cc ? (long long)B * (((long long)p.E * p.K + 3) / 4) : 0);
     prof_mark(pl, KID_LANGEVIN, stream);
     CCSD_LAUNCH(k_langevin_apply, dim3(grid_for(total, 256)), dim3(CCSD_NTHREADS), 0, stream, a, na,
                 (const unsigned long long*)w.offbits, (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells);

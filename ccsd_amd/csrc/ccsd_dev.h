@@ -111,6 +111,11 @@ struct NoiseArgs {
     unsigned long long seed;
     unsigned int draw_x, draw_adj, draw_r;
     long long b_off;
+    // element -> Philox group map of the rank2 draw: 0: group (e >> 2, k) = the four edge rows 4 (e >> 2) .. + 3 of column k (the
+    // layout of an MFMA accumulator: predictor draws, priors, S4 draws); 1: group t >> 2 of the flattened index t = e K + k = four
+    // CONSECUTIVE elements of a row (the layout of a 16-byte load: the Langevin corrector's draws, generated where rank2 streams
+    // through registers -- k_r2's block load, k_langevin_apply, k_noise_norm)
+    int flat_r;
 };
 
 // Philox4x32-10 (Salmon et al. 2011), counter = (group, sample, draw, 0), key = seed
@@ -185,6 +190,16 @@ CCSD_DEV void raw_noise_r4(const NoiseArgs& na, int b, int eg, int k, int E, int
         }
     } else {
         philox_normal4(na.seed, na.draw_r, na.b_off + b, (unsigned)(eg * K + k), n);
+    }
+}
+
+// rank2 noise of flat group g: elements 4 g .. 4 g + 3 of the sample's flattened (E, K) block (NoiseArgs::flat_r == 1)
+CCSD_DEV void raw_noise_rflat4(const NoiseArgs& na, int b, int g, int EK, float* n) {
+    if (na.zr) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) n[s] = 4 * g + s < EK ? na.zr[(size_t)b * EK + 4 * g + s] : 0.f;
+    } else {
+        philox_normal4(na.seed, na.draw_r, na.b_off + b, (unsigned)g, n);
     }
 }
 

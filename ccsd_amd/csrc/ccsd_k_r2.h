@@ -45,7 +45,6 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     float* sAdj = sAco + p.a_cinit * E;    // 3 x [N*N] scratch for the powers
     float* sRed = sAdj + 3 * NN;           // [64]
     unsigned char* sFrb = reinterpret_cast<unsigned char*>(sRed + 64);   // [Kp4] flags_right (cell masks) as bytes
-    __shared__ unsigned long long s_off;
 #ifndef CCSD_EMU
     __shared__ int s_hdone;              // H-tile tasks finished (phase 1 -> 2 hand-over)
 #endif
@@ -55,59 +54,15 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     constexpr int MTF = ST ? MT - 1 : MT;                 // full 16-row tiles
     constexpr int E0 = 16 * MTF;                          // first strip row (ST)
 
-    // ---- phase 0: rank2 block -> LDS; masks; adjacency powers
+    // ---- phase 0: masks; rank2 block -> LDS (with the Langevin corrector's work on it, see below); adjacency powers
     stamp(ra.dbg, 0);
-    if (tid == 0) {
-        s_off = ra.offbits[b];                // switched-off nodes (k_flagbits): one load instead of a serial walk over the flags
 #ifndef CCSD_EMU
-        s_hdone = 0;
+    if (tid == 0) s_hdone = 0;
 #endif
-    }
-    // With the fused Langevin apply (predictor launches of ccsd_sampler_run) the raw scores of the norms pass are loaded
-    // alongside and F + c1*net goes to LDS in the same pass (same fma as k_langevin_apply; the noise term follows below).
-    float c1f = 0.f, c2f = 0.f;
-    if (ra.cf.on) corr_coef(ra.cf, 2, &c1f, &c2f);
-    const float* Ng = ra.cf.on ? ra.cf.net_r + (size_t)b * E * K : Fg;
-    if (((E * K) & 3) == 0) {
-        // the block is 16-byte aligned and a multiple of 16 bytes: batches of four float4 loads in flight per thread
-        const float4* F4 = reinterpret_cast<const float4*>(Fg);
-        const float4* N4 = reinterpret_cast<const float4*>(Ng);
-        const int n4 = (E * K) >> 2;
-        for (int base = tid; base < n4; base += 4 * nth) {
-            float4 v[4], nv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i4 = base + u * nth; v[u] = F4[i4 < n4 ? i4 : n4 - 1]; }
-            if (ra.cf.on) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const int i4 = base + u * nth; nv[u] = N4[i4 < n4 ? i4 : n4 - 1]; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    v[u].x = fmaf(c1f, nv[u].x, v[u].x); v[u].y = fmaf(c1f, nv[u].y, v[u].y);
-                    v[u].z = fmaf(c1f, nv[u].z, v[u].z); v[u].w = fmaf(c1f, nv[u].w, v[u].w);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i4 = base + u * nth;
-                if (i4 < n4) {
-                    int e, k;
-                    dK.divmod(4 * i4, e, k);
-                    const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        sF[e * ldk + k] = vv[q];
-                        if (++k == K) { k = 0; ++e; }
-                    }
-                }
-            }
-        }
-    } else {
-        for (int t = tid; t < E * K; t += nth) {
-            int e, k;
-            dK.divmod(t, e, k);
-            sF[e * ldk + k] = ra.cf.on ? fmaf(c1f, Ng[t], Fg[t]) : Fg[t];
-        }
-    }
+    // switched-off nodes of the complex (k_flagbits): a uniform address, i.e. one scalar load per wave -- no LDS round trip
+    const unsigned long long off = ra.offbits[b];
+    for (int k = tid; k < Kp4; k += nth) sFrb[k] = (k < K && !(cells[k] & off)) ? 1 : 0;
+    for (int e = tid; e < 64; e += nth) sFl[e] = e < E ? edge_on(off, edges, e) : 0.f;
     for (int t = tid; t < E * (Kp4 - K); t += nth) { const int e = t / (Kp4 - K), k = K + t % (Kp4 - K); sF[e * ldk + k] = 0.f; }
     // Second hodge layer's projections.  Linear mlp_value (every shipped checkpoint): rank2'[e,k] = fl[e] fr[k] (s[e] F[e,k] + b)
     // with s[e] = sum_c w_c a_c[e] from the adjacency powers, so  P_1 = rank2' Wcat_1 = fl (s ((F o fr) Wcat_1) + b (fr Wcat_1)):
@@ -131,10 +86,78 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
             sAdj[i] = v; sAdj[NN + i] = v;
         }
     }
-    __syncthreads();
-    const unsigned long long off = s_off;
-    for (int k = tid; k < Kp4; k += nth) sFrb[k] = (k < K && !(cells[k] & off)) ? 1 : 0;
-    for (int e = tid; e < 64; e += nth) sFl[e] = e < E ? edge_on(off, edges, e) : 0.f;
+    __syncthreads();                       // the mask tables are complete
+    // The block load.  The Langevin corrector's rank2 draw is keyed by FLAT groups of four consecutive elements (NoiseArgs::flat_r)
+    // = one 16-byte load of this loop, so the corrector's work on rank2 happens here, where the block streams through registers:
+    //  * norms launch (MODE_NORMS): the noise norm  sum (z fl fr)^2  of the draw (gen_noise_rank2 + torch.norm, cc_utils.py:613-615,
+    //    solver.py:793-797) -- the epilogue then only squares the score;
+    //  * predictor launch of ccsd_sampler_run (cf.on): the fused corrector apply  F <- fma(c2, z fl fr, fma(c1, net, F))  with the raw
+    //    scores of the norms pass loaded alongside (same expression as k_langevin_apply), one pass, no LDS read-modify-write.
+    float s_net = 0.f, s_z = 0.f;
+    {
+        float c1f = 0.f, c2f = 0.f;
+        if (ra.cf.on) corr_coef(ra.cf, 2, &c1f, &c2f);
+        NoiseArgs nc = na;                                   // the corrector draw of this launch
+        if (ra.cf.on) { nc.zr = nullptr; nc.draw_r = ra.cf.draw_r; }
+        const bool znorm = ep.mode == MODE_NORMS && na.flat_r, zuse = znorm || ra.cf.on;
+        const float* Ng = ra.cf.on ? ra.cf.net_r + (size_t)b * E * K : Fg;
+        const int EK = E * K;
+        if ((EK & 3) == 0) {
+            // the block is 16-byte aligned and a multiple of 16 bytes: batches of four float4 loads in flight per thread
+            const float4* F4 = reinterpret_cast<const float4*>(Fg);
+            const float4* N4 = reinterpret_cast<const float4*>(Ng);
+            const int n4 = EK >> 2;
+            for (int base = tid; base < n4; base += 4 * nth) {
+                float4 v[4], nv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int i4 = base + u * nth; v[u] = F4[i4 < n4 ? i4 : n4 - 1]; }
+                if (ra.cf.on) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int i4 = base + u * nth; nv[u] = N4[i4 < n4 ? i4 : n4 - 1]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i4 = base + u * nth;
+                    if (i4 < n4) {
+                        int e, k;
+                        dK.divmod(4 * i4, e, k);
+                        float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                        if (zuse) {
+                            const float nn[4] = {nv[u].x, nv[u].y, nv[u].z, nv[u].w};
+                            float z[4];
+                            raw_noise_rflat4(nc, b, i4, EK, z);
+                            int e2 = e, k2 = k;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float zz = z[q] * sFl[e2] * (float)sFrb[k2];
+                                if (znorm) s_z = fmaf(zz, zz, s_z);
+                                if (ra.cf.on) vv[q] = fmaf(c2f, zz, fmaf(c1f, nn[q], vv[q]));
+                                if (++k2 == K) { k2 = 0; ++e2; }
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            sF[e * ldk + k] = vv[q];
+                            if (++k == K) { k = 0; ++e; }
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int t = tid; t < EK; t += nth) {
+                int e, k;
+                dK.divmod(t, e, k);
+                float v = Fg[t];
+                if (zuse) {
+                    const float z = nc.zr ? nc.zr[(size_t)b * EK + t] : philox_normal1(nc.seed, nc.draw_r, nc.b_off + b, (unsigned)t);
+                    const float zz = z * sFl[e] * (float)sFrb[k];
+                    if (znorm) s_z = fmaf(zz, zz, s_z);
+                    if (ra.cf.on) v = fmaf(c2f, zz, fmaf(c1f, Ng[t], v));
+                }
+                sF[e * ldk + k] = v;
+            }
+        }
+    }
     if (adjpow) {
         // acoef[c][e] = (adj^(c+1))[i_e][j_e]   (pow_tensor + adj_to_hodgedual, graph_utils.py:285-292, cc_utils.py:1525-1536)
         float* A = sAdj; float* P0_ = sAdj + NN; float* P1_ = sAdj + 2 * NN;
@@ -154,30 +177,6 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
         }
     }
     __syncthreads();
-    if (ra.cf.on) {
-        // fused Langevin corrector apply on the LDS-resident block, noise term: F <- (F + c1*net) + c2*z (masked)
-        const float c2 = c2f;
-        NoiseArgs nc = na;
-        nc.zr = nullptr; nc.draw_r = ra.cf.draw_r;
-        const int egn = (E + 3) >> 2;
-        for (int t = tid; t < egn * K; t += nth) {
-            int eg, k;
-            dK.divmod(t, eg, k);
-            float z[4];
-            raw_noise_r4(nc, b, eg, k, E, K, z);
-            const float fr = (float)sFrb[k];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int e = 4 * eg + r;
-                if (e < E) {
-                    // same expression as k_langevin_apply: fma(c2, z*fl*fr, fma(c1, net, v))
-                    const float zz = z[r] * sFl[e] * fr;
-                    sF[e * ldk + k] = fmaf(c2, zz, sF[e * ldk + k]);
-                }
-            }
-        }
-        __syncthreads();
-    }
     stamp(ra.dbg, 1);
     const HodgeLayerD& h0 = p.hl[0];
     const HodgeLayerD& h1 = p.hl[1];
@@ -461,12 +460,14 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     // ---- phase 2: (H F) per 16-column tile, ScoreNetworkF element-wise, epilogue straight to HBM.
     // H's A-fragments live in registers for the whole phase.
     stamp(ra.dbg, 3);
-    float s_net = 0.f, s_z = 0.f;
+    // norms launch: the noise norm of a flat-keyed corrector draw was taken in phase 0; only a draw keyed by 4-row groups (the S4
+    // sampler's first draw) is generated -- and squared -- in the epilogue
+    const bool eznorm = !na.flat_r;
     const int ntn = (K + 15) >> 4, ksE = Ep4 >> 2;
     auto epi4 = [&](int e0, int k, const float* hf) {
         if (e0 >= E || k >= K) return;
         float z[4] = {0.f, 0.f, 0.f, 0.f};
-        if (ep.mode != MODE_SCORE) raw_noise_r4(na, b, e0 >> 2, k, E, K, z);   // one Philox group = 4 edge rows
+        if (ep.mode == MODE_PRED || (ep.mode == MODE_NORMS && eznorm)) raw_noise_r4(na, b, e0 >> 2, k, E, K, z);   // one Philox group = 4 edge rows
         const float fr = (float)sFrb[k];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                 if (ep.mode == MODE_NORMS) {
                     ep.out[gi] = net;
                     s_net = fmaf(net, net, s_net);
-                    s_z = fmaf(zz, zz, s_z);
+                    if (eznorm) s_z = fmaf(zz, zz, s_z);
                 } else {
                     const float mean = fmaf(ep.pa, f, ep.pb * net);
                     if (ep.mean) ep.mean[gi] = mean;
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                 for (int i = 0; i < TF; ++i) {
                     const int e0 = 16 * i + 4 * kq;
                     float z[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (MODE != 0) {
+                    if (MODE >= 2 || (MODE == 1 && eznorm)) {
                         if (INJ) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) z[r] = zrp[gi + (unsigned)(r * K)];
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                             if (MODE == 1) {
                                 outp[g] = net;
                                 s_net = fmaf(net, net, s_net);
-                                s_z = fmaf(zz, zz, s_z);
+                                if (eznorm) s_z = fmaf(zz, zz, s_z);
                             } else {
                                 const float mean = fmaf(pa, f, net);     // v_mean = pa v + pb net (pb folded into net)
                                 if (MODE == 3) meanp[g] = mean;
@@ -663,7 +664,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                 const float fr = (float)sFrb[n];
                 const unsigned gi = (unsigned)(E0 * K + n);
                 float z[4] = {0.f, 0.f, 0.f, 0.f};
-                if (MODE != 0) {
+                if (MODE >= 2 || (MODE == 1 && eznorm)) {
                     if (INJ) {
                         const float* const zrp = na.zr + (size_t)b * E * K;
 #pragma unroll
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                             if (MODE == 1) {
                                 outp[g] = net;
                                 s_net = fmaf(net, net, s_net);
-                                s_z = fmaf(zz, zz, s_z);
+                                if (eznorm) s_z = fmaf(zz, zz, s_z);
                             } else {
                                 const float mean = fmaf(pa, f, net);
                                 if (MODE == 3) meanp[g] = mean;
@@ -841,7 +842,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                         const int e0 = 16 * i + 4 * kq;
                         if (!last || e0 < E) {
                             float z[4] = {0.f, 0.f, 0.f, 0.f};
-                            if (MODE != 0) {
+                            if (MODE >= 2 || (MODE == 1 && eznorm)) {
                                 if (INJ) {
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) z[r] = (!last || e0 + r < E) ? zrp[gi + (unsigned)(r * K)] : 0.f;
@@ -866,7 +867,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                                         if (MODE == 1) {
                                             outp[g] = net;
                                             s_net = fmaf(net, net, s_net);
-                                            s_z = fmaf(zz, zz, s_z);
+                                            if (eznorm) s_z = fmaf(zz, zz, s_z);
                                         } else {
                                             const float mean = fmaf(pa, f, net); // v_mean = pa v + pb net (pb folded into net)
                                             if (MODE == 3) meanp[g] = mean;

@@ -421,12 +421,14 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
     }
     const unsigned long long off = offbits[b];
     float s_net = 0.f, s_z = 0.f;
+    const bool znorm = !na.flat_r || na.zr != nullptr;   // host-supplied draws are read per element, whatever the group layout
     tile_foreach4n<NP>(accs, [&](int ml, int nl, const float (*hfp)[4]) {
         const int k = n0 + nl, e0 = m0 + ml;
         if (k >= K || e0 >= E) return;
         const float fr = cell_on(off, cells, k);
         float z[4] = {0.f, 0.f, 0.f, 0.f};
-        if (ep.mode != MODE_SCORE) raw_noise_r4(na, b, e0 >> 2, k, E, K, z);
+        // (norms launch of a flat-keyed corrector draw with in-kernel Philox: its noise norm comes from k_noise_norm)
+        if (ep.mode == MODE_PRED || (ep.mode == MODE_NORMS && znorm)) raw_noise_r4(na, b, e0 >> 2, k, E, K, z);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int e = e0 + s;

@@ -11,7 +11,7 @@ __global__ void k_normsum(const float* __restrict__ norm2, const float* __restri
                           int is_cc, float* __restrict__ sums) {
     // up to 1024 threads: one sample per thread and one L2 round trip for B <= 1024; the six sums are reduced together (wave
     // butterflies, one barrier, a fixed-order pass over the waves) -- the launch sits between the norms pass and the predictor
-    // kernels of every PC step, so its latency is on the step's critical path
+    // kernels of every PC step, so its latency is on the step's critical path.  (Many tiles per sample: k_normpart first.)
     __shared__ float red[16 * 6];
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
@@ -51,6 +51,57 @@ __global__ void k_normsum(const float* __restrict__ norm2, const float* __restri
 #endif
 }
 
+// k_normpart: first level of the norm reduction when a sample has many partials (tiled rank-2 path: one pair per 64 x 64 tile of
+// k_hf_score, plus the chunk partials of k_noise_norm): out[b] = { sum_t part[b][t][0], sum_t part[b][t][1] + sum_c zpart[b][c] }.
+// One workgroup per sample, fixed summation order (deterministic).  k_normsum then runs with ntiles = 1 on `out`.
+__global__ void k_normpart(const float* __restrict__ part, int ntiles, const float* __restrict__ zpart, int nchunk,
+                           float* __restrict__ out) {
+    __shared__ float red[64];
+    const int b = blockIdx.x;
+    float sn = 0.f, sz = 0.f;
+    for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
+        const float* p2 = part + ((size_t)b * ntiles + t) * 2;
+        sn += p2[0];
+        sz += p2[1];
+    }
+    if (zpart)
+        for (int c = threadIdx.x; c < nchunk; c += blockDim.x) sz += zpart[(size_t)b * nchunk + c];
+    const float tn = block_sum(sn, red);
+    const float tz = block_sum(sz, red);
+    if (threadIdx.x == 0) { out[(size_t)b * 2 + 0] = tn; out[(size_t)b * 2 + 1] = tz; }
+}
+
+// k_noise_norm: sum of squares of the masked rank2 noise of a corrector draw, per sample and chunk (tiled rank-2 path, Philox
+// noise: the draw is keyed by flat groups, NoiseArgs::flat_r, so the MFMA-layout epilogue of k_hf_score cannot produce it
+// cheaply; pure arithmetic, no rank2 traffic).  zpart[b][chunk] = sum over the chunk's groups of (z fl fr)^2
+// (gen_noise_rank2 + torch.norm, cc_utils.py:613-615, solver.py:793-797).  grid (nchunk, B); CH groups per workgroup.
+#define CCSD_NN_CH 4096
+__global__ void k_noise_norm(NoiseArgs na, const unsigned long long* __restrict__ offbits, const unsigned char* __restrict__ edges,
+                             const unsigned long long* __restrict__ cells, int E, int K, float* __restrict__ zpart) {
+    __shared__ float red[64];
+    const int b = blockIdx.y, EK = E * K, ng = (EK + 3) >> 2;
+    const unsigned long long off = offbits[b];
+    const int g0 = blockIdx.x * CCSD_NN_CH, g1 = g0 + CCSD_NN_CH < ng ? g0 + CCSD_NN_CH : ng;
+    const FastDiv dK(K);
+    float acc = 0.f;
+    for (int g = g0 + threadIdx.x; g < g1; g += blockDim.x) {
+        float z[4];
+        raw_noise_rflat4(na, b, g, EK, z);
+        int e, k;
+        dK.divmod(4 * g, e, k);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (4 * g + s < EK) {
+                const float zz = z[s] * edge_on(off, edges, e) * cell_on(off, cells, k);
+                acc = fmaf(zz, zz, acc);
+            }
+            if (++k == K) { k = 0; ++e; }
+        }
+    }
+    const float t = block_sum(acc, red);
+    if (threadIdx.x == 0) zpart[(size_t)b * gridDim.x + blockIdx.x] = t;
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_langevin_apply: step = (snr * zn / gn)^2 * 2 * alpha; v_mean = v + step*score;
 // v = v_mean + sqrt(2 step) * z * scale_eps          (solver.py:767-769, 781-783, 797-801)
@@ -77,38 +128,62 @@ CCSD_DEV void langevin_coef(const LangArgs& a, int t, float* c1, float* c2) {
 __global__ void k_langevin_apply(LangArgs a, NoiseArgs na, const unsigned long long* __restrict__ offbits,
                                  const unsigned char* __restrict__ edges, const unsigned long long* __restrict__ cells) {
     const long long nxe = (long long)a.B * a.N * a.F, nae = (long long)a.B * a.N * a.N;
-    const long long nre = a.is_cc ? (long long)a.B * ((a.E + 3) / 4) * a.K : 0;  // one thread per 4-edge group x column
+    // rank2: one thread per flat Philox group = four consecutive elements of the sample's (E, K) block (NoiseArgs::flat_r): with
+    // E K a multiple of 4 every group is one aligned 16-byte load of the state, one of the raw score and one 16-byte store
+    const int EK = a.E * a.K, ng = (EK + 3) >> 2;
+    const long long nre = a.is_cc ? (long long)a.B * ng : 0;
     const long long total = nxe + nae + nre;
+    const bool vec = (EK & 3) == 0;
     float c1x, c2x, c1a, c2a, c1r = 0.f, c2r = 0.f;
     langevin_coef(a, 0, &c1x, &c2x);
     langevin_coef(a, 1, &c1a, &c2a);
     if (a.is_cc) langevin_coef(a, 2, &c1r, &c2r);
+    const FastDiv dK(a.K > 0 ? a.K : 1);
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-        if (t < nxe) {
-            const int per = a.N * a.F, b = (int)(t / per), idx = (int)(t % per), i = idx / a.F;
+        if (t < nre) {                                           // (the rank2 groups come first: the bulk of the work, aligned)
+            const int b = (int)(t / ng), g = (int)(t - (long long)b * ng);
+            const size_t base = (size_t)b * EK + 4 * (size_t)g;
+            float v[4], nv[4], z[4];
+            if (vec) {
+                const float4 v4 = *reinterpret_cast<const float4*>(a.r + base), n4 = *reinterpret_cast<const float4*>(a.nr + base);
+                v[0] = v4.x; v[1] = v4.y; v[2] = v4.z; v[3] = v4.w;
+                nv[0] = n4.x; nv[1] = n4.y; nv[2] = n4.z; nv[3] = n4.w;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const bool in = 4 * g + s < EK;
+                    v[s] = in ? a.r[base + s] : 0.f;
+                    nv[s] = in ? a.nr[base + s] : 0.f;
+                }
+            }
+            raw_noise_rflat4(na, b, g, EK, z);
+            const unsigned long long off = offbits[b];
+            int e, k;
+            dK.divmod(4 * g, e, k);
+            float o[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int ec = e < a.E ? e : a.E - 1;           // (beyond the block only in a ragged last group: never stored)
+                const float zz = z[s] * edge_on(off, edges, ec) * cell_on(off, cells, k);
+                o[s] = fmaf(c2r, zz, fmaf(c1r, nv[s], v[s]));
+                if (++k == a.K) { k = 0; ++e; }
+            }
+            if (vec) *reinterpret_cast<float4*>(a.orr + base) = make_float4(o[0], o[1], o[2], o[3]);
+            else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (4 * g + s < EK) a.orr[base + s] = o[s];
+            }
+        } else if (t < nre + nxe) {
+            const long long u = t - nre;
+            const int per = a.N * a.F, b = (int)(u / per), idx = (int)(u % per), i = idx / a.F;
             const float z = raw_noise_x(na, b, idx, per) * a.flags[(size_t)b * a.N + i];
-            a.ox[t] = fmaf(c2x, z, fmaf(c1x, a.nx[t], a.x[t]));
-        } else if (t < nxe + nae) {
-            const long long u = t - nxe;
+            a.ox[u] = fmaf(c2x, z, fmaf(c1x, a.nx[u], a.x[u]));
+        } else {
+            const long long u = t - nre - nxe;
             const int per = a.N * a.N, b = (int)(u / per), ij = (int)(u % per), i = ij / a.N, j = ij % a.N;
             const float z = raw_noise_adj(na, b, i, j, a.N) * a.flags[(size_t)b * a.N + i] * a.flags[(size_t)b * a.N + j];
             a.oadj[u] = fmaf(c2a, z, fmaf(c1a, a.nadj[u], a.adj[u]));
-        } else {
-            const long long u = t - nxe - nae;
-            const int eg_n = (a.E + 3) / 4;
-            const int k = (int)(u % a.K), eg = (int)((u / a.K) % eg_n), b = (int)(u / ((long long)a.K * eg_n));
-            float z[4];
-            raw_noise_r4(na, b, eg, k, a.E, a.K, z);
-            const unsigned long long off = offbits[b];
-            const float fr = cell_on(off, cells, k);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int e = 4 * eg + s;
-                if (e >= a.E) continue;
-                const size_t gi = ((size_t)b * a.E + e) * a.K + k;
-                const float zz = z[s] * edge_on(off, edges, e) * fr;
-                a.orr[gi] = fmaf(c2r, zz, fmaf(c1r, a.nr[gi], a.r[gi]));
-            }
         }
     }
 }
@@ -189,11 +264,23 @@ __global__ void k_init_state(float* x, float* adj, float* r, const float* __rest
                              const unsigned long long* __restrict__ offbits, const unsigned char* __restrict__ edges,
                              const unsigned long long* __restrict__ cells, int B, int N, int F, int E, int K, int is_cc) {
     const long long nxe = (long long)B * N * F, nae = (long long)B * N * N;
-    const int eg_n = (E + 3) / 4;
-    const long long nre = is_cc ? (long long)B * eg_n * K : 0;
+    const int eg_n = (E + 3) / 4, EK = E * K, ng = (EK + 3) >> 2;
+    const long long nre = is_cc ? (na.flat_r ? (long long)B * ng : (long long)B * eg_n * K) : 0;
     const long long total = nxe + nae + nre;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-        if (t < nxe) {
+        if (t >= nxe + nae && na.flat_r) {            // a corrector draw: flat groups (ccsd_noise_draws)
+            const long long u = t - nxe - nae;
+            const int b = (int)(u / ng), g = (int)(u - (long long)b * ng);
+            float z[4];
+            raw_noise_rflat4(na, b, g, EK, z);
+            const unsigned long long off = offbits[b];
+            int e = (4 * g) / K, k = (4 * g) % K;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (4 * g + s < EK) r[(size_t)b * EK + 4 * g + s] = edge_on(off, edges, e) * z[s] * cell_on(off, cells, k);
+                if (++k == K) { k = 0; ++e; }
+            }
+        } else if (t < nxe) {
             const int per = N * F, b = (int)(t / per), idx = (int)(t % per);
             x[t] = raw_noise_x(na, b, idx, per) * flags[(size_t)b * N + idx / F];
         } else if (t < nxe + nae) {
