@@ -61,6 +61,7 @@ struct ccsd_plan {
     // diagnostic knobs, read from the environment ONCE at plan creation (never on the launch path):
     // CCSD_OLD_GEMM_P, CCSD_XA_THREADS, CCSD_NO_FUSED_APPLY (CCSD_NO_FUSED_R2 / CCSD_XA_PASS / CCSD_XA_GCH / CCSD_NO_CHAIN shape the plan itself)
     int opt_old_gemm_p = 0, opt_xa_threads = 256, opt_no_fused_apply = 0;
+    int opt_r2_stagger_mask = 0, opt_r2_stagger_sleep = 0;     // CCSD_R2_STAGGER="mask,sleep" (diagnostic)
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     unsigned prof_mask = 0;
     size_t prof_used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -214,6 +215,7 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     pl->cfg = *cfg;
     pl->opt_old_gemm_p = getenv("CCSD_OLD_GEMM_P") != nullptr;
     pl->opt_no_fused_apply = getenv("CCSD_NO_FUSED_APPLY") != nullptr;
+    if (const char* sg = getenv("CCSD_R2_STAGGER")) sscanf(sg, "%d,%d", &pl->opt_r2_stagger_mask, &pl->opt_r2_stagger_sleep);
     if (const char* xt = getenv("CCSD_XA_THREADS")) { const int v = atoi(xt); if (v >= 64 && v <= 512 && v % 64 == 0) pl->opt_xa_threads = v; }
     PlanBuilder pb;
     pl->nweights = ccsd_build_plan(cfg, &pl->h, pb);
@@ -531,6 +533,7 @@ static int launch_r2(const ccsd_plan* pl, int B, const float* rank2, const float
     if (cf) ra.cf = *cf;
     ra.rank2 = rank2; ra.adj = adj; ra.flags = flags; ra.offbits = w.offbits; ra.P0 = w.P0; ra.P1 = w.P1; ra.U1 = w.U1; ra.want_p = want_p;
     ra.ldk = pl->r2_ldk; ra.ldh = pl->r2_ldh; ra.dbg = pl->dbg; ra.wp = pl->wp;
+    ra.stagger_mask = pl->opt_r2_stagger_mask; ra.stagger_sleep = pl->opt_r2_stagger_sleep;
     if (want_p && pl->h.h_L > 1) w.p1_raw = pl->h.hl[0].mval.n == 1;
     prof_mark(const_cast<ccsd_plan*>(pl), KID_R2, stream);
     const dim3 blk(CCSD_NTHREADS == 1 ? 1 : 512);

@@ -3,12 +3,16 @@
 #pragma once
 #include "ccsd_rank2_common.h"
 
+#ifndef CCSD_R2_LB
+#define CCSD_R2_LB 4       // float4 loads in flight per thread in the block load (without the raw scores alongside)
+#endif
 struct R2Args {
     const float* rank2; const float* adj; const float* flags;
     const unsigned long long* offbits;     // per-sample bitmask of switched-off nodes
     float* P0; float* P1;
     float* U1;             // [B][wc_1]: fr . Wcat_1 of the complex (linear mlp_value: P1 then holds the raw (F o fr) Wcat_1)
     int want_p;            // write the hodge projections (the A-network will run on the same state)
+    int stagger_mask, stagger_sleep;   // workgroups with (blockIdx.x & mask) != 0 start `sleep` x 64 cycles late (see launch_r2)
     int ldk, ldh;
     long long* dbg;
     const float* wp;       // packed buffer (Wcat^T of the hodge projections)
@@ -61,9 +65,6 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
 #endif
     // switched-off nodes of the complex (k_flagbits): a uniform address, i.e. one scalar load per wave -- no LDS round trip
     const unsigned long long off = ra.offbits[b];
-    for (int k = tid; k < Kp4; k += nth) sFrb[k] = (k < K && !(cells[k] & off)) ? 1 : 0;
-    for (int e = tid; e < 64; e += nth) sFl[e] = e < E ? edge_on(off, edges, e) : 0.f;
-    for (int t = tid; t < E * (Kp4 - K); t += nth) { const int e = t / (Kp4 - K), k = K + t % (Kp4 - K); sF[e * ldk + k] = 0.f; }
     // Second hodge layer's projections.  Linear mlp_value (every shipped checkpoint): rank2'[e,k] = fl[e] fr[k] (s[e] F[e,k] + b)
     // with s[e] = sum_c w_c a_c[e] from the adjacency powers, so  P_1 = rank2' Wcat_1 = fl (s ((F o fr) Wcat_1) + b (fr Wcat_1)):
     // this kernel delivers the two adjacency-independent factors -- Q_1 = (F o fr) Wcat_1 (in P1) and u_1 = fr Wcat_1 (in U1) --
@@ -71,28 +72,49 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     // powers here (rank2' is then formed element by element in the GEMM's loader).
     const int hodge2 = (p.h_L > 1) && ra.want_p;
     const bool adjpow = hodge2 && p.hl[0].mval.n > 1;
-    if (adjpow) {
-        float c1a = 0.f, c2a = 0.f;
-        if (ra.cf.on) corr_coef(ra.cf, 1, &c1a, &c2a);
-        for (int i = tid; i < NN; i += nth) {
-            float v = ra.adj[(size_t)b * NN + i];
-            if (ra.cf.on) {   // the A-network of the predictor sees the corrected adjacency
-                NoiseArgs nc = na;
-                nc.zadj = nullptr; nc.draw_adj = ra.cf.draw_adj;
-                const int ii = i / N, jj = i % N;
-                const float z = raw_noise_adj(nc, b, ii, jj, N) * ra.flags[(size_t)b * N + ii] * ra.flags[(size_t)b * N + jj];
-                v = fmaf(c2a, z, fmaf(c1a, ra.cf.net_adj[(size_t)b * NN + i], v));
+    // mask tables, zero padding of the K tail, adjacency of the general mlp_value path; ends with the barrier that publishes them
+    // (`between`: called after the tables' own global loads are requested and before they are used -- the block load puts its first
+    // batch there, so that the in-order return of vector loads delivers the few table bytes first)
+    auto build_tables = [&](auto&& between) {
+        unsigned long long cw[2];
+        unsigned int ew = 0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int k = tid + u * nth; cw[u] = cells[k < K ? k : K - 1]; }
+        if (tid < 64) ew = *reinterpret_cast<const unsigned short*>(edges + 2 * (tid < E ? tid : E - 1));
+        between();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int k = tid + u * nth; if (k < Kp4) sFrb[k] = (k < K && !(cw[u] & off)) ? 1 : 0; }
+        for (int k = tid + 2 * nth; k < Kp4; k += nth) sFrb[k] = (k < K && !(cells[k] & off)) ? 1 : 0;
+        if (tid < 64) sFl[tid] = (tid < E && !(((off >> (ew & 0xffu)) | (off >> (ew >> 8))) & 1ull)) ? 1.f : 0.f;
+        for (int e = tid + nth; e < 64; e += nth) sFl[e] = e < E ? edge_on(off, edges, e) : 0.f;    // (fewer than 64 threads: host emulation)
+        for (int t = tid; t < E * (Kp4 - K); t += nth) { const int e = t / (Kp4 - K), k = K + t % (Kp4 - K); sF[e * ldk + k] = 0.f; }
+        if (adjpow) {
+            float c1a = 0.f, c2a = 0.f;
+            if (ra.cf.on) corr_coef(ra.cf, 1, &c1a, &c2a);
+            for (int i = tid; i < NN; i += nth) {
+                float v = ra.adj[(size_t)b * NN + i];
+                if (ra.cf.on) {   // the A-network of the predictor sees the corrected adjacency
+                    NoiseArgs nc = na;
+                    nc.zadj = nullptr; nc.draw_adj = ra.cf.draw_adj;
+                    const int ii = i / N, jj = i % N;
+                    const float z = raw_noise_adj(nc, b, ii, jj, N) * ra.flags[(size_t)b * N + ii] * ra.flags[(size_t)b * N + jj];
+                    v = fmaf(c2a, z, fmaf(c1a, ra.cf.net_adj[(size_t)b * NN + i], v));
+                }
+                sAdj[i] = v; sAdj[NN + i] = v;
             }
-            sAdj[i] = v; sAdj[NN + i] = v;
         }
-    }
-    __syncthreads();                       // the mask tables are complete
+        __syncthreads();
+        stamp(ra.dbg, 8);
+    };
     // The block load.  The Langevin corrector's rank2 draw is keyed by FLAT groups of four consecutive elements (NoiseArgs::flat_r)
     // = one 16-byte load of this loop, so the corrector's work on rank2 happens here, where the block streams through registers:
     //  * norms launch (MODE_NORMS): the noise norm  sum (z fl fr)^2  of the draw (gen_noise_rank2 + torch.norm, cc_utils.py:613-615,
     //    solver.py:793-797) -- the epilogue then only squares the score;
     //  * predictor launch of ccsd_sampler_run (cf.on): the fused corrector apply  F <- fma(c2, z fl fr, fma(c1, net, F))  with the raw
     //    scores of the norms pass loaded alongside (same expression as k_langevin_apply), one pass, no LDS read-modify-write.
+    // The loop is double buffered: the loads of batch i + 1 are in flight while batch i is processed (Philox + Box-Muller are ~100
+    // vector instructions per group); the first batch is requested before the mask tables are built.  With K even (and E K a
+    // multiple of 4) a group is two aligned pairs (e, k..k+1), (e', k'..k'+1): masks and LDS stores go pair-wise.
     float s_net = 0.f, s_z = 0.f;
     {
         float c1f = 0.f, c2f = 0.f;
@@ -102,48 +124,81 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
         const bool znorm = ep.mode == MODE_NORMS && na.flat_r, zuse = znorm || ra.cf.on;
         const float* Ng = ra.cf.on ? ra.cf.net_r + (size_t)b * E * K : Fg;
         const int EK = E * K;
-        if ((EK & 3) == 0) {
-            // the block is 16-byte aligned and a multiple of 16 bytes: batches of four float4 loads in flight per thread
+        if ((EK & 3) == 0 && (K & 1) == 0) {
             const float4* F4 = reinterpret_cast<const float4*>(Fg);
             const float4* N4 = reinterpret_cast<const float4*>(Ng);
+            const float4* Z4 = reinterpret_cast<const float4*>(nc.zr ? nc.zr + (size_t)b * EK : Fg);
             const int n4 = EK >> 2;
-            for (int base = tid; base < n4; base += 4 * nth) {
-                float4 v[4], nv[4];
+            const FastDiv dK2(K >> 1);                        // pair index -> (row, pair within the row)
+            auto phase0 = [&](auto LB_, auto CF_, auto ZN_) {
+                constexpr int LB = decltype(LB_)::value;      // float4 loads per thread and batch
+                constexpr bool CF = decltype(CF_)::value;     // fused corrector apply: the raw scores are loaded alongside
+                constexpr bool ZN = decltype(ZN_)::value;     // noise norm of the corrector draw
+                constexpr int LN = CF ? LB : 1;
+                float4 va[LB], vb[LB], qa[LN], qb[LN];
+                auto issue = [&](float4* v, float4* q, int base) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int i4 = base + u * nth; v[u] = F4[i4 < n4 ? i4 : n4 - 1]; }
-                if (ra.cf.on) {
+                    for (int u = 0; u < LB; ++u) { const int i4 = base + u * nth; v[u] = F4[i4 < n4 ? i4 : n4 - 1]; }
+                    if (CF) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) { const int i4 = base + u * nth; nv[u] = N4[i4 < n4 ? i4 : n4 - 1]; }
-                }
+                        for (int u = 0; u < LB; ++u) { const int i4 = base + u * nth; q[CF ? u : 0] = N4[i4 < n4 ? i4 : n4 - 1]; }
+                    }
+                };
+                auto consume = [&](const float4* v, const float4* q, int base) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i4 = base + u * nth;
-                    if (i4 < n4) {
-                        int e, k;
-                        dK.divmod(4 * i4, e, k);
-                        float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-                        if (zuse) {
-                            const float nn[4] = {nv[u].x, nv[u].y, nv[u].z, nv[u].w};
-                            float z[4];
-                            raw_noise_rflat4(nc, b, i4, EK, z);
-                            int e2 = e, k2 = k;
+                    for (int u = 0; u < LB; ++u) {
+                        const int i4 = base + u * nth;
+                        if (i4 < n4) {
+                            int e, kp;
+                            dK2.divmod(2 * i4, e, kp);                       // first pair of the group: row e, columns 2 kp, 2 kp + 1
+                            const int k = 2 * kp;
+                            const bool wrap = k + 2 == K;                    // second pair starts the next row
+                            const int e1 = wrap ? e + 1 : e, k1 = wrap ? 0 : k + 2;
+                            float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                            if (CF || ZN) {
+                                float z[4];
+                                if (nc.zr) { const float4 z4 = Z4[i4]; z[0] = z4.x; z[1] = z4.y; z[2] = z4.z; z[3] = z4.w; }
+                                else philox_normal4(nc.seed, nc.draw_r, nc.b_off + b, (unsigned)i4, z);
+                                const unsigned f0 = *reinterpret_cast<const unsigned short*>(sFrb + k), f1 = *reinterpret_cast<const unsigned short*>(sFrb + k1);
+                                const float fl0 = sFl[e], fl1 = sFl[e1];
+                                const float m[4] = {fl0 * (float)(f0 & 0xffu), fl0 * (float)(f0 >> 8), fl1 * (float)(f1 & 0xffu), fl1 * (float)(f1 >> 8)};
+                                const float4 n4v = q[CF ? u : 0];
+                                const float nn[4] = {n4v.x, n4v.y, n4v.z, n4v.w};
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const float zz = z[q] * sFl[e2] * (float)sFrb[k2];
-                                if (znorm) s_z = fmaf(zz, zz, s_z);
-                                if (ra.cf.on) vv[q] = fmaf(c2f, zz, fmaf(c1f, nn[q], vv[q]));
-                                if (++k2 == K) { k2 = 0; ++e2; }
+                                for (int j = 0; j < 4; ++j) {
+                                    const float zz = z[j] * m[j];
+                                    if (ZN) s_z = fmaf(zz, zz, s_z);
+                                    if (CF) vv[j] = fmaf(c2f, zz, fmaf(c1f, nn[j], vv[j]));
+                                }
                             }
-                        }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            sF[e * ldk + k] = vv[q];
-                            if (++k == K) { k = 0; ++e; }
+                            *reinterpret_cast<float2*>(sF + e * ldk + k) = make_float2(vv[0], vv[1]);
+                            *reinterpret_cast<float2*>(sF + e1 * ldk + k1) = make_float2(vv[2], vv[3]);
                         }
                     }
+                };
+                const int step = LB * nth;
+                int base = tid;
+                build_tables([&]() { issue(va, qa, base); });
+                while (true) {
+                    const bool more_b = base - tid + step < n4;              // (uniform)
+                    if (more_b) issue(vb, qb, base + step);
+                    consume(va, qa, base);
+                    if (!more_b) break;
+                    base += step;
+                    const bool more_a = base - tid + step < n4;
+                    if (more_a) issue(va, qa, base + step);
+                    consume(vb, qb, base);
+                    if (!more_a) break;
+                    base += step;
                 }
-            }
+            };
+            typedef std::integral_constant<bool, true> T_;
+            typedef std::integral_constant<bool, false> F_;
+            if (ra.cf.on) phase0(std::integral_constant<int, 3>{}, T_{}, F_{});
+            else if (znorm) phase0(std::integral_constant<int, 3>{}, F_{}, T_{});
+            else phase0(std::integral_constant<int, 3>{}, F_{}, F_{});
         } else {
+            build_tables([]() {});
             for (int t = tid; t < EK; t += nth) {
                 int e, k;
                 dK.divmod(t, e, k);
@@ -158,6 +213,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
             }
         }
     }
+    stamp(ra.dbg, 9);
     if (adjpow) {
         // acoef[c][e] = (adj^(c+1))[i_e][j_e]   (pow_tensor + adj_to_hodgedual, graph_utils.py:285-292, cc_utils.py:1525-1536)
         float* A = sAdj; float* P0_ = sAdj + NN; float* P1_ = sAdj + 2 * NN;

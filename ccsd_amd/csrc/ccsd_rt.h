@@ -29,6 +29,8 @@ struct dim3 {
 };
 struct float4 { float x, y, z, w; };
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+struct float2 { float x, y; };
+static inline float2 make_float2(float a, float b) { return float2{a, b}; }
 static dim3 threadIdx(0, 0, 0), blockIdx(0, 0, 0), blockDim(1, 1, 1), gridDim(1, 1, 1);
 static inline void __syncthreads() {}
 static float* emu_smem = nullptr;
