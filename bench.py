@@ -73,11 +73,11 @@ WORKLOADS = {
 # one of the two figures exists.  Neither roofline is what actually limits k_r2 / k_xa: they are bound by vector-instruction
 # issue (on gfx950 an fp32 MFMA and VALU work share the SIMD's vector pipe), reported as `issue_frac`.
 KERNEL_BOUND = {"k_xa": "mfma", "k_r2": "mfma", "k_hf_score": "hbm", "k_gemm_h": "mfma", "k_gemm_p": "mfma", "k_langevin_apply": "hbm",
-                "k_s4_apply": "hbm"}
+                "k_s4_apply": "hbm", "k_ew1": "hbm"}
 KERNEL_LIMITER = {"k_r2": "vector-instruction issue: fp32 MFMA (32 cycles each) and VALU (2 cycles each) share one pipe per SIMD",
                   "k_xa": "latency of one graph's critical path (barrier intervals), then vector-instruction issue"}
 N_SIMDS, MAX_CLOCK_HZ = 1024, 2.4e9                       # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md chip table
-KERNEL_NAMES = ["k_xa", "k_r2", "k_hf_score", "k_gemm_h", "k_gemm_p", "k_langevin_apply", "k_s4_apply"]
+KERNEL_NAMES = ["k_xa", "k_r2", "k_hf_score", "k_gemm_h", "k_gemm_p", "k_langevin_apply", "k_s4_apply", "k_ew1"]
 PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r02_pmc.json", "r01_pmc_traffic.json")]   # newest first
 KERNEL_SOURCES = [os.path.join(ROOT, "ccsd_amd", "csrc", f) for f in ("ccsd_dev.h", "ccsd_rank2_common.h", "ccsd_k_rank2.h", "ccsd_k_r2.h", "ccsd_k_xa.h", "ccsd_k_update.h", "ccsd_attn_stack.inc", "ccsd_plan.h", "ccsd_api.h")]
 
@@ -237,6 +237,9 @@ def kernel_work(wname: str, kname: str, E: int, K: int):
                                              "(E*K fp32 each)")
     if kname in ("k_langevin_apply", "k_s4_apply"):
         return None, 3 * E * K * 4, "read state + raw score, write state (rank2 dominates)"
+    if kname == "k_ew1":
+        return None, 2 * E * K * 4, ("element-wise ScoreNetworkF (cnum = 1): mean over the step's two launches -- the norms launch reads rank2, the "
+                                     "predictor launch reads it and writes the corrected and the new rank2")
     if kname == "k_gemm_p" and wl.get("wc"):
         return 2 * E * K * wl["wc"], None, "hodge projection GEMM P_0 = rank2 . Wcat (2 E K wc FLOPs)"
     if kname == "k_gemm_h":

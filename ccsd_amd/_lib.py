@@ -27,7 +27,7 @@ EXPORTS = [
     "ccsd_noise_draws", "ccsd_plan_query",
 ]
 QUERIES = {"fused_r2": 0, "xa_variant": 1, "r2_lds_bytes": 2, "xa_lds_bytes": 3, "fused_loop": 4}
-KERNEL_IDS = {"k_xa": 0, "k_gemm_p": 1, "k_hf_score": 2, "k_gemm_h": 3, "k_langevin_apply": 4, "k_r2": 5, "k_s4_apply": 6}
+KERNEL_IDS = {"k_xa": 0, "k_gemm_p": 1, "k_hf_score": 2, "k_gemm_h": 3, "k_langevin_apply": 4, "k_r2": 5, "k_s4_apply": 6, "k_ew1": 7}
 
 
 class StepCoef(C.Structure):

@@ -58,6 +58,8 @@ struct ccsd_plan {
     // fused rank-2 kernel (k_r2): eligibility and LDS geometry
     int fused_r2 = 0, r2_ldk = 0, r2_ldh = 0;
     size_t r2_lds = 0;
+    // element-wise rank-2 side (k_ew1): affine ScoreNetworkF without a Hodge Laplacian term (cnum = 1), tiled path, PC samplers
+    int ew1 = 0;
     // diagnostic knobs, read from the environment ONCE at plan creation (never on the launch path):
     // CCSD_OLD_GEMM_P, CCSD_XA_THREADS, CCSD_NO_FUSED_APPLY (CCSD_NO_FUSED_R2 / CCSD_XA_PASS / CCSD_XA_GCH / CCSD_NO_CHAIN shape the plan itself)
     int opt_old_gemm_p = 0, opt_xa_threads = 256, opt_no_fused_apply = 0;
@@ -74,7 +76,7 @@ struct ccsd_plan {
 #endif
 };
 
-enum { KID_XA = 0, KID_GEMM_P = 1, KID_HF = 2, KID_GEMM_H = 3, KID_LANGEVIN = 4, KID_R2 = 5, KID_S4 = 6 };
+enum { KID_XA = 0, KID_GEMM_P = 1, KID_HF = 2, KID_GEMM_H = 3, KID_LANGEVIN = 4, KID_R2 = 5, KID_S4 = 6, KID_EW1 = 7 };
 static void prof_mark(ccsd_plan* pl, int kid, void* stream) {
 #ifndef CCSD_EMU
     if (!(pl->prof_mask & (1u << kid))) return;
@@ -325,6 +327,8 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
             pl->fused_r2 = 1; pl->r2_ldk = ldk; pl->r2_ldh = ldh; pl->r2_lds = fl * 4;
         }
     }
+    pl->ew1 = cfg->is_cc && !pl->fused_r2 && pl->h.f_affine && pl->h.f_cnum == 1 && cfg->predictor != CCSD_PRED_S4 &&
+              getenv("CCSD_NO_EW1") == nullptr;
     if (pl->h.h_L > 2 && !pl->fused_r2) {
         ccsd_plan_destroy(pl);
         return set_err(CCSD_ERR_UNSUPPORTED, "more than two HodgeAdjAttentionLayers need the fused rank-2 kernel (E <= 64, cnum <= 2, hidden widths <= 16)");
@@ -366,8 +370,8 @@ static Workspace carve_ws(const ccsd_plan* pl, int B, void* base) {
     w.net_r = (float*)take(p.is_cc ? (size_t)B * E * K * 4 : 0);
     w.norm2 = (float*)take((size_t)B * 4 * 4);
     w.ntiles = p.is_cc ? ((p.K + T_BN - 1) / T_BN) * ((p.E + T_BM - 1) / T_BM) : 0;
-    w.part = (float*)take((size_t)B * (w.ntiles ? w.ntiles : 1) * 2 * 4);
-    w.nchunk = p.is_cc ? (int)((((size_t)p.E * p.K + 3) / 4 + CCSD_NN_CH - 1) / CCSD_NN_CH) : 0;   // k_noise_norm: chunks of flat groups per sample
+    w.nchunk = p.is_cc ? (int)((((size_t)p.E * p.K + 3) / 4 + CCSD_NN_CH - 1) / CCSD_NN_CH) : 0;   // k_noise_norm / k_ew1: chunks of flat groups per sample
+    { const int np = w.ntiles > w.nchunk ? w.ntiles : w.nchunk; w.part = (float*)take((size_t)B * (np ? np : 1) * 2 * 4); }
     w.zpart = (float*)take((size_t)B * (w.nchunk ? w.nchunk : 1) * 4);
     w.part2 = (float*)take((size_t)B * 2 * 4);
     w.sums = (float*)take(64);
@@ -527,6 +531,25 @@ static int launch_hf(const ccsd_plan* pl, int B, const float* rank2, RankEpi& ep
     return CCSD_OK;
 }
 
+// element-wise ScoreNetworkF (k_ew1).  ep: mode / scalars / out / mean / part as for k_hf_score; `net_out` (NORMS, nullable): keep the
+// raw score; `cf` (PRED, nullable): fused corrector apply, F1 goes to `f1`
+static int launch_ew1(const ccsd_plan* pl, int B, const float* rank2, RankEpi& ep, NoiseArgs& na, Workspace& w, void* stream,
+                      float* net_out = nullptr, const CorrFuse* cf = nullptr, float* f1 = nullptr) {
+    const PlanD& p = pl->h;
+    Ew1Args a{};
+    a.r = rank2; a.out = ep.out; a.mean = ep.mean; a.f1 = f1; a.net_out = net_out; a.part = ep.part;
+    a.mode = ep.mode; a.apply = (cf && cf->on) ? 1 : 0;
+    a.sscale = ep.sscale; a.pa = ep.pa; a.pb = ep.pb; a.pc = ep.pc; a.alpha = p.f_alpha; a.gamma = p.f_gamma;
+    if (a.apply) { a.sums = cf->sums; a.ss = cf->ss[2]; a.sde_alpha = cf->alpha[2]; a.snr = cf->snr; a.seps = cf->seps; a.draw_corr = cf->draw_r; }
+    a.E = p.E; a.K = p.K;
+    prof_mark(const_cast<ccsd_plan*>(pl), KID_EW1, stream);
+    CCSD_LAUNCH(k_ew1, dim3(w.nchunk, B), dim3(CCSD_NTHREADS), 0, stream, a, na, (const unsigned long long*)w.offbits,
+                (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells);
+    prof_mark(const_cast<ccsd_plan*>(pl), KID_EW1, stream);
+    LAUNCH_CHECK();
+    return CCSD_OK;
+}
+
 static int launch_r2(const ccsd_plan* pl, int B, const float* rank2, const float* adj, const float* flags, int want_p,
                      RankEpi& ep, NoiseArgs& na, Workspace& w, void* stream, const CorrFuse* cf = nullptr) {
     R2Args ra{};
@@ -565,7 +588,10 @@ static NoiseArgs make_noise(const ccsd_noise_t* n, uint64_t seed, int64_t off, u
 static inline int corrector_flat(const ccsd_plan* pl) { return pl->cfg.predictor != CCSD_PRED_S4 ? 1 : 0; }
 
 // does ccsd_sampler_run fuse the Langevin corrector's apply pass into the predictor launches of this plan?
-static inline bool fused_apply_ok(const ccsd_plan* pl) { return pl->fused_r2 && !pl->opt_no_fused_apply; }
+// (k_r2 plans; k_ew1 plans whose hodge projections do not depend on the adjacency: one hodge layer)
+static inline bool fused_apply_ok(const ccsd_plan* pl) { return (pl->fused_r2 || (pl->ew1 && pl->h.h_L <= 1)) && !pl->opt_no_fused_apply; }
+// every rank2 draw of a k_ew1 plan is keyed by flat groups (the kernel streams 16-byte pieces); otherwise only the corrector's
+static inline int predictor_flat(const ccsd_plan* pl) { return pl->ew1 ? 1 : 0; }
 
 // ---------------- API ----------------
 extern "C" int ccsd_score(ccsd_plan_t* pl, int32_t target, int32_t B, const ccsd_state_t* in, const float* flags,
@@ -590,6 +616,7 @@ extern "C" int ccsd_score(ccsd_plan_t* pl, int32_t target, int32_t B, const ccsd
         RankEpi ep{};
         ep.mode = MODE_SCORE; ep.sscale = sscale; ep.out = out;
         if (pl->fused_r2) return launch_r2(pl, B, in->rank2, in->adj, flags, 0, ep, na, w, stream);
+        if (pl->ew1) return launch_ew1(pl, B, in->rank2, ep, na, w, stream);
         if ((st = launch_h(pl, B, in->rank2, w, stream))) return st;
         return launch_hf(pl, B, in->rank2, ep, na, w, stream);
     }
@@ -639,8 +666,9 @@ extern "C" int ccsd_noise_draws(ccsd_plan_t* pl, int32_t B, const float* flags, 
     if (!pl) return set_err(CCSD_ERR_INVALID, "NULL plan");
     const int per_step = pl->cfg.predictor == CCSD_PRED_S4 ? 3 : pl->cfg.n_corr_steps + 1;
     if (step < 0 || step >= pl->cfg.diff_steps || phase < 0 || phase >= per_step) return set_err(CCSD_ERR_INVALID, "step / phase out of range");
-    const int flat = pl->cfg.predictor != CCSD_PRED_S4 && phase < pl->cfg.n_corr_steps && pl->cfg.corrector == CCSD_CORR_LANGEVIN;
-    return draws_to_state(pl, B, flags, nullptr, seed, sample_offset, draw_base(pl, step, phase), out, stream, flat ? corrector_flat(pl) : 0);
+    const bool corr = pl->cfg.predictor != CCSD_PRED_S4 && phase < pl->cfg.n_corr_steps && pl->cfg.corrector == CCSD_CORR_LANGEVIN;
+    return draws_to_state(pl, B, flags, nullptr, seed, sample_offset, draw_base(pl, step, phase), out, stream,
+                          corr ? corrector_flat(pl) : predictor_flat(pl));
 }
 
 extern "C" int ccsd_plan_query(const ccsd_plan_t* pl, int32_t what, int64_t* value) {
@@ -664,7 +692,7 @@ extern "C" int ccsd_plan_query(const ccsd_plan_t* pl, int32_t what, int64_t* val
 // iterate (== base for the first inner step).
 static int corrector_norms(ccsd_plan* pl, int B, int step, int it, const ccsd_state_t* base, const ccsd_state_t* cur,
                            const float* flags, const ccsd_noise_t* noise, uint64_t seed, int64_t off, float* sums,
-                           Workspace& w, void* stream) {
+                           Workspace& w, void* stream, bool keep_net = true) {
     const PlanD& p = pl->h;
     int st;
     NoiseArgs na = make_noise(noise, seed, off, draw_base(pl, step, it), corrector_flat(pl));
@@ -685,7 +713,14 @@ static int corrector_norms(ccsd_plan* pl, int B, int step, int it, const ccsd_st
     xa.flags = flags; xa.do_x = xa.do_a = 1; xa.mode = MODE_NORMS;
     xa.out_x = w.net_x; xa.out_a = w.net_adj; xa.norm2 = w.norm2;
     if ((st = launch_xa(pl, B, xa, na, w, stream))) return st;
-    if (p.is_cc && !fused) {
+    if (p.is_cc && !fused && pl->ew1) {
+        // element-wise ScoreNetworkF: one streaming pass gives both norm partials per (sample, chunk); the raw score is kept only
+        // for a separate ccsd_corrector_apply (the fused loop recomputes it)
+        RankEpi ep{};
+        ep.mode = MODE_NORMS; ep.out = w.net_r; ep.part = w.part;
+        if ((st = launch_ew1(pl, B, cur->rank2, ep, na, w, stream, keep_net ? w.net_r : nullptr))) return st;
+        ntiles = w.nchunk;
+    } else if (p.is_cc && !fused) {
         if ((st = launch_h(pl, B, cur->rank2, w, stream))) return st;
         RankEpi ep{};
         ep.mode = MODE_NORMS; ep.out = w.net_r; ep.part = w.part;
@@ -695,7 +730,7 @@ static int corrector_norms(ccsd_plan* pl, int B, int step, int it, const ccsd_st
     if (p.is_cc && !fused) {
         // tiled path: the noise norm of a flat-keyed Philox draw comes from its own (traffic-free) kernel; the per-tile partials of
         // k_hf_score and its chunk partials are reduced per sample first (one workgroup per sample), then over the batch
-        const bool zk = na.flat_r && !na.zr;
+        const bool zk = na.flat_r && !na.zr && !pl->ew1;
         if (zk) {
             CCSD_LAUNCH(k_noise_norm, dim3(w.nchunk, B), dim3(CCSD_NTHREADS), 0, stream, na, (const unsigned long long*)w.offbits,
                         (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, p.E, p.K, w.zpart);
@@ -742,9 +777,10 @@ static int predictor(ccsd_plan* pl, int B, int step, const ccsd_state_t* in, con
                      const float* fuse_sums = nullptr) {
     const PlanD& p = pl->h;
     int st;
-    NoiseArgs na = make_noise(noise, seed, off, draw_base(pl, step, pl->cfg.n_corr_steps));
+    NoiseArgs na = make_noise(noise, seed, off, draw_base(pl, step, pl->cfg.n_corr_steps), predictor_flat(pl));
     const ccsd_step_coef_t* c = &pl->coef[(size_t)step * 3];
     const bool fused = pl->fused_r2 && p.is_cc;
+    const bool ew1 = pl->ew1 && p.is_cc && !fused;
     CorrFuse cf{};
     if (fuse_sums) {   // the Langevin corrector's apply pass runs in the prologues of this half-step's kernels
         cf.on = 1; cf.net_x = w.net_x; cf.net_adj = w.net_adj; cf.net_r = w.net_r; cf.sums = fuse_sums;
@@ -758,6 +794,14 @@ static int predictor(ccsd_plan* pl, int B, int step, const ccsd_state_t* in, con
         ep.mode = MODE_PRED; ep.pa = c[2].pa; ep.pb = c[2].pb; ep.pc = c[2].pc;
         ep.out = out->rank2; ep.mean = mean ? mean->rank2 : nullptr;
         if ((st = launch_r2(pl, B, in->rank2, in->adj, flags, 1, ep, na, w, stream, &cf))) return st;
+    } else if (ew1) {
+        // element-wise ScoreNetworkF first: with the fused apply it produces the corrected rank2 (in the raw-score scratch, which
+        // the fused loop does not fill) that the hodge projections of the A-network must see
+        RankEpi ep{};
+        ep.mode = MODE_PRED; ep.pa = c[2].pa; ep.pb = c[2].pb; ep.pc = c[2].pc;
+        ep.out = out->rank2; ep.mean = mean ? mean->rank2 : nullptr;
+        if ((st = launch_ew1(pl, B, in->rank2, ep, na, w, stream, nullptr, &cf, w.net_r))) return st;
+        if ((st = launch_p(pl, B, in->adj, cf.on ? (const float*)w.net_r : in->rank2, w, stream))) return st;
     } else if ((st = launch_p(pl, B, in->adj, in->rank2, w, stream))) return st;
     XaArgs xa{};
     xa.xX = xa.xA = in->x; xa.adjX = xa.adjA = in->adj; xa.flags = flags;
@@ -768,7 +812,7 @@ static int predictor(ccsd_plan* pl, int B, int step, const ccsd_state_t* in, con
     xa.mean_x = mean ? mean->x : nullptr; xa.mean_a = mean ? mean->adj : nullptr;
     xa.cf = cf;
     if ((st = launch_xa(pl, B, xa, na, w, stream))) return st;
-    if (p.is_cc && !fused) {
+    if (p.is_cc && !fused && !ew1) {
         if ((st = launch_h(pl, B, in->rank2, w, stream))) return st;
         RankEpi ep{};
         ep.mode = MODE_PRED; ep.pa = c[2].pa; ep.pb = c[2].pb; ep.pc = c[2].pc;
@@ -888,7 +932,7 @@ extern "C" int ccsd_sampler_run(ccsd_plan_t* pl, int32_t B, const float* flags, 
             ccsd_state_t t = a; a = b; b = t;
         } else if (lang && fused_apply_ok(pl)) {
             // a -> [norms pass] ; [apply fused into the predictor kernels] -> b ; swap roles
-            if ((st = corrector_norms(pl, B, step, 0, &a, &a, flags, nullptr, seed, sample_offset, w.sums, w, stream))) return st;
+            if ((st = corrector_norms(pl, B, step, 0, &a, &a, flags, nullptr, seed, sample_offset, w.sums, w, stream, /*keep_net=*/pl->fused_r2 != 0))) return st;
             if ((st = predictor(pl, B, step, &a, flags, nullptr, seed, sample_offset, &b, want_mean ? result : nullptr, w, stream, w.sums))) return st;
             ccsd_state_t t = a; a = b; b = t;
         } else if (lang) {   // a -> (corrector) -> b -> (predictor) -> a

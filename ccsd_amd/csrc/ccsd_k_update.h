@@ -189,6 +189,113 @@ __global__ void k_langevin_apply(LangArgs a, NoiseArgs na, const unsigned long l
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_ew1: the whole rank-2 side of a half-step when ScoreNetworkF is affine with cnum = 1 -- net = fl fr (alpha F + gamma), no
+// Hodge Laplacian term (ScoreNetwork_F.py:175-217 with cnum = 1: pow_tensor_cc returns [F]; the N = 38 substitute of
+// zinc250k_CC) -- so the score is element-wise and rank2 streams through once, 16 bytes per lane, in flat Philox groups:
+//   SCORE  out = sscale net
+//   NORMS  partial sums of net^2 and (z fl fr)^2 per (sample, chunk); the raw score is stored only on request (step-wise API:
+//          ccsd_corrector_apply reads it; ccsd_sampler_run recomputes it in the apply below instead of a 2 x E K x 4 B round trip)
+//   PRED   [fused Langevin corrector apply  F1 = fma(c2, z fl fr, fma(c1, net(F), F)), written to `f1`: the hodge projection
+//          GEMM of the A-network reads it]  then  mean = pa F1 + pb net(F1),  out = mean + pc z' fl fr   (solver.py:797-801, 429-457)
+// Same expressions as k_hf_score / k_langevin_apply.  grid (chunks of CCSD_NN_CH groups, B).
+// ---------------------------------------------------------------------------------------------
+struct Ew1Args {
+    const float* r; float* out; float* mean; float* f1; float* net_out; float* part;
+    int mode, apply;
+    float sscale, pa, pb, pc, alpha, gamma;
+    const float* sums; float ss, sde_alpha, snr, seps; unsigned int draw_corr;
+    int E, K;
+};
+__global__ void k_ew1(Ew1Args a, NoiseArgs na, const unsigned long long* __restrict__ offbits, const unsigned char* __restrict__ edges,
+                      const unsigned long long* __restrict__ cells) {
+    __shared__ float red[64];
+    const int b = blockIdx.y, EK = a.E * a.K, ng = (EK + 3) >> 2;
+    const unsigned long long off = offbits[b];
+    const int g0 = blockIdx.x * CCSD_NN_CH, g1 = g0 + CCSD_NN_CH < ng ? g0 + CCSD_NN_CH : ng;
+    const FastDiv dK(a.K);
+    const bool vec = (EK & 3) == 0;
+    float c1 = 0.f, c2 = 0.f;
+    if (a.mode == MODE_PRED && a.apply) {
+        const float gn = fabsf(a.ss) * a.sums[2], zn = a.sums[5];          // (corr_coef / langevin_coef for the rank2 target)
+        const float q = a.snr * zn / gn;
+        const float step = q * q * 2.f * a.sde_alpha;
+        c1 = step * a.ss;
+        c2 = sqrtf(step * 2.f) * a.seps;
+    }
+    NoiseArgs nc = na;                                                      // corrector draw (NORMS: the launch's own draw)
+    if (a.mode == MODE_PRED) { nc.zr = nullptr; nc.draw_r = a.draw_corr; }
+    float s_net = 0.f, s_z = 0.f;
+    for (int g = g0 + threadIdx.x; g < g1; g += blockDim.x) {
+        const size_t base = (size_t)b * EK + 4 * (size_t)g;
+        float v[4];
+        if (vec) { const float4 v4 = *reinterpret_cast<const float4*>(a.r + base); v[0] = v4.x; v[1] = v4.y; v[2] = v4.z; v[3] = v4.w; }
+        else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) v[s] = 4 * g + s < EK ? a.r[base + s] : 0.f;
+        }
+        int e, k;
+        dK.divmod(4 * g, e, k);
+        float m[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int ec = e < a.E ? e : a.E - 1;
+            m[s] = edge_on(off, edges, ec) * cell_on(off, cells, k);           // flags_left * flags_right, cc_utils.py:590
+            if (++k == a.K) { k = 0; ++e; }
+        }
+        float o[4], mu[4], w1[4], nt[4];
+        float zc[4] = {0.f, 0.f, 0.f, 0.f}, zp[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.mode == MODE_NORMS || (a.mode == MODE_PRED && a.apply)) raw_noise_rflat4(nc, b, g, EK, zc);
+        if (a.mode == MODE_PRED) raw_noise_rflat4(na, b, g, EK, zp);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float f = v[s];
+            float net = m[s] * fmaf(a.alpha, f, a.gamma);                     // fnet_element<AFFINE>, cnum = 1
+            if (a.mode == MODE_SCORE) {
+                o[s] = a.sscale * net;
+            } else if (a.mode == MODE_NORMS) {
+                const float zz = zc[s] * m[s];
+                nt[s] = net;
+                s_net = fmaf(net, net, s_net);
+                s_z = fmaf(zz, zz, s_z);
+            } else {
+                if (a.apply) {
+                    f = fmaf(c2, zc[s] * m[s], fmaf(c1, net, f));             // k_langevin_apply
+                    w1[s] = f;
+                    net = m[s] * fmaf(a.alpha, f, a.gamma);
+                }
+                const float mean = fmaf(a.pa, f, a.pb * net);                 // v_mean = pa*v + pb*net (k_hf_score, MODE_PRED)
+                mu[s] = mean;
+                o[s] = fmaf(a.pc, zp[s] * m[s], mean);
+            }
+        }
+        auto st4 = [&](float* dst, const float* val) {
+            if (vec) *reinterpret_cast<float4*>(dst + base) = make_float4(val[0], val[1], val[2], val[3]);
+            else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (4 * g + s < EK) dst[base + s] = val[s];
+            }
+        };
+        if (a.mode == MODE_NORMS) { if (a.net_out) st4(a.net_out, nt); }
+        else {
+            st4(a.out, o);
+            if (a.mode == MODE_PRED) {
+                if (a.apply) st4(a.f1, w1);
+                if (a.mean) st4(a.mean, mu);
+            }
+        }
+    }
+    if (a.mode == MODE_NORMS) {
+        const float tn = block_sum(s_net, red);
+        const float tz = block_sum(s_z, red);
+        if (threadIdx.x == 0) {
+            a.part[((size_t)b * gridDim.x + blockIdx.x) * 2 + 0] = tn;
+            a.part[((size_t)b * gridDim.x + blockIdx.x) * 2 + 1] = tz;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_s4_apply: the update half of one S4_solver step (solver.py:1296-1352 graph, 1446-1529 CC), element-wise:
 //   v1 = v + step*score + sqrt(2 step)*z1*scale_eps        Langevin-style correction with the step's score
 //   v2 = m1*v1 + s1*z2                                     sde.transition(v1, t, dt/2)

@@ -219,7 +219,7 @@ int ccsd_rank2_cells(const float* rank2_dev, int32_t B, int32_t E, int64_t K, fl
                      int32_t* counts_dev, void* stream);
 
 /* Measurement hooks (bench.py): time every launch of selected kernels with HIP events on the launch stream.
- * kernel_id: 0 k_xa, 1 k_gemm_p, 2 k_hf_score, 3 k_gemm_h, 4 k_langevin_apply, 5 k_r2, 6 k_s4_apply; each call adds one kernel to the
+ * kernel_id: 0 k_xa, 1 k_gemm_p, 2 k_hf_score, 3 k_gemm_h, 4 k_langevin_apply, 5 k_r2, 6 k_s4_apply, 7 k_ew1; each call adds one kernel to the
  * selection, -1 clears it.  ccsd_profile_read synchronises on that kernel's events and returns launches + summed ms. */
 int ccsd_profile_kernel(ccsd_plan_t* plan, int32_t kernel_id);
 /* bracket only every stride-th launch of the selected kernels (default 1 = every launch): event records break

@@ -417,14 +417,18 @@ def case_one_step_vs_oracle_large(name, lib, device, B, counts, predictor, corre
         assert_close(g_, w_, f"{name} B={B} one step {p}")
 
 
-def case_production_loop_vs_oracle(name, lib, device, B, counts, steps, predictor, corrector, snr, seps, seed=5, expect_fused=None):
+def case_production_loop_vs_oracle(name, lib, device, B, counts, steps, predictor, corrector, snr, seps, seed=5, expect_fused=None,
+                                   source=None):
     """The PRODUCTION loop -- one ccsd_sampler_run call: in-kernel Philox noise, the Langevin apply fused into the predictor
     kernels' prologues where the plan supports it -- against the oracle, value for value.  ccsd_noise_draws exports the masked
     draws the kernels consume for every (step, half-step); the oracle replays them as its noise stream (RecordedNoise) from the
     same prior.  Also: the Python-driven step-wise loop (ccsd_corrector_norms + ccsd_corrector_apply + ccsd_predictor, the path
     the golden cases exercise) must reproduce the single call bit for bit.  (solver.py:1123-1147.)"""
     assert corrector == "Langevin"
-    meta, parts = load_ckpt_np(name)
+    if source is None:
+        meta, parts = load_ckpt_np(name)
+    else:                                  # networks that are not a shipped checkpoint: (meta in the checkpoint layout, weights)
+        meta, parts = source
     cfg, is_cc = meta["config"], meta["is_cc"]
     N, Fd = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
     names = ["x", "adj"] + (["rank2"] if is_cc else [])
@@ -474,6 +478,22 @@ def case_production_loop_vs_oracle(name, lib, device, B, counts, steps, predicto
     assert rec.i == len(draws), "the oracle consumed a different number of draws"
     for p, g_, w_ in zip(names, got, want):
         assert_close(g_, w_, f"{name} B={B} production loop, {steps} steps, {p}")
+
+
+def case_zinc5b_production_loop(lib, device):
+    """The N = 38 combinatorial-complex substitute (E = 703, K = 8436, cnum = 1 affine ScoreNetworkF: the element-wise kernel
+    k_ew1, Langevin apply fused into it and into k_xa) through ccsd_sampler_run against the oracle on the exported draws."""
+    g, meta5, sd, flags, _ = zinc5b_setup()
+    N, Fd, d_min, d_max, E, K = meta5["dims"]
+    sm = meta5["sampler"]
+    meta = {"is_cc": True, "config": {"data": {"max_node_num": N, "max_feat_num": Fd, "d_min": d_min, "d_max": d_max},
+                                      "sde": {p: dict(meta5["sde"][p], num_scales=1000) for p in ("x", "adj", "rank2")}}}
+    parts = {}
+    for p in ("x", "adj", "rank2"):
+        meta[f"params_{p}"] = meta5["params"][p]
+        parts[p] = {k: v.clone().requires_grad_(True) for k, v in sd[p].items()}
+    case_production_loop_vs_oracle("zinc250k_CC_5b", lib, device, 2, [38, 23], 2, sm["predictor"], sm["corrector"], sm["snr"],
+                                   sm["scale_eps"], seed=29, expect_fused=True, source=(meta, parts))
 
 
 def case_fused_r2_nonaffine_shapes(lib, device):

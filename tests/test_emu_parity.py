@@ -150,3 +150,7 @@ def test_production_loop_vs_oracle(lib):
 
 def test_fused_r2_serves_nonaffine_shapes(lib):
     pc.case_fused_r2_nonaffine_shapes(lib, DEV)
+
+
+def test_zinc5b_production_loop_vs_oracle(lib):
+    pc.case_zinc5b_production_loop(lib, DEV)

@@ -329,3 +329,7 @@ def test_rccl_single_rank_group(lib):
             assert torch.equal(u, v), f"1-rank exact mode != single-process run for {p}"
     finally:
         dist.destroy_process_group()
+
+
+def test_zinc5b_production_loop_vs_oracle(lib):
+    pc.case_zinc5b_production_loop(lib, DEV)
