@@ -64,6 +64,7 @@ struct ccsd_plan {
     // CCSD_OLD_GEMM_P, CCSD_XA_THREADS, CCSD_NO_FUSED_APPLY (CCSD_NO_FUSED_R2 / CCSD_XA_PASS / CCSD_XA_GCH / CCSD_NO_CHAIN shape the plan itself)
     int opt_old_gemm_p = 0, opt_xa_threads = 256, opt_no_fused_apply = 0;
     int opt_r2_stagger_mask = 0, opt_r2_stagger_sleep = 0;     // CCSD_R2_STAGGER="mask,sleep" (diagnostic)
+    int opt_no_merge = 0;                                      // CCSD_NO_MERGE (diagnostic: separate norms / predictor k_r2 launches)
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     unsigned prof_mask = 0;
     size_t prof_used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -217,6 +218,7 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     pl->cfg = *cfg;
     pl->opt_old_gemm_p = getenv("CCSD_OLD_GEMM_P") != nullptr;
     pl->opt_no_fused_apply = getenv("CCSD_NO_FUSED_APPLY") != nullptr;
+    pl->opt_no_merge = getenv("CCSD_NO_MERGE") != nullptr;
     if (const char* sg = getenv("CCSD_R2_STAGGER")) sscanf(sg, "%d,%d", &pl->opt_r2_stagger_mask, &pl->opt_r2_stagger_sleep);
     if (const char* xt = getenv("CCSD_XA_THREADS")) { const int v = atoi(xt); if (v >= 64 && v <= 512 && v % 64 == 0) pl->opt_xa_threads = v; }
     PlanBuilder pb;
@@ -349,6 +351,7 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
 struct Workspace {
     unsigned long long* offbits;
     float *H, *P0, *P1, *U1, *acoef, *net_x, *net_adj, *net_r, *norm2, *part, *sums, *chan, *zpart, *part2;
+    float *P0b, *P1b, *U1b;         // second set of hodge projections (merged k_r2 launch: the next norms pass's)
     int ntiles, nchunk;
     int p1_raw;     // who filled P1 last: k_r2 with the raw factors (1, see k_r2) or k_gemm_p with the finished projections (0)
     size_t bytes;
@@ -364,6 +367,10 @@ static Workspace carve_ws(const ccsd_plan* pl, int B, void* base) {
     w.P0 = (float*)take(p.h_L > 0 ? (size_t)B * E * p.hl[0].wc * 4 : 0);
     w.P1 = (float*)take(p.h_L > 1 ? (size_t)B * E * p.h_pw * 4 : 0);
     w.U1 = (float*)take(p.h_L > 1 ? (size_t)B * p.h_pw * 4 : 0);
+    const bool two = pl->fused_r2 != 0;
+    w.P0b = (float*)take(two && p.h_L > 0 ? (size_t)B * E * p.hl[0].wc * 4 : 0);
+    w.P1b = (float*)take(two && p.h_L > 1 ? (size_t)B * E * p.h_pw * 4 : 0);
+    w.U1b = (float*)take(two && p.h_L > 1 ? (size_t)B * p.h_pw * 4 : 0);
     w.acoef = (float*)take(p.h_L > 1 ? (size_t)B * p.a_cinit * E * 4 : 0);
     w.net_x = (float*)take((size_t)B * p.N * p.F * 4);
     w.net_adj = (float*)take((size_t)B * p.N * p.N * 4);
@@ -429,7 +436,7 @@ static int launch_h(const ccsd_plan* pl, int B, const float* rank2, Workspace& w
 }
 struct RankEpi;
 static int launch_r2(const ccsd_plan* pl, int B, const float* rank2, const float* adj, const float* flags, int want_p,
-                     RankEpi& ep, NoiseArgs& na, Workspace& w, void* stream, const CorrFuse* cf);
+                     RankEpi& ep, NoiseArgs& na, Workspace& w, void* stream, const CorrFuse* cf, int merge_draw);
 // hodge projections for ScoreNetworkA_CC from (adj, rank2)
 static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* rank2, Workspace& w, void* stream) {
     const PlanD& p = pl->h;
@@ -441,7 +448,7 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
         RankEpi ep{};
         ep.mode = MODE_SCORE; ep.sscale = 0.f; ep.out = w.net_r;
         NoiseArgs na0{};
-        return launch_r2(pl, B, rank2, adj, nullptr, 1, ep, na0, w, stream, nullptr);
+        return launch_r2(pl, B, rank2, adj, nullptr, 1, ep, na0, w, stream, nullptr, -1);
     }
     w.p1_raw = 0;
     const int rows = B * p.E;
@@ -482,8 +489,8 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
     }
     return CCSD_OK;
 }
-static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Workspace& w, void* stream) {
-    xa.P0 = w.P0; xa.P1 = w.P1; xa.U1 = w.U1; xa.chan_ws = w.chan;
+static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Workspace& w, void* stream, bool set_b = false) {
+    xa.P0 = set_b ? w.P0b : w.P0; xa.P1 = set_b ? w.P1b : w.P1; xa.U1 = set_b ? w.U1b : w.U1; xa.chan_ws = w.chan;
     xa.p1_raw = w.p1_raw; xa.dbg = pl->dbg ? pl->dbg + 32 : nullptr;
     const int xa_threads = pl->opt_xa_threads;   // 256 unless CCSD_XA_THREADS was set when the plan was created (diagnostic: 64..512)
     prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
@@ -550,10 +557,16 @@ static int launch_ew1(const ccsd_plan* pl, int B, const float* rank2, RankEpi& e
     return CCSD_OK;
 }
 
+// merge_draw >= 0: merged launch -- after this (predictor) pass the kernel runs the NEXT corrector's norms pass on the new block
+// (draw index merge_draw; raw score -> w.net_r, partials -> w.part, projections -> the second buffer set)
 static int launch_r2(const ccsd_plan* pl, int B, const float* rank2, const float* adj, const float* flags, int want_p,
-                     RankEpi& ep, NoiseArgs& na, Workspace& w, void* stream, const CorrFuse* cf = nullptr) {
+                     RankEpi& ep, NoiseArgs& na, Workspace& w, void* stream, const CorrFuse* cf = nullptr, int merge_draw = -1) {
     R2Args ra{};
     if (cf) ra.cf = *cf;
+    if (merge_draw >= 0) {
+        ra.merge = 1; ra.draw_r2 = (unsigned)merge_draw;
+        ra.P0b = w.P0b; ra.P1b = w.P1b; ra.U1b = w.U1b; ra.net2 = w.net_r; ra.part2 = w.part;
+    }
     ra.rank2 = rank2; ra.adj = adj; ra.flags = flags; ra.offbits = w.offbits; ra.P0 = w.P0; ra.P1 = w.P1; ra.U1 = w.U1; ra.want_p = want_p;
     ra.ldk = pl->r2_ldk; ra.ldh = pl->r2_ldh; ra.dbg = pl->dbg; ra.wp = pl->wp;
     ra.stagger_mask = pl->opt_r2_stagger_mask; ra.stagger_sleep = pl->opt_r2_stagger_sleep;
@@ -588,6 +601,14 @@ static NoiseArgs make_noise(const ccsd_noise_t* n, uint64_t seed, int64_t off, u
 static inline int corrector_flat(const ccsd_plan* pl) { return pl->cfg.predictor != CCSD_PRED_S4 ? 1 : 0; }
 
 // does ccsd_sampler_run fuse the Langevin corrector's apply pass into the predictor launches of this plan?
+// merged k_r2 launches (predictor of step i + rank-2 side of the norms pass of step i + 1): the row-strip instantiation of the
+// kernel (E = 33..36, affine ScoreNetworkF, linear mlp_value), pair-wise block load (K even, E K a multiple of 4)
+static inline bool merge_ok(const ccsd_plan* pl) {
+    if (!pl->fused_r2 || pl->opt_no_fused_apply || pl->opt_no_merge) return false;
+    int mt, rs; bool aff, gen1;
+    r2_shape(pl, &mt, &rs, &aff, &gen1);
+    return mt == 3 && rs == 1 && aff && !gen1 && (pl->h.K & 1) == 0 && ((pl->h.E * pl->h.K) & 3) == 0;
+}
 // (k_r2 plans; k_ew1 plans whose hodge projections do not depend on the adjacency: one hodge layer)
 static inline bool fused_apply_ok(const ccsd_plan* pl) { return (pl->fused_r2 || (pl->ew1 && pl->h.h_L <= 1)) && !pl->opt_no_fused_apply; }
 // every rank2 draw of a k_ew1 plan is keyed by flat groups (the kernel streams 16-byte pieces); otherwise only the corrector's
@@ -690,9 +711,11 @@ extern "C" int ccsd_plan_query(const ccsd_plan_t* pl, int32_t what, int64_t* val
 
 // phase 1 of the Langevin corrector.  `base` = pre-corrector state, `cur` = per-target current
 // iterate (== base for the first inner step).
+// r2_done: the rank-2 side of this norms pass (raw score, partials, hodge projections in the second buffer set) was already
+// produced by the merged k_r2 launch of the previous predictor half-step
 static int corrector_norms(ccsd_plan* pl, int B, int step, int it, const ccsd_state_t* base, const ccsd_state_t* cur,
                            const float* flags, const ccsd_noise_t* noise, uint64_t seed, int64_t off, float* sums,
-                           Workspace& w, void* stream, bool keep_net = true) {
+                           Workspace& w, void* stream, bool keep_net = true, bool r2_done = false) {
     const PlanD& p = pl->h;
     int st;
     NoiseArgs na = make_noise(noise, seed, off, draw_base(pl, step, it), corrector_flat(pl));
@@ -704,7 +727,7 @@ static int corrector_norms(ccsd_plan* pl, int B, int step, int it, const ccsd_st
     if (fused) {
         RankEpi ep{};
         ep.mode = MODE_NORMS; ep.out = w.net_r; ep.part = w.part;
-        if ((st = launch_r2(pl, B, cur->rank2, cur->adj, flags, 1, ep, na, w, stream))) return st;
+        if (!r2_done && (st = launch_r2(pl, B, cur->rank2, cur->adj, flags, 1, ep, na, w, stream))) return st;
         ntiles = 1;
     } else if ((st = launch_p(pl, B, cur->adj, base->rank2, w, stream))) return st;
     XaArgs xa{};
@@ -712,7 +735,7 @@ static int corrector_norms(ccsd_plan* pl, int B, int step, int it, const ccsd_st
     xa.xA = base->x; xa.adjA = cur->adj;      // score_adj(x_0, adj_cur)    solver.py:775
     xa.flags = flags; xa.do_x = xa.do_a = 1; xa.mode = MODE_NORMS;
     xa.out_x = w.net_x; xa.out_a = w.net_adj; xa.norm2 = w.norm2;
-    if ((st = launch_xa(pl, B, xa, na, w, stream))) return st;
+    if ((st = launch_xa(pl, B, xa, na, w, stream, fused && r2_done))) return st;
     if (p.is_cc && !fused && pl->ew1) {
         // element-wise ScoreNetworkF: one streaming pass gives both norm partials per (sample, chunk); the raw score is kept only
         // for a separate ccsd_corrector_apply (the fused loop recomputes it)
@@ -774,7 +797,7 @@ static int corrector_apply(ccsd_plan* pl, int B, int step, int it, const ccsd_st
 }
 static int predictor(ccsd_plan* pl, int B, int step, const ccsd_state_t* in, const float* flags, const ccsd_noise_t* noise,
                      uint64_t seed, int64_t off, ccsd_state_t* out, ccsd_state_t* mean, Workspace& w, void* stream,
-                     const float* fuse_sums = nullptr) {
+                     const float* fuse_sums = nullptr, bool merge_next = false) {
     const PlanD& p = pl->h;
     int st;
     NoiseArgs na = make_noise(noise, seed, off, draw_base(pl, step, pl->cfg.n_corr_steps), predictor_flat(pl));
@@ -793,7 +816,10 @@ static int predictor(ccsd_plan* pl, int B, int step, const ccsd_state_t* in, con
         RankEpi ep{};
         ep.mode = MODE_PRED; ep.pa = c[2].pa; ep.pb = c[2].pb; ep.pc = c[2].pc;
         ep.out = out->rank2; ep.mean = mean ? mean->rank2 : nullptr;
-        if ((st = launch_r2(pl, B, in->rank2, in->adj, flags, 1, ep, na, w, stream, &cf))) return st;
+        // merged launch: the rank-2 side of the NEXT step's norms pass follows in the same launch (its corrector draw: rank2 slot of
+        // draw_base(step + 1, 0))
+        const int md = merge_next ? (int)draw_base(pl, step + 1, 0) + 2 : -1;
+        if ((st = launch_r2(pl, B, in->rank2, in->adj, flags, 1, ep, na, w, stream, &cf, md))) return st;
     } else if (ew1) {
         // element-wise ScoreNetworkF first: with the fused apply it produces the corrected rank2 (in the raw-score scratch, which
         // the fused loop does not fill) that the hodge projections of the A-network must see
@@ -931,9 +957,13 @@ extern "C" int ccsd_sampler_run(ccsd_plan_t* pl, int32_t B, const float* flags, 
                                want_mean ? result : nullptr, w, stream))) return st;
             ccsd_state_t t = a; a = b; b = t;
         } else if (lang && fused_apply_ok(pl)) {
-            // a -> [norms pass] ; [apply fused into the predictor kernels] -> b ; swap roles
-            if ((st = corrector_norms(pl, B, step, 0, &a, &a, flags, nullptr, seed, sample_offset, w.sums, w, stream, /*keep_net=*/pl->fused_r2 != 0))) return st;
-            if ((st = predictor(pl, B, step, &a, flags, nullptr, seed, sample_offset, &b, want_mean ? result : nullptr, w, stream, w.sums))) return st;
+            // a -> [norms pass] ; [apply fused into the predictor kernels] -> b ; swap roles.  Merged k_r2 launches: the predictor's
+            // k_r2 also runs the rank-2 side of the next step's norms pass on the block it has just produced (r2_done below)
+            const bool merged = merge_ok(pl);
+            const bool r2_done = merged && step > first_step;
+            const bool merge_next = merged && !lastone;
+            if ((st = corrector_norms(pl, B, step, 0, &a, &a, flags, nullptr, seed, sample_offset, w.sums, w, stream, /*keep_net=*/pl->fused_r2 != 0, r2_done))) return st;
+            if ((st = predictor(pl, B, step, &a, flags, nullptr, seed, sample_offset, &b, want_mean ? result : nullptr, w, stream, w.sums, merge_next))) return st;
             ccsd_state_t t = a; a = b; b = t;
         } else if (lang) {   // a -> (corrector) -> b -> (predictor) -> a
             if ((st = corrector_norms(pl, B, step, 0, &a, &a, flags, nullptr, seed, sample_offset, w.sums, w, stream))) return st;

@@ -13,6 +13,13 @@ struct R2Args {
     float* U1;             // [B][wc_1]: fr . Wcat_1 of the complex (linear mlp_value: P1 then holds the raw (F o fr) Wcat_1)
     int want_p;            // write the hodge projections (the A-network will run on the same state)
     int stagger_mask, stagger_sleep;   // workgroups with (blockIdx.x & mask) != 0 start `sleep` x 64 cycles late (see launch_r2)
+    // Merged launch (ccsd_sampler_run, E = 36 geometry): the predictor half-step of PC step i, then -- on the new rank2 block, which
+    // the epilogue also wrote back into LDS -- the norms pass of the corrector of step i + 1 (its ScoreNetworkF score to HBM, both
+    // norm partials, the hodge projections of the new state into the second buffer set): one block load instead of two.
+    int merge;
+    unsigned int draw_r2;  // the next step's corrector draw (flat groups)
+    float* P0b; float* P1b; float* U1b;
+    float* net2; float* part2;
     int ldk, ldh;
     long long* dbg;
     const float* wp;       // packed buffer (Wcat^T of the hodge projections)
@@ -233,6 +240,40 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
         }
     }
     __syncthreads();
+    // ---- one pass = phase 1 + phase 2 over the LDS-resident block.  A merged launch (ra.merge) makes two: pass 0 the predictor
+    // half-step (its epilogue writes the new rank2 to HBM AND back into the block), pass 1 the next corrector's norms pass on it.
+    const int npass = ra.merge ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+    const bool wb = ra.merge && pass == 0;        // write the new state back into sF (pass 0 of a merged launch)
+    if (pass == 1) {
+        __syncthreads();                          // every wave is done with H and with its columns of the block
+        ep.mode = MODE_NORMS; ep.out = ra.net2; ep.mean = nullptr; ep.part = ra.part2;
+        na.zr = nullptr; na.draw_r = ra.draw_r2; na.flat_r = 1;
+        ra.P0 = ra.P0b; ra.P1 = ra.P1b; ra.U1 = ra.U1b;
+#ifndef CCSD_EMU
+        if (tid == 0) s_hdone = 0;
+#endif
+        // noise norm of the next corrector draw: the groups and the order of the norms launch's block load (bitwise the same sum)
+        {
+            const int EK = E * K, n4 = EK >> 2;
+            const FastDiv dK2(K >> 1);
+            for (int base = tid; base < n4; base += nth) {
+                float z[4];
+                philox_normal4(na.seed, na.draw_r, na.b_off + b, (unsigned)base, z);
+                int e, kp;
+                dK2.divmod(2 * base, e, kp);
+                const int k = 2 * kp;
+                const bool wrap = k + 2 == K;
+                const int e1 = wrap ? e + 1 : e, k1 = wrap ? 0 : k + 2;
+                const unsigned f0 = *reinterpret_cast<const unsigned short*>(sFrb + k), f1 = *reinterpret_cast<const unsigned short*>(sFrb + k1);
+                const float fl0 = sFl[e], fl1 = sFl[e1];
+                const float m[4] = {fl0 * (float)(f0 & 0xffu), fl0 * (float)(f0 >> 8), fl1 * (float)(f1 & 0xffu), fl1 * (float)(f1 >> 8)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float zz = z[j] * m[j]; s_z = fmaf(zz, zz, s_z); }
+            }
+        }
+        __syncthreads();
+    }
     stamp(ra.dbg, 1);
     const HodgeLayerD& h0 = p.hl[0];
     const HodgeLayerD& h1 = p.hl[1];
@@ -489,7 +530,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     nHtasks = nH;
     const int nw1 = nth >> 6, wave1 = tid >> 6;
     int n1 = ntask;
-    if (AFFINE) {
+    if (AFFINE && !wb) {     // (a pass that writes the new state back into the block runs every task first: they read all of it)
         n1 = ((nH + nw1 - 1) / nw1) * nw1;
         if (n1 > ntask) n1 = ntask;
     }
@@ -504,7 +545,8 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     // Every wave of the workgroup is resident and runs its phase-1 tasks unconditionally, so the count is always reached:
     // the wait has no give-up path into phase 2 (an incomplete H would mean silently wrong scores).  The guard only turns a
     // broken invariant (never observed; ~10 s of polling) into a loud kernel abort instead of an endless spin.
-    if (nHtasks > 0) {
+    if (wb) __syncthreads();
+    else if (nHtasks > 0) {
         unsigned spins = 0;
         while (__hip_atomic_load(&s_hdone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < nHtasks) {
             __builtin_amdgcn_s_sleep(8);
@@ -545,7 +587,9 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                 } else {
                     const float mean = fmaf(ep.pa, f, ep.pb * net);
                     if (ep.mean) ep.mean[gi] = mean;
-                    ep.out[gi] = fmaf(ep.pc, zz, mean);
+                    const float nv = fmaf(ep.pc, zz, mean);
+                    ep.out[gi] = nv;
+                    if (wb) sF[e * ldk + k] = nv;
                 }
             }
         }
@@ -684,7 +728,9 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                             } else {
                                 const float mean = fmaf(pa, f, net);     // v_mean = pa v + pb net (pb folded into net)
                                 if (MODE == 3) meanp[g] = mean;
-                                outp[g] = fmaf(pc, zz, mean);
+                                const float nv = fmaf(pc, zz, mean);
+                                outp[g] = nv;
+                                if (wb) sF[(e0 + r) * ldk + n] = nv;     // merged launch: the next pass works on the new block
                             }
                         }
                     }
@@ -750,7 +796,9 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                             } else {
                                 const float mean = fmaf(pa, f, net);
                                 if (MODE == 3) meanp[g] = mean;
-                                outp[g] = fmaf(pc, zz, mean);
+                                const float nv = fmaf(pc, zz, mean);
+                                outp[g] = nv;
+                                if (wb) sF[e * ldk + n] = nv;
                             }
                         }
                     }
@@ -1006,6 +1054,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
         }
     }
 #endif
+    }   // pass
     // (no phase 3: the epilogue wrote the results to HBM)
     stamp(ra.dbg, 4);
     if (ep.mode == MODE_NORMS) {
