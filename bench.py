@@ -226,9 +226,16 @@ def cpu_baseline_cert():
     return d
 
 
+MERGED_R2 = False     # set from the plan (engine.query("merged_r2")): a k_r2 launch = predictor half-step + the next norms pass
+
+
 def kernel_work(wname: str, kname: str, E: int, K: int):
     """Algorithmic work of ONE launch per complex: (flops, bytes, what)."""
     wl = WORKLOADS[wname]
+    if kname == "k_r2" and MERGED_R2:
+        return 2 * wl["flop_f"], 4 * E * K * 4, ("merged launch = two ScoreNetworkF evaluations; FLOPs: 2 x the dense-as-written GEMM FLOPs of "
+                                                "ScoreNetworkF (SURVEY 8a); bytes: read rank2 + the raw score of the norms pass, write the new rank2 + "
+                                                "the next raw score (4 x E*K fp32)")
     if kname == "k_xa":
         f = None if wl["flop_x"] is None else wl["flop_x"] + wl["flop_a"]
         return f, None, "dense-as-written GEMM FLOPs of ScoreNetworkX + ScoreNetworkA(_CC) (SURVEY 8a)"
@@ -402,6 +409,8 @@ def _main(real_stdout):
     run(max(1, args.warmup))
     eng = inner.engine()
     E, K = eng.E, eng.K
+    global MERGED_R2
+    MERGED_R2 = bool(eng.query("merged_r2"))
     if not args.no_kernel_events:
         for kname in KERNEL_NAMES:                   # HIP events around those kernels' launches, on their stream
             eng.profile_kernel(kname)

@@ -26,7 +26,7 @@ EXPORTS = [
     "ccsd_predictor", "ccsd_s4_apply", "ccsd_sampler_run", "ccsd_quantize", "ccsd_rank2_cells", "ccsd_profile_kernel", "ccsd_profile_stride", "ccsd_profile_read", "ccsd_profile_launches", "ccsd_debug_stamps",
     "ccsd_noise_draws", "ccsd_plan_query",
 ]
-QUERIES = {"fused_r2": 0, "xa_variant": 1, "r2_lds_bytes": 2, "xa_lds_bytes": 3, "fused_loop": 4}
+QUERIES = {"fused_r2": 0, "xa_variant": 1, "r2_lds_bytes": 2, "xa_lds_bytes": 3, "fused_loop": 4, "merged_r2": 5, "ew1": 6}
 KERNEL_IDS = {"k_xa": 0, "k_gemm_p": 1, "k_hf_score": 2, "k_gemm_h": 3, "k_langevin_apply": 4, "k_r2": 5, "k_s4_apply": 6, "k_ew1": 7}
 
 

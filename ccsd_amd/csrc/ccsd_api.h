@@ -704,6 +704,9 @@ extern "C" int ccsd_plan_query(const ccsd_plan_t* pl, int32_t what, int64_t* val
             *value = (!s4 && pl->cfg.corrector == CCSD_CORR_LANGEVIN && pl->cfg.n_corr_steps == 1 && fused_apply_ok(pl)) ? 1 : 0;
             break;
         }
+        case CCSD_QUERY_MERGED_R2: *value = (pl->cfg.predictor != CCSD_PRED_S4 && pl->cfg.corrector == CCSD_CORR_LANGEVIN && pl->cfg.n_corr_steps == 1 &&
+                                             fused_apply_ok(pl) && merge_ok(pl)) ? 1 : 0; break;
+        case CCSD_QUERY_EW1: *value = pl->ew1; break;
         default: return set_err(CCSD_ERR_INVALID, "unknown query");
     }
     return CCSD_OK;

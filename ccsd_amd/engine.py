@@ -144,7 +144,7 @@ class PCEngine:
                                                  C.byref(so), self._stream()))
 
     def query(self, what: str) -> int:
-        """Which kernels the plan selected (ccsd_plan_query): "fused_r2", "xa_variant", "r2_lds_bytes", "xa_lds_bytes", "fused_loop"."""
+        """Which kernels the plan selected (ccsd_plan_query): "fused_r2", "xa_variant", "r2_lds_bytes", "xa_lds_bytes", "fused_loop", "merged_r2", "ew1"."""
         v = C.c_int64(0)
         self.lib.check(self.lib.ccsd_plan_query(self.handle, _lib.QUERIES[what], C.byref(v)))
         return v.value

@@ -159,7 +159,10 @@ enum {
     CCSD_QUERY_XA_VARIANT = 1,    /* instantiation of the graph-network kernel k_xa: 0 plain, 1 HodgeBaseline, 2 X_GMH, 3 general */
     CCSD_QUERY_R2_LDS_BYTES = 2,
     CCSD_QUERY_XA_LDS_BYTES = 3,
-    CCSD_QUERY_FUSED_LOOP = 4     /* 1: ccsd_sampler_run fuses the Langevin apply into the predictor launches */
+    CCSD_QUERY_FUSED_LOOP = 4,    /* 1: ccsd_sampler_run fuses the Langevin apply into the predictor launches */
+    CCSD_QUERY_MERGED_R2 = 5,     /* 1: ... and k_r2 runs the predictor half-step of step i and the rank-2 side of the norms pass of step i + 1
+                                     in one launch (one block load per PC step) */
+    CCSD_QUERY_EW1 = 6            /* 1: element-wise rank-2 kernel k_ew1 (affine ScoreNetworkF without a Hodge Laplacian term, cnum = 1) */
 };
 int ccsd_plan_query(const ccsd_plan_t* plan, int32_t what, int64_t* value);
 
