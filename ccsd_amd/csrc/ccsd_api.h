@@ -420,9 +420,10 @@ static int launch_flagbits(const ccsd_plan* pl, int B, const float* flags, Works
 static int launch_h(const ccsd_plan* pl, int B, const float* rank2, Workspace& w, void* stream) {
     const PlanD& p = pl->h;
     if (!p.is_cc || p.f_cnum < 2) return CCSD_OK;
-    dim3 g((p.E + T_BN - 1) / T_BN, (p.E + T_BM - 1) / T_BM, B);
+    const int nth_ = (p.E + T_BM - 1) / T_BM;
+    dim3 g(xcd_grid(B, nth_ * (nth_ + 1) / 2));
     prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_H, stream);
-    CCSD_LAUNCH(k_gemm_h, g, dim3(CCSD_NTHREADS), 0, stream, rank2, w.H, p.E, p.K, p.f_hmask);
+    CCSD_LAUNCH(k_gemm_h, g, dim3(CCSD_NTHREADS), 0, stream, rank2, w.H, p.E, p.K, p.f_hmask, B);
     prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_H, stream);
     LAUNCH_CHECK();
     for (int j = 2; j < p.f_cnum; ++j) {       // H^j = H^(j-1) . H  (pow_tensor_cc, cc_utils.py:972-977)
@@ -518,10 +519,10 @@ static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Work
 }
 static int launch_hf(const ccsd_plan* pl, int B, const float* rank2, RankEpi& ep, NoiseArgs& na, Workspace& w, void* stream) {
     const PlanD& p = pl->h;
-    dim3 g((p.K + T_BN - 1) / T_BN, (p.E + T_BM - 1) / T_BM, B);
+    dim3 g(xcd_grid(B, ((p.K + T_BN - 1) / T_BN) * ((p.E + T_BM - 1) / T_BM)));
     prof_mark(const_cast<ccsd_plan*>(pl), KID_HF, stream);
 #define HF_ARGS (const PlanD*)pl->d, (const float*)pl->w, rank2, (const float*)w.H, (const unsigned long long*)w.offbits, \
-                (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, ep, na
+                (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, ep, na, B
     const int fw = fnet_width(p);
 #define HF_GO(NP_) \
     do { \

@@ -15,16 +15,34 @@ __global__ void k_flagbits(const float* __restrict__ flags, unsigned long long* 
         offbits[b] = m;
     }
 }
+// Tiles of the tiled rank-2 kernels are numbered so that ALL tiles of one complex run on ONE XCD: workgroups are dealt round-robin
+// over the 8 XCDs (linear block id mod 8), each with its own 4 MB L2, and the tiles of a complex share its operands (k_gemm_h:
+// every 64-row slab of F feeds 3-4 tiles; k_hf_score: every row tile of a column block reads the same E x 64 slab of F, every
+// column block the same rows of H).  id = 8 (T (b / 8) + t) + b % 8  <->  (complex b, tile t): one HBM fetch per operand instead of
+// one per sharing tile.  Placement is a speed matter only; grid = xcd_grid(B, T) workgroups, ids with b >= B return at once.
+CCSD_DEV bool xcd_sample_tile(int id, int T, int B, int* b, int* t) {
+    const int grp = id / (8 * T), rem = id - grp * 8 * T;
+    *t = rem >> 3;
+    *b = 8 * grp + (rem & 7);
+    return *b < B;
+}
+static inline int xcd_grid(int B, int T) { return ((B + 7) / 8) * 8 * T; }
+
 // ---------------------------------------------------------------------------------------------
 // k_gemm_h: H[b] = (F[b] F[b]^T) * hodge_mask           hodge_laplacian + mask, cc_utils.py:929, 964-969
-// grid (ceil(E/64), ceil(E/64), B)
+// grid xcd_grid(B, nt (nt + 1) / 2), nt = ceil(E/64): the upper-triangle tiles of a complex (H is symmetric: mirrored on store)
 // ---------------------------------------------------------------------------------------------
 #define H_BK 32   // k per slab (two 16-wide MFMA k blocks)
 #define H_LD 40   // LDS row stride in floats: 16-byte aligned rows, == 8 mod 32 -> conflict-free ds_read_b128 fragments
 __global__ __launch_bounds__(256) void k_gemm_h(const float* __restrict__ rank2, float* __restrict__ H, int E, int K,
-                                                int zero_diag) {
-    const int b = blockIdx.z, m0 = blockIdx.y * T_BM, n0 = blockIdx.x * T_BN;
-    if (blockIdx.x < blockIdx.y) return;        // H is symmetric: upper-triangle tiles only, mirrored on store
+                                                int zero_diag, int B) {
+    const int nt = (E + T_BM - 1) / T_BM;
+    int b, t;
+    if (!xcd_sample_tile((int)blockIdx.x, nt * (nt + 1) / 2, B, &b, &t)) return;
+    int ty = 0;                                  // upper-triangle tile t -> (row tile ty, column tile tx >= ty), row-major
+    while (t >= nt - ty) { t -= nt - ty; ++ty; }
+    const int tx = ty + t;
+    const int m0 = ty * T_BM, n0 = tx * T_BN;
     const float* Fb = rank2 + (size_t)b * E * K;
     TileAcc acc;
     tile_zero(acc);
@@ -49,7 +67,7 @@ __global__ __launch_bounds__(256) void k_gemm_h(const float* __restrict__ rank2,
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-    const bool diag = blockIdx.x == blockIdx.y, vec = (K & 3) == 0;
+    const bool diag = tx == ty, vec = (K & 3) == 0;
     // thread -> (row, 4-float column group) of the 64 x 32 slab: two groups per thread and matrix
     const int r0 = tid >> 3, c4 = (tid & 7) * 4;
     auto ldg = [&](int row, int k) -> float4 {
@@ -109,7 +127,7 @@ __global__ __launch_bounds__(256) void k_gemm_h(const float* __restrict__ rank2,
             if (m < E) {
                 const float hv = (zero_diag && m == n) ? 0.f : v[s];
                 Hb[(size_t)m * E + n] = hv;
-                if (blockIdx.x != blockIdx.y) Hb[(size_t)n * E + m] = hv;
+                if (tx != ty) Hb[(size_t)n * E + m] = hv;
             }
         }
     });
@@ -306,7 +324,7 @@ __global__ void k_edgecoef(const float* __restrict__ adj, float* __restrict__ ac
 // ---------------------------------------------------------------------------------------------
 // k_hf_score: ScoreNetworkF.  Tile (edge rows m0.., cell columns n0..) of  H.F  on MFMA, then per
 // element the channel MLP stack of ScoreNetwork_F.py:198-217 and one of three fused epilogues.
-// grid (ceil(K/64), ceil(E/64), B)
+// grid xcd_grid(B, ceil(K/64) ceil(E/64))
 // ---------------------------------------------------------------------------------------------
 // NP: Hodge powers the instantiation can hold (1: cnum <= 2, the common case -- one accumulator, no loop; CCSD_MAXCN - 1 otherwise)
 template <bool AFFINE, int FW, int NP>
@@ -315,11 +333,15 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
                                                   const unsigned long long* __restrict__ offbits,
                                                   const unsigned char* __restrict__ edges,
                                                   const unsigned long long* __restrict__ cells, RankEpi ep,
-                                                  NoiseArgs na) {
+                                                  NoiseArgs na, int B) {
     __shared__ float red[64];
     const PlanD& p = *plan;
     const int E = p.E, K = p.K;
-    const int b = blockIdx.z, m0 = blockIdx.y * T_BM, n0 = blockIdx.x * T_BN;
+    const int ncb = (K + T_BN - 1) / T_BN, nrt = (E + T_BM - 1) / T_BM;
+    int b, tile;
+    if (!xcd_sample_tile((int)blockIdx.x, ncb * nrt, B, &b, &tile)) return;       // (see xcd_sample_tile: a complex's tiles share an XCD)
+    const int rty = tile / ncb, cbx = tile - rty * ncb;
+    const int m0 = rty * T_BM, n0 = cbx * T_BN;
     const float* Fb = rank2 + (size_t)b * E * K;
     // one (H^j F) tile per Hodge power j = 1 .. cnum - 1 (pow_tensor_cc, cc_utils.py:961-979): the powers H^j (B, E, E) lie
     // behind each other in the workspace (k_gemm_h, k_gemm_pow); the F slabs are re-read per power (cnum > 2 only)
@@ -331,7 +353,7 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
     for (int jp = 0; jp < NP; ++jp) {
     if (jp >= npow) break;
     TileAcc& acc = accs[jp];
-    const float* Hb = H + ((size_t)jp * gridDim.z + b) * E * E;
+    const float* Hb = H + ((size_t)jp * B + b) * E * E;
 #ifdef CCSD_EMU
     static float As[T_BK * T_LD], Bs[T_BK * T_LD];
     {
@@ -456,7 +478,7 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
         const float tn = block_sum(s_net, red);
         const float tz = block_sum(s_z, red);
         if (threadIdx.x == 0) {
-            const int tile = blockIdx.y * gridDim.x + blockIdx.x, nt = gridDim.x * gridDim.y;
+            const int nt = ncb * nrt;
             ep.part[((size_t)b * nt + tile) * 2 + 0] = tn;
             ep.part[((size_t)b * nt + tile) * 2 + 1] = tz;
         }
