@@ -411,6 +411,9 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
             // (the mlp_attention weight blocks, the diagonal hodge adjacency and P_1's per-edge factors were staged behind pow_tensor)
             const HodgeLayerD& h0 = p.hl[0];
             const int qw0 = 2 * h0.adim;
+            // row stride of the first layer's Q|K rows: odd (qw0 is even), so that the lanes of the dense pair loop -- consecutive
+            // edges e2 -- read a Q|K element from 32 different banks instead of 4 (the general layer loop keeps the packed rows)
+            const int ldq0 = VAR == XA_GEN ? qw0 : qw0 + 1;
             const FastDiv dqw0(qw0), dEqw0(E * qw0);
             const float* P0b = xa.P0 + (size_t)b * E * h0.wc;
             float* s_p1c = s_hd + p.a_nch_hodge * E;
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                 dqw0.divmod(r, e, d);
                 const float a = s_chan[c * NN + pair_off(e)];
                 const float g = 1.0f / sqrtf(fmaxf(a, 1.f));
-                s_hq[t] = fmaf(g * a * g, P0b[(size_t)e * h0.wc + c * qw0 + d], w[h0.bcat + c * qw0 + d]);
+                s_hq[(c * E + e) * ldq0 + d] = fmaf(g * a * g, P0b[(size_t)e * h0.wc + c * qw0 + d], w[h0.bcat + c * qw0 + d]);
             }
             const bool w4_0 = mlp_maxw(h0.matt) <= 4 && h0.cin <= 4;
             __syncthreads();
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                     for (int c = 0; c < CCSD_SMALLW; ++c) {
                         float sacc = 0.f;
                         if (c < h0.cin) {
-                            const float* q = s_hq + (c * E + e) * qw0;
+                            const float* q = s_hq + (c * E + e) * ldq0;
                             sacc = attn_logits(q, q + h0.adim, h0.nchunk, h0.dsplit, rks) * (1.0f / (float)h0.nchunk);
                         }
                         in[c] = sacc;
@@ -475,36 +478,97 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                     }
                 }
 #endif
-                int pe_n = 0, pe2_n = 0;
-                if (tid < npair) { pe_n = xa.hpairs[2 * tid]; pe2_n = xa.hpairs[2 * tid + 1]; }
-                for (int t = tid; t < npair; t += nth) {
-                    const int e = pe_n, e2 = pe2_n;
-                    if (t + nth < npair) { pe_n = xa.hpairs[2 * (t + nth)]; pe2_n = xa.hpairs[2 * (t + nth) + 1]; }   // next pair: in flight
-                    float in[CCSD_SMALLW], out[CCSD_SMALLW];
+                // The loop is bound by the LATENCY of one thread's dependent chain (LDS reads -> dot products -> exp -> rcp ..., the same
+                // 21 k cycles with one or with four workgroups on the CU), not by issue: with the channel count, the chunk count and the
+                // chunk width known at compile time every logit of a pair is an independent chain in ONE basic block (the run-time
+                // loops and the `c < cin` branches of the general form serialise them)
+                auto dense_pairs = [&](auto CIN_, auto COUT_) {
+                    constexpr int CIN = decltype(CIN_)::value, COUT = decltype(COUT_)::value;   // 0: general (run-time) form
+                    if constexpr (CIN > 0) {
+                        // nchunk == 2, dsplit == 2, adim == 4, one Linear in mlp_attention (checked by the caller): Q = row[0..3], K = row[4..7].
+                        // PB pairs per thread and pass, all in one basic block: PB x CIN x 4 independent logit chains
+                        constexpr int PB = 2;
+                        for (int t0 = tid; t0 < npair; t0 += PB * nth) {
+                            int pe[PB], pe2[PB];
 #pragma unroll
-                    for (int c = 0; c < CCSD_SMALLW; ++c) {
-                        float v = 0.f;
-                        if (c < h0.cin) {
-                            const float* q1 = s_hq + (c * E + e) * qw0;
-                            const float* q2 = s_hq + (c * E + e2) * qw0;
-                            const float s1 = attn_logits(q1, q2 + h0.adim, h0.nchunk, h0.dsplit, rks);
-                            const float s2 = attn_logits(q2, q1 + h0.adim, h0.nchunk, h0.dsplit, rks);
-                            v = (s1 * rnc0 + s2 * rnc0) * 0.5f;
+                            for (int u = 0; u < PB; ++u) {
+                                const int t = t0 + u * nth, tc = t < npair ? t : npair - 1;
+                                const unsigned short pr = *reinterpret_cast<const unsigned short*>(xa.hpairs + 2 * tc);
+                                pe[u] = pr & 0xff; pe2[u] = pr >> 8;
+                            }
+                            float outv[PB][COUT];
+#pragma unroll
+                            for (int u = 0; u < PB; ++u) {
+                                float in[4] = {0.f, 0.f, 0.f, 0.f}, out[4];
+#pragma unroll
+                                for (int c = 0; c < CIN; ++c) {
+                                    const float* q1 = s_hq + (c * E + pe[u]) * ldq0;
+                                    const float* q2 = s_hq + (c * E + pe2[u]) * ldq0;
+                                    float a1[8], a2[8];
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j) { a1[j] = q1[j]; a2[j] = q2[j]; }
+                                    // (same operation order as attn_logit_sum<2>: first product rounded, second fused)
+                                    const float s1 = tanh_f(fmaf(a1[1], a2[5], a1[0] * a2[4]) * rks) + tanh_f(fmaf(a1[3], a2[7], a1[2] * a2[6]) * rks);
+                                    const float s2 = tanh_f(fmaf(a2[1], a1[5], a2[0] * a1[4]) * rks) + tanh_f(fmaf(a2[3], a1[7], a2[2] * a1[6]) * rks);
+                                    in[c] = (s1 * rnc0 + s2 * rnc0) * 0.5f;
+                                }
+                                small_mlp_lds<4>(s_hw, 1, in, out);
+                                const float fh = s_flags[edge_i(pe[u])] * s_flags[edge_j(pe[u])];
+                                const float fh2 = s_flags[edge_i(pe2[u])] * s_flags[edge_j(pe2[u])];
+#pragma unroll
+                                for (int o = 0; o < COUT; ++o) { const float tv = tanh_f(out[o] * fh * fh2); outv[u][o] = tv + tv; }   // symmetric inputs: h + h^T = 2h
+                            }
+#pragma unroll
+                            for (int u = 0; u < PB; ++u)
+                                if (t0 + u * nth < npair) {
+                                    const int e = pe[u], e2 = pe2[u];
+#pragma unroll
+                                    for (int o = 0; o < COUT; ++o) {
+                                        s_h1m[o * E * E + e * E + e2] = outv[u][o];
+                                        s_h1m[o * E * E + e2 * E + e] = outv[u][o];
+                                        if (e == e2) s_hd[(p.a_cinit + o) * E + e] = outv[u][o];
+                                    }
+                                }
                         }
-                        in[c] = v;
+                        return;
                     }
-                    if (w4_0) small_mlp_lds<4>(s_hw, h0.matt.n, in, out); else small_mlp_lds<CCSD_SMALLW>(s_hw, h0.matt.n, in, out);
-                    const float fh = s_flags[edge_i(e)] * s_flags[edge_j(e)];
-                    const float fh2 = s_flags[edge_i(e2)] * s_flags[edge_j(e2)];
+                    int pe_n = 0, pe2_n = 0;
+                    if (tid < npair) { pe_n = xa.hpairs[2 * tid]; pe2_n = xa.hpairs[2 * tid + 1]; }
+                    for (int t = tid; t < npair; t += nth) {
+                        const int e = pe_n, e2 = pe2_n;
+                        if (t + nth < npair) { pe_n = xa.hpairs[2 * (t + nth)]; pe2_n = xa.hpairs[2 * (t + nth) + 1]; }   // next pair: in flight
+                        float in[CCSD_SMALLW], out[CCSD_SMALLW];
+                        {
 #pragma unroll
-                    for (int o = 0; o < CCSD_SMALLW; ++o)
-                        if (o < h0.cout) {
-                            const float tv = tanh_f(out[o] * fh * fh2);   // inputs are exactly symmetric -> h + h^T = 2h
-                            s_h1m[o * E * E + e * E + e2] = tv + tv;
-                            s_h1m[o * E * E + e2 * E + e] = tv + tv;
-                            if (e == e2) s_hd[(p.a_cinit + o) * E + e] = tv + tv;
+                            for (int c = 0; c < CCSD_SMALLW; ++c) {
+                                float v = 0.f;
+                                if (c < h0.cin) {
+                                    const float* q1 = s_hq + (c * E + e) * ldq0;
+                                    const float* q2 = s_hq + (c * E + e2) * ldq0;
+                                    const float s1 = attn_logits(q1, q2 + h0.adim, h0.nchunk, h0.dsplit, rks);
+                                    const float s2 = attn_logits(q2, q1 + h0.adim, h0.nchunk, h0.dsplit, rks);
+                                    v = (s1 * rnc0 + s2 * rnc0) * 0.5f;
+                                }
+                                in[c] = v;
+                            }
+                            if (w4_0) small_mlp_lds<4>(s_hw, h0.matt.n, in, out); else small_mlp_lds<CCSD_SMALLW>(s_hw, h0.matt.n, in, out);
                         }
-                }
+                        const float fh = s_flags[edge_i(e)] * s_flags[edge_j(e)];
+                        const float fh2 = s_flags[edge_i(e2)] * s_flags[edge_j(e2)];
+#pragma unroll
+                        for (int o = 0; o < CCSD_SMALLW; ++o)
+                            if (o < h0.cout) {
+                                const float tv = tanh_f(out[o] * fh * fh2);   // inputs are exactly symmetric -> h + h^T = 2h
+                                s_h1m[o * E * E + e * E + e2] = tv + tv;
+                                s_h1m[o * E * E + e2 * E + e] = tv + tv;
+                                if (e == e2) s_hd[(p.a_cinit + o) * E + e] = tv + tv;
+                            }
+                    }
+                };
+                if (VAR != XA_GEN && h0.cin == 2 && h0.cout == 4 && h0.adim == 4 && h0.nchunk == 2 && h0.dsplit == 2 && h0.matt.n == 1 && w4_0)
+                    dense_pairs(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});     // (the qm9_CC shape)
+                else
+                    dense_pairs(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
                 __syncthreads();
                 stamp(xa.dbg, 17);
                 // second (last) HodgeAdjAttentionLayer: dense hodge adjacency, only the diagonal of its output

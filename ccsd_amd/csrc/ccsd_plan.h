@@ -442,7 +442,8 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     const int NNpad = (NN + 15) / 16 * 16;
     int hq_floats = 0, h1m_floats = 0;
     if (p->h_L) {
-        for (int l = 0; l < p->h_L; ++l) { int v = ccsd_hl(*p, l).cin * E * 2 * ccsd_hl(*p, l).adim; if (v > hq_floats) hq_floats = v; }
+        // (+1: the first layer's rows have an odd stride in k_xa -- bank-conflict-free reads in the dense pair loop)
+        for (int l = 0; l < p->h_L; ++l) { int v = ccsd_hl(*p, l).cin * E * (2 * ccsd_hl(*p, l).adim + (l == 0 ? 1 : 0)); if (v > hq_floats) hq_floats = v; }
         for (int l = 0; l + 1 < p->h_L; ++l) { int v = ccsd_hl(*p, l).cout * E * E; if (v > h1m_floats) h1m_floats = v; }
         if (E > NN) { pb.fail(CCSD_ERR_UNSUPPORTED, "E > N*N"); return 0; }
     }
