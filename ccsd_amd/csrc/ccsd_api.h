@@ -64,6 +64,8 @@ struct ccsd_plan {
     // CCSD_OLD_GEMM_P, CCSD_XA_THREADS, CCSD_NO_FUSED_APPLY (CCSD_NO_FUSED_R2 / CCSD_XA_PASS / CCSD_XA_GCH / CCSD_NO_CHAIN shape the plan itself)
     int opt_old_gemm_p = 0, opt_xa_threads = 256, opt_no_fused_apply = 0;
     int opt_r2_stagger_mask = 0, opt_r2_stagger_sleep = 0;     // CCSD_R2_STAGGER="mask,sleep" (diagnostic)
+    int opt_xa_prio = 0;                                       // CCSD_XA_PRIO (diagnostic: k_xa issue-priority scheme)
+    int opt_xa_stagger_mask = 0, opt_xa_stagger_sleep = 0;     // CCSD_XA_STAGGER="mask,sleep" (diagnostic)
     int opt_no_merge = 0;                                      // CCSD_NO_MERGE (diagnostic: separate norms / predictor k_r2 launches)
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     unsigned prof_mask = 0;
@@ -219,6 +221,8 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     pl->opt_old_gemm_p = getenv("CCSD_OLD_GEMM_P") != nullptr;
     pl->opt_no_fused_apply = getenv("CCSD_NO_FUSED_APPLY") != nullptr;
     pl->opt_no_merge = getenv("CCSD_NO_MERGE") != nullptr;
+    if (const char* pr = getenv("CCSD_XA_PRIO")) pl->opt_xa_prio = atoi(pr);
+    if (const char* sg = getenv("CCSD_XA_STAGGER")) sscanf(sg, "%d,%d", &pl->opt_xa_stagger_mask, &pl->opt_xa_stagger_sleep);
     if (const char* sg = getenv("CCSD_R2_STAGGER")) sscanf(sg, "%d,%d", &pl->opt_r2_stagger_mask, &pl->opt_r2_stagger_sleep);
     if (const char* xt = getenv("CCSD_XA_THREADS")) { const int v = atoi(xt); if (v >= 64 && v <= 512 && v % 64 == 0) pl->opt_xa_threads = v; }
     PlanBuilder pb;
@@ -493,6 +497,7 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
 static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Workspace& w, void* stream, bool set_b = false) {
     xa.P0 = set_b ? w.P0b : w.P0; xa.P1 = set_b ? w.P1b : w.P1; xa.U1 = set_b ? w.U1b : w.U1; xa.chan_ws = w.chan;
     xa.p1_raw = w.p1_raw; xa.dbg = pl->dbg ? pl->dbg + 32 : nullptr;
+    xa.stagger_mask = pl->opt_xa_stagger_mask; xa.stagger_sleep = pl->opt_xa_stagger_sleep; xa.prio_mode = pl->opt_xa_prio;
     const int xa_threads = pl->opt_xa_threads;   // 256 unless CCSD_XA_THREADS was set when the plan was created (diagnostic: 64..512)
     prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
     xa.wp = pl->wp; xa.hpairs = pl->hpairs;

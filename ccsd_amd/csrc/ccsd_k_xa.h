@@ -30,6 +30,8 @@ struct XaArgs {
     const unsigned char* hpairs;          // (e, e2), e <= e2: unordered pairs of the dense hodge layer
     long long* dbg;
     CorrFuse cf;
+    int prio_mode;                        // 0: priority = dispatch rank (default); 1: none; 2-4: diagnostic variants (CCSD_XA_PRIO)
+    int stagger_mask, stagger_sleep;      // diagnostic (CCSD_XA_STAGGER): workgroups with (blockIdx.x & mask) != 0 start sleep x 64 cycles late
 };
 
 // fused Langevin corrector apply for x and adj held in LDS (same expressions as k_langevin_apply)
@@ -49,6 +51,16 @@ CCSD_DEV void corr_apply_xa(const CorrFuse& cf, const NoiseArgs& na, int b, int 
         const float z = raw_noise_adj(nc, b, i, j, N) * s_flags[i] * s_flags[j];
         s_adj[t] = fmaf(c2a, z, fmaf(c1a, cf.net_adj[(size_t)b * N * N + t], s_adj[t]));
     }
+}
+
+// s_setprio with a run-time (wave-uniform) level 0..3
+CCSD_DEV void wave_prio(int p) {
+#ifndef CCSD_EMU
+    if (p == 0) __builtin_amdgcn_s_setprio(0); else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
+#else
+    (void)p;
+#endif
 }
 
 // clamp(rowsum(A with unit diagonal), 1)^-1/2 for `nc` channels   (DenseGCNConv, layers.py:139-145)
@@ -177,6 +189,32 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
 #endif
 
     stamp(xa.dbg, 0);
+#if !defined(CCSD_EMU) && !defined(CCSD_BARRIER_PROF)
+    if (xa.dbg && (tid & 63) == 0 && wave_id < 4) {      // diagnostic: where the hardware put this wave (HW_ID: SIMD, CU, SE, XCC)
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xa.dbg[(size_t)blockIdx.x * 64 + 26 + wave_id] = (long long)hw | ((long long)xcc << 32);
+    }
+#endif
+#ifndef CCSD_EMU
+    // Issue priority by dispatch age.  The workgroups b, b + 256, b + 512, b + 768 share a CU (tools/stamps.py reads HW_ID: 256 of
+    // 256 CUs) and run in lockstep; the SIMDs arbitrate between their waves by priority, then AGE, so the youngest workgroup of a CU
+    // loses every contended slot: measured lives 145 k / 145 k / 158 k / 177 k cycles, and the launch lasts as long as the slowest.
+    // Raising the priority with the dispatch rank evens the four out.  (A hint: placement and timing never affect results.)
+    const int prio_rank = (blockIdx.x >> 8) & 3;
+    // prio_mode 0: the priority ROTATES with the phase -- rank r has level (r + phase) mod 4, so every workgroup is the favoured
+    // one in a quarter of the phases and the four finish together; 2: static (level = rank); 1: none
+    auto prio_phase = [&](int phase) {
+        if (xa.prio_mode == 0) wave_prio((prio_rank + phase) & 3);
+        else if (xa.prio_mode == 2 && phase == 0) wave_prio(prio_rank);
+    };
+    int prio_k = 1;
+    prio_phase(0);
+    if (xa.stagger_sleep && (blockIdx.x & xa.stagger_mask)) {
+        for (int i = 0; i < xa.stagger_sleep; i += 100) __builtin_amdgcn_s_sleep(100);
+    }
+#endif
     for (int i = tid; i < N; i += nth) s_flags[i] = xa.flags[(size_t)b * N + i];
     float nx_net = 0.f, nx_z = 0.f, na_net = 0.f, na_z = 0.f;
 
@@ -240,11 +278,13 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
 #define ATTN_LAYERS p.gl
 #define ATTN_NL p.x_depth
 #define ATTN_TAP(l) gmh_tap(l)
+#define ATTN_MID(l) (void)0
 #define ATTN_IDLE(l) (void)0
 #include "ccsd_attn_stack.inc"
 #undef ATTN_LAYERS
 #undef ATTN_NL
 #undef ATTN_TAP
+#undef ATTN_MID
 #undef ATTN_IDLE
         } else {
         gcn_dinv(s_adj, s_dinv, 1, N);
@@ -389,7 +429,8 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
         if (hodge_on && !hodge_idle) hodge_early(tid, nth);
 #define ATTN_LAYERS p.al
 #define ATTN_NL p.a_L
-#define ATTN_TAP(l) (void)0
+#define ATTN_TAP(l) prio_phase(prio_k++)
+#define ATTN_MID(l) prio_phase(prio_k++)
 #define ATTN_IDLE(l)                                                                                  \
     if (x_late && (l) < 2 && wave_id == n_waves - 1) (void)xnet_late_stage((l), p, w, wp, sm, xa, na, b);   \
     if (hodge_idle && (l) == 2 && wave_id == n_waves - 1) hodge_early(tid - wave_id * (nth / n_waves), nth / n_waves);
@@ -397,9 +438,11 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
 #undef ATTN_LAYERS
 #undef ATTN_NL
 #undef ATTN_TAP
+#undef ATTN_MID
 #undef ATTN_IDLE
 
         stamp(xa.dbg, 12);
+        prio_phase(prio_k++);
         // ---- hodge branch of ScoreNetworkA_CC (ScoreNetwork_A_CC.py:295-316)
         if (VAR != XA_HB && p.h_L > 0) {
             float* s_hd = sm + p.o_hd;          // [hodge channel][E]: diagonals that reach the final MLP
@@ -571,6 +614,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                     dense_pairs(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
                 __syncthreads();
                 stamp(xa.dbg, 17);
+                prio_phase(prio_k++);
                 // second (last) HodgeAdjAttentionLayer: dense hodge adjacency, only the diagonal of its output
                 float* s_deg = sm + p.o_deg;         // [cin1][E]
                 for (int t = tid; t < h1.cin * E; t += nth) {
@@ -984,6 +1028,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
         }
 
         stamp(xa.dbg, 13);
+        prio_phase(prio_k++);
         // ---- final MLP over every (i,j) on [graph channels | hodge channels]  (ScoreNetwork_A_CC.py:318-331)
         const MlpD& m = p.a_fin;
         const float* wf = w;

@@ -72,3 +72,50 @@ if os.environ.get("STAMPS_BARRIERS"):
         print(f"  {k:3d} {dur[k]:9.0f}   " + " ".join(f"{busy[w, k]:7.0f}" for w in range(4)) + f"   at {np.median(rel[:, k] - start):8.0f}")
     ct = dfull[B + 255, :16].astype(np.int64)
     print("layer 1 edge-MLP interval, workgroup 0 wave 0: chain tile (entry, gather, linear 1, middle, last + epilogue), node MLP second Linear:", [int(ct[i + 1] - ct[i]) for i in range(0, 5)], int(ct[7] - ct[6]), int(ct[8] - ct[7]))
+life = x[:, 14] - x[:, 0]
+print("k_xa workgroup life percentiles (min, 10, 50, 90, 99, max):", [int(np.percentile(life, q)) for q in (0, 10, 50, 90, 99, 100)])
+lr = d[:, 5] - d[:, 0]
+print("k_r2 workgroup life percentiles (min, 10, 50, 90, 99, max):", [int(np.percentile(lr, q)) for q in (0, 10, 50, 90, 99, 100)])
+hw = x[:, 26:30].astype(np.int64)
+simd = (hw >> 4) & 3
+cu = (hw[:, 0] >> 8) & 15
+se = (hw[:, 0] >> 13) & 7        # (gfx9 HW_ID: [3:0] wave, [5:4] simd, [7:6] pipe, [11:8] cu, [12] sh, [15:13] se)
+xcc = (hw[:, 0] >> 32) & 15
+distinct = np.array([len(set(r)) for r in simd])
+for k in (4, 3, 2, 1):
+    m = distinct == k
+    if m.any():
+        print(f"workgroups with waves on {k} distinct SIMDs: {int(m.sum())}, median life {int(np.median(life[m]))}, p90 {int(np.percentile(life[m], 90))}")
+slow = life > np.percentile(life, 85)
+print("slow workgroups (top 15 %): distinct-SIMD histogram", np.bincount(distinct[slow], minlength=5)[1:], " all:", np.bincount(distinct, minlength=5)[1:])
+key = (xcc.astype(np.int64) << 16) | (se << 8) | (((hw[:, 0] >> 12) & 1) << 4) | cu
+groups = {}
+for i, kk in enumerate(key):
+    groups.setdefault(int(kk), []).append(i)
+sizes = np.array([len(v) for v in groups.values()])
+print("workgroups per (xcc, se, sh, cu):", np.bincount(sizes))
+gl = np.array([[life[i] for i in v][:4] + [0] * (4 - min(4, len(v))) for v in groups.values()])
+print("per-CU: median of (max life - min life) among its workgroups:", int(np.median(gl.max(1) - np.where(gl > 0, gl, 10**9).min(1))))
+cs = np.array([np.mean([life[i] for i in v]) for v in groups.values()])
+print("per-CU mean life percentiles (min, 50, 90, max):", [int(np.percentile(cs, q)) for q in (0, 50, 90, 100)])
+labs = {0: "start", 1: "X-net done", 2: "L0 start", 5: "L1 start", 8: "L2 start", 12: "hodge start", 13: "final MLP start", 14: "end"}
+ks = sorted(labs)
+fast = life < np.percentile(life, 30)
+print("phase durations, fast (bottom 30 %) vs slow (top 15 %) workgroups:")
+for a_, b_ in zip(ks[:-1], ks[1:]):
+    print(f"  {labs[a_]:16s} -> {labs[b_]:16s} fast {int(np.median(x[fast, b_] - x[fast, a_])):7d}   slow {int(np.median(x[slow, b_] - x[slow, a_])):7d}")
+print("co-resident workgroups of a few CUs: (block id, life, start - min start):")
+for kk in list(groups)[:6]:
+    v = groups[kk]
+    s0 = min(x[i, 0] for i in v)
+    print("  ", sorted((int(i), int(life[i]), int(x[i, 0] - s0)) for i in v))
+order_ok = 0
+slow_is_last = 0
+for v in groups.values():
+    ids = sorted(v)
+    if len(ids) == 4 and all((ids[j + 1] - ids[j]) % 256 == 0 for j in range(3)):
+        order_ok += 1
+    st = sorted(v, key=lambda i: x[i, 0])
+    if life[st[-1]] == max(life[i] for i in v):
+        slow_is_last += 1
+print("CUs whose four block ids are congruent mod 256:", order_ok, "of", len(groups), "; CUs whose last-started workgroup is the slowest:", slow_is_last)
