@@ -197,7 +197,6 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
         xa.dbg[(size_t)blockIdx.x * 64 + 26 + wave_id] = (long long)hw | ((long long)xcc << 32);
     }
 #endif
-#ifndef CCSD_EMU
     // Issue priority by dispatch age.  The workgroups b, b + 256, b + 512, b + 768 share a CU (tools/stamps.py reads HW_ID: 256 of
     // 256 CUs) and run in lockstep; the SIMDs arbitrate between their waves by priority, then AGE, so the youngest workgroup of a CU
     // loses every contended slot: measured lives 145 k / 145 k / 158 k / 177 k cycles, and the launch lasts as long as the slowest.
@@ -211,6 +210,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
     };
     int prio_k = 1;
     prio_phase(0);
+#ifndef CCSD_EMU
     if (xa.stagger_sleep && (blockIdx.x & xa.stagger_mask)) {
         for (int i = 0; i < xa.stagger_sleep; i += 100) __builtin_amdgcn_s_sleep(100);
     }
