@@ -624,6 +624,13 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                     const float* Hc = s_h1m + (size_t)c * E * E + e;
                     float s0 = 0.f, s1 = 0.f;
                     int e2 = 0;
+                    for (; e2 + 12 <= E; e2 += 12) {             // twelve LDS reads in flight per round (a 2-term body waits per pair)
+                        float v[12];
+#pragma unroll
+                        for (int u = 0; u < 12; ++u) v[u] = Hc[(e2 + u) * E];
+#pragma unroll
+                        for (int u = 0; u < 12; u += 2) { s0 += v[u]; s1 += v[u + 1]; }
+                    }
                     for (; e2 + 2 <= E; e2 += 2) { s0 += Hc[e2 * E]; s1 += Hc[(e2 + 1) * E]; }
                     if (e2 < E) s0 += Hc[e2 * E];
                     s_deg[t] = 1.0f / sqrtf(fmaxf(s0 + s1, 1.f));
@@ -640,28 +647,43 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                             const float* Hc = s_h1m + (size_t)pf_c * E * E;
                             const float* dg = s_deg + pf_c * E;
                             const int d = 16 * pf_ct + pf_l15;
-                            float bval[16];
+                            // (every LDS operand of a loop is requested before the first use: a uniform branch per step would put each
+                            // read and its s_waitcnt into a basic block of its own -- 3.1 k cycles per row tile for nine MFMAs)
+                            float bval[16], dgv[16], pc0[16], pc1[16];
+#pragma unroll
+                            for (int s0 = 0; s0 < 16; ++s0) {
+                                const int k = 4 * s0 + pf_kq, kc = k < E ? k : E - 1;
+                                dgv[s0] = dg[kc]; pc0[s0] = s_p1c[kc]; pc1[s0] = s_p1c[E + kc];
+                            }
+                            const bool raw = xa.p1_raw != 0;
 #pragma unroll
                             for (int s0 = 0; s0 < 16; ++s0) {
                                 const int k = 4 * s0 + pf_kq;
-                                const int kc = k < E ? k : E - 1;
-                                bval[s0] = (k < E && d < qw1) ? dg[kc] * p1_compose(kc, pfb[s0], pfu) : 0.f;
+                                const float comp = raw ? fmaf(pc0[s0], pfb[s0], pc1[s0] * pfu) : pfb[s0];      // p1_compose
+                                bval[s0] = (k < E && d < qw1) ? dgv[s0] * comp : 0.f;
                             }
                             const float bias = w[h1.bcat + pf_c * qw1 + (d < qw1 ? d : qw1 - 1)];
                             for (int rt = 0; rt < mtE; ++rt) {
                                 const int e = 16 * rt + pf_l15, ec = e < E ? e : E - 1;
+                                float hv[16], dgo[4];
+#pragma unroll
+                                for (int s0 = 0; s0 < 16; ++s0) {
+                                    const int k = 4 * s0 + pf_kq;
+                                    hv[s0] = Hc[ec * E + (k < E ? k : E - 1)];
+                                }
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { const int eo = 16 * rt + 4 * pf_kq + r; dgo[r] = dg[eo < E ? eo : E - 1]; }
                                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                                 for (int s0 = 0; s0 < 16; ++s0)
                                     if (s0 < ksE) {
                                         const int k = 4 * s0 + pf_kq;
-                                        const float hv = Hc[ec * E + (k < E ? k : E - 1)];
-                                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32((e < E && k < E) ? hv : 0.f, bval[s0], acc, 0, 0, 0);
+                                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32((e < E && k < E) ? hv[s0] : 0.f, bval[s0], acc, 0, 0, 0);
                                     }
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
                                     const int eo = 16 * rt + 4 * pf_kq + r;
-                                    if (eo < E && d < qw1) s_hq[(pf_c * E + eo) * qw1 + d] = fmaf(dg[eo], acc[r], bias);
+                                    if (eo < E && d < qw1) s_hq[(pf_c * E + eo) * qw1 + d] = fmaf(dgo[r], acc[r], bias);
                                 }
                             }
                         }
@@ -691,16 +713,24 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                 // one lane per (edge, channel), 8 lanes per edge: the channel's attention logit, then the edge's lane 0 collects the
                 // eight and runs mlp_attention (one lane per edge walked the channels one after the other: 7.6 k cycles of a single
                 // wave while the other three waited)
-                for (int t0 = tid; t0 < ((8 * E + 63) & ~63); t0 += nth) {
-                    const int e = t0 >> 3, c = t0 & 7;
+                const bool fast1 = h1.adim == 4 && h1.nchunk == 2 && h1.dsplit == 2;    // (the qm9_CC shape: both chunks in one block)
+                // lanes per edge: 4 when the layer has at most four input channels (E = 36: 144 lanes, ONE pass of the 256 threads
+                // instead of a second pass that only wave 0 walks), else 8
+                const int lsh = h1.cin <= 4 ? 2 : 3, lpe = 1 << lsh;
+                for (int t0 = tid; t0 < ((lpe * E + 63) & ~63); t0 += nth) {
+                    const int e = t0 >> lsh, c = t0 & (lpe - 1);
                     float sacc = 0.f;
                     if (e < E && c < h1.cin) {
                         const float* q = s_hq + (c * E + e) * qw1;
+                        if (fast1) {
+                            const float4 qq = *reinterpret_cast<const float4*>(q), kk = *reinterpret_cast<const float4*>(q + 4);
+                            sacc = (tanh_f(fmaf(qq.y, kk.y, qq.x * kk.x) * rks) + tanh_f(fmaf(qq.w, kk.w, qq.z * kk.z) * rks)) * 0.5f;
+                        } else
                         sacc = attn_logits(q, q + h1.adim, h1.nchunk, h1.dsplit, rks) * (1.0f / (float)h1.nchunk);
                     }
                     float in[CCSD_SMALLW], out[CCSD_SMALLW];
 #pragma unroll
-                    for (int k = 0; k < CCSD_SMALLW; ++k) in[k] = __shfl(sacc, ((tid & 63) & ~7) + k, 64);
+                    for (int k = 0; k < CCSD_SMALLW; ++k) in[k] = k < lpe ? __shfl(sacc, ((tid & 63) & ~(lpe - 1)) + (k < lpe ? k : 0), 64) : 0.f;
                     if (c != 0 || e >= E) continue;
                     if (w4_1) small_mlp_lds<4>(s_hw + p.hw_stride, h1.matt.n, in, out); else small_mlp_lds<CCSD_SMALLW>(s_hw + p.hw_stride, h1.matt.n, in, out);
 #else

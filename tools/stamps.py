@@ -119,3 +119,4 @@ for v in groups.values():
     if life[st[-1]] == max(life[i] for i in v):
         slow_is_last += 1
 print("CUs whose four block ids are congruent mod 256:", order_ok, "of", len(groups), "; CUs whose last-started workgroup is the slowest:", slow_is_last)
+print("hodge MFMA projection (wave 0): operands ready after", int(np.median(x[:, 22] - x[:, 18])), ", first row tile", int(np.median(x[:, 23] - x[:, 22])), ", rest + barrier", int(np.median(x[:, 19] - x[:, 23])))
