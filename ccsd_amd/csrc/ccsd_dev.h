@@ -791,17 +791,26 @@ CCSD_DEV void gcn_tile_multi(const float* xT, int ldn, int fin, int N, const flo
 #pragma unroll
             for (int c = 0; c < NC; ++c) bw[u][c] = wcol[kc * cp + 16 * c];
         }
+        // (the x fragments of the four steps are requested before the first MFMA: inside the per-step branch every LDS read would
+        // sit in a basic block of its own and be waited for on the spot)
+        float avs[4][NTN];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = 4 * (s00 + u) + kq, kc = k < fin ? k : fin - 1;
+#pragma unroll
+            for (int tn = 0; tn < NTN; ++tn) {
+                const int j = 16 * tn + l15;
+                const float a0 = xT[kc * ldn + (j < N ? j : N - 1)];
+                avs[u][tn] = (j < N && k < fin) ? a0 : 0.f;              // rows beyond N / k beyond fin contribute nothing
+            }
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (s00 + u < ks) {
-                const int k = 4 * (s00 + u) + kq, kc = k < fin ? k : fin - 1;
 #pragma unroll
                 for (int tn = 0; tn < NTN; ++tn) {
-                    const int j = 16 * tn + l15;
-                    const float a0 = xT[kc * ldn + (j < N ? j : N - 1)];
-                    const float av = (j < N && k < fin) ? a0 : 0.f;      // rows beyond N / k beyond fin contribute nothing
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) xw[c][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[u][c], xw[c][tn], 0, 0, 0);
+                    for (int c = 0; c < NC; ++c) xw[c][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[u][tn], bw[u][c], xw[c][tn], 0, 0, 0);
                 }
             }
     }
@@ -823,24 +832,31 @@ CCSD_DEV void gcn_tile_multi(const float* xT, int ldn, int fin, int N, const flo
         f32x4 acc[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float afr[NTN][4], dio[4];
 #pragma unroll
         for (int tn = 0; tn < NTN; ++tn)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int j = 16 * tn + 4 * kq + jj, jc = j < N ? j : N - 1;
                 const float a0 = A[ic * N + jc];
-                const float av = (i < N && j < N) ? (i == j ? 1.f : a0) : 0.f;
+                afr[tn][jj] = (i < N && j < N) ? (i == j ? 1.f : a0) : 0.f;
+            }
 #pragma unroll
-                for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xw[c][tn][jj], acc[c], 0, 0, 0);
+        for (int r = 0; r < 4; ++r) { const int io = 16 * ti + 4 * kq + r; dio[r] = dinv[io < N ? io : N - 1]; }
+#pragma unroll
+        for (int tn = 0; tn < NTN; ++tn)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[tn][jj], xw[c][tn][jj], acc[c], 0, 0, 0);
             }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int io = 16 * ti + 4 * kq + r;
             if (io < N) {
-                const float di = dinv[io];
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
-                    if (col0 + 16 * c + l15 < ncols) out(io, col0 + 16 * c + l15, fmaf(acc[c][r], di, bb[c]));
+                    if (col0 + 16 * c + l15 < ncols) out(io, col0 + 16 * c + l15, fmaf(acc[c][r], dio[r], bb[c]));
             }
         }
     }
