@@ -3,6 +3,7 @@
 The fixtures under tests/golden/ were produced by tools/make_golden.py, which imports the
 upstream reference in the build container.  These tests run anywhere (no GPU, no reference).
 """
+import contextlib
 import json
 
 import numpy as np
@@ -291,3 +292,50 @@ def test_registry_errors_match_reference():
         O.SDE("foo", 0.1, 1.0, 10)
     with pytest.raises(ValueError):
         O.run_network({"model_type": "nope"}, {}, None, None, None, None)
+
+
+@contextlib.contextmanager
+def ulp_perturbed_draws(pattern_seed):
+    """Every torch.randn / randn_like draw moved by exactly one ulp, up or down by a seeded pattern (a 6e-8 relative change)."""
+    rn, rl = torch.randn, torch.randn_like
+    gen = np.random.default_rng(pattern_seed)
+
+    def bump(t):
+        up = torch.from_numpy(gen.integers(0, 2, size=tuple(t.shape)).astype(bool))
+        return torch.nextafter(t, torch.where(up, torch.full_like(t, float("inf")), torch.full_like(t, float("-inf"))))
+    torch.randn = lambda *s, **k: bump(rn(*s, **k))
+    torch.randn_like = lambda t, **k: bump(rl(t, **k))
+    try:
+        yield
+    finally:
+        torch.randn, torch.randn_like = rn, rl
+
+
+def test_traj_rtol_is_the_reference_one_ulp_sensitivity():
+    """The only trajectory tolerances wider than 1e-4 (parity_cases.TRAJ_RTOL: S4 on ENZYMES_small_CC with 4 / 20 scales) are
+    pinned to a measurement on the reference algorithm alone: the oracle reproduces the golden bit for bit, and the same fp32
+    run with every normal draw moved by one ulp ends `sens` away from it on rank2 (relative to the tensor's scale, the
+    measure assert_close uses).  TRAJ_RTOL must lie within [1.5, 2.5] x the median sensitivity over four perturbation patterns:
+    no implementation that rounds anywhere differently from the reference can be held to less, and a tolerance looser than that
+    would hide defects."""
+    from tests.parity_cases import TRAJ_RTOL
+    gname, ckpt = "s4_ccsd_enzymes_small_CC", "ccsd_enzymes_small_CC"
+    g = load_golden(f"g5_{gname}.npz")
+    assert rng_matches(g)
+    assert set(TRAJ_RTOL) == {(gname, "k4"), (gname, "k20")}
+    for case in ("k4", "k20"):
+        fn, nets, flags, parts = oracle_sampler_from_golden(g, ckpt, case)
+        torch.manual_seed(int(g["seed"]))
+        plain = fn(*nets, flags)[2]
+        ref = torch.from_numpy(g[f"{case}/rank2"])
+        _close(plain.numpy(), ref.numpy(), "the oracle no longer reproduces the S4 ENZYMES golden: re-derive TRAJ_RTOL")
+        scale = ref.abs().max().item()
+        sens = []
+        for pattern in range(4):
+            with ulp_perturbed_draws(pattern):
+                torch.manual_seed(int(g["seed"]))
+                pert = fn(*nets, flags)[2]
+            sens.append(((pert - plain).abs().max() / scale).item())
+        med = float(np.median(sens))
+        assert med > 0.5e-4, (case, sens)
+        assert 1.5 * med <= TRAJ_RTOL[(gname, case)] <= 2.5 * med, (case, sens, TRAJ_RTOL[(gname, case)])

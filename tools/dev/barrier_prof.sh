@@ -9,7 +9,7 @@ if [ "$1" = build ]; then
     O=ccsd_amd/csrc/_obj
     mkdir -p tools/dev/_prof
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DCCSD_BARRIER_PROF -c ccsd_amd/csrc/ccsd_xa.hip -o tools/dev/_prof/ccsd_xa_prof.o
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $O/ccsd_hip.o $O/ccsd_r2.o tools/dev/_prof/ccsd_xa_prof.o -o tools/dev/_prof/libccsd_hip.so
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $O/ccsd_hip.o $O/ccsd_r2.o $O/ccsd_r2b.o $O/ccsd_r2c.o $O/ccsd_r2d.o tools/dev/_prof/ccsd_xa_prof.o -o tools/dev/_prof/libccsd_hip.so
     rm tools/dev/_prof/ccsd_xa_prof.o
 else
     cp tools/dev/_prof/libccsd_hip.so ccsd_amd/libccsd_hip.so

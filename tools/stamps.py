@@ -109,6 +109,11 @@ for kk in list(groups)[:6]:
     v = groups[kk]
     s0 = min(x[i, 0] for i in v)
     print("  ", sorted((int(i), int(life[i]), int(x[i, 0] - s0)) for i in v))
+w0 = np.array([len(set(int(simd[i, 0]) for i in v)) for v in groups.values() if len(v) == 4])
+print("co-resident workgroups: distinct SIMDs among their wave-0s (histogram over CUs, 1..4):", np.bincount(w0, minlength=5)[1:])
+print("SIMD of waves 0..3 of the co-resident workgroups of a few CUs (by block id):")
+for kk in list(groups)[:6]:
+    print("  ", [(int(i), [int(t) for t in simd[i]]) for i in sorted(groups[kk])])
 order_ok = 0
 slow_is_last = 0
 for v in groups.values():
