@@ -18,6 +18,9 @@ static inline int xa_variant(const PlanD& p) {
     for (int l = 0; l < p.a_L; ++l) conv_mlp = conv_mlp || p.al[l].conv_mlp;
     if (p.x_gmh) for (int l = 0; l < p.x_depth; ++l) conv_mlp = conv_mlp || p.gl[l].conv_mlp;
     if (conv_mlp || (p.hb_L && p.x_gmh) || p.h_L > 2) return XA_GEN;
+    // the small-graph XA_PLAIN / XA_GMH variants are compiled without the two widest final-MLP chain shapes (ccsd_k_xa.h: they cost
+    // them their registers -- 30 VGPRs spilled around the final MLP of every launch); the HodgeBaseline networks need them
+    if (!p.chan_global && !p.hb_L && p.a_fin.chain >= 5) return XA_GEN;
     return p.hb_L ? XA_HB : p.x_gmh ? XA_GMH : XA_PLAIN;
 }
 static inline const void* xa_kernel(const PlanD& p) {

@@ -33,10 +33,25 @@ __device__ long long g_ct[16];
 // ---------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------
+// Index of the calling wave in its workgroup, as a value the compiler KNOWS to be wave-uniform.  hipcc treats threadIdx.x >> 6 as
+// divergent (the launch bounds give no y / z extents), so every `for (task = wave; ...)` loop, its index arithmetic and the
+// weight pointers derived from it would run on the vector ALU under exec masks; v_readfirstlane moves it to an SGPR once.
+CCSD_DEV int wave_index() {
+#ifdef CCSD_EMU
+    return 0;
+#else
+    return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#endif
+}
 // Diagnostic cycle stamps (ccsd_debug_stamps): thread 0 of every workgroup writes the shader clock at phase
 // boundaries into a caller buffer [workgroup][64] (k_r2: slots 0.., k_xa: slots 32..).  NULL (the default) compiles to a uniform branch not taken.
 CCSD_DEV void stamp(long long* dbg, int slot) {
 #ifndef CCSD_EMU
+#ifdef CCSD_STOP_DIAG
+    // Diagnostic build only (tools/dev/phase_mix.sh): the whole grid ends at the stamp whose slot + 1 the host wrote behind the stamp rows, so
+    // that per-dispatch PMC counters of launches stopped at successive stamps difference into a per-phase instruction mix.
+    if (dbg && dbg[((size_t)gridDim.x + 254) * 64 + 63] == slot + 1) __builtin_amdgcn_endpgm();
+#endif
     if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 64 + slot] = (long long)__builtin_readcyclecounter();
     // slot 0 / the kernel's last slot also leave the constant 100 MHz counter two slots from the end of the kernel's half-row:
     // shader clock = cycles / real time (tools/stamps.py)
@@ -247,7 +262,7 @@ CCSD_DEV float block_sum(float v, float* red) {
 #else
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+    const int wave = wave_index(), lane = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
     __syncthreads();
     if (lane == 0) red[wave] = v;
     __syncthreads();
@@ -406,7 +421,7 @@ CCSD_DEV void block_linear(float* Y, int ldy, const float* X, int ldx, const flo
         }
 #else
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = wave_index(), lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int mt = (rows + 15) >> 4, nt = (out + 15) >> 4, ks = (in + 3) >> 2;
     const int l15 = lane & 15, kq = lane >> 4;
     for (int task = wave; task < mt * nt; task += nw) {
@@ -626,7 +641,7 @@ CCSD_DEV void mlp_chain(const MlpD& m, const float* __restrict__ wp, const float
 #ifdef CCSD_EMU
     const int wave = 0, nw = 1;
 #else
-    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int wave = wave_index(), nw = blockDim.x >> 6;
 #endif
     for (int tile = wave; tile < (rows + 15) >> 4; tile += nw) mlp_chain_tile<NI, NH, NO>(m, wp, X, ldx, X2, ksplit, 16 * tile, rows, rowoff, epi);
 }
@@ -900,7 +915,7 @@ CCSD_DEV void tile_mma(TileAcc& t, const float* As, const float* Bs) {
             t.a[i][j] = acc;
         }
 #else
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = wave_index(), lane = threadIdx.x & 63;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32, l15 = lane & 15, kq = lane >> 4;
 #pragma unroll
     for (int s = 0; s < T_BK / 4; ++s) {
@@ -924,7 +939,7 @@ CCSD_DEV void tile_foreach4(TileAcc& t, Fn f) {
             f(i, j, v);
         }
 #else
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = wave_index(), lane = threadIdx.x & 63;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32, l15 = lane & 15, kq = lane >> 4;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -947,7 +962,7 @@ CCSD_DEV void tile_foreach4n(TileAcc* t, Fn f) {
             f(i, j, v);
         }
 #else
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = wave_index(), lane = threadIdx.x & 63;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32, l15 = lane & 15, kq = lane >> 4;
 #pragma unroll
     for (int i = 0; i < 2; ++i)

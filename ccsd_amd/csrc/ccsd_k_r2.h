@@ -275,6 +275,13 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
         __syncthreads();
     }
     stamp(ra.dbg, 1);
+#ifdef CCSD_STOP_DIAG
+    // diagnostic build (tools/dev/phase_mix.sh): ablation bits written by the host behind the stamp rows -- 1: no projection k loops,
+    // 2: no H k loops, 4: no column-tile epilogue, 8: epilogue without noise, 16: no column tiles at all
+    const int diag = ra.dbg ? (int)ra.dbg[((size_t)gridDim.x + 254) * 64 + 62] : 0;
+#else
+    constexpr int diag = 0;
+#endif
     const HodgeLayerD& h0 = p.hl[0];
     const HodgeLayerD& h1 = p.hl[1];
     const bool doP0 = ra.want_p && p.h_L > 0, doP1 = hodge2;
@@ -451,6 +458,9 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
             for (int u = 0; u < D - 1; ++u)
                 if (blk0 + u < nblk) block(u, blk0 + u, false);
         };
+        if ((diag & 1) && type != 0) { (void)0; }
+        else if ((diag & 2) && type == 0) { (void)0; }
+        else
         if (ST && strip) {
             if (type == 2) kloop(BoolTag<false>{}, BoolTag<true>{}, BoolTag<true>{});
             else if (type == 0) kloop(BoolTag<true>{}, BoolTag<false>{}, BoolTag<true>{});
@@ -528,7 +538,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     // path): phase 2's epilogue is pure VALU work (Philox, Box-Muller, masks, update), the projection tiles pure MFMA work, and
     // the partner waves of a SIMD then feed different pipes instead of queueing for the same one phase after phase.
     nHtasks = nH;
-    const int nw1 = nth >> 6, wave1 = tid >> 6;
+    const int nw1 = nth >> 6, wave1 = wave_index();
     int n1 = ntask;
     if (AFFINE && !wb) {     // (a pass that writes the new state back into the block runs every task first: they read all of it)
         n1 = ((nH + nw1 - 1) / nw1) * nw1;
@@ -623,7 +633,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
         //    swaps per register) leaves the finished sums of column tile j in the lanes of class j, so all 64 lanes carry four
         //    real elements (one Philox group each) instead of a quarter-filled third row tile per column tile.
         typedef float f32x4 __attribute__((ext_vector_type(4)));
-        const int wave = tid >> 6, nw = nth >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+        const int wave = wave_index(), nw = nth >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
         constexpr int TF = MT - 1;                          // full row tiles == full 16-wide blocks of the contraction index
         const int ar0 = l15 * ldh + 4 * kq;                // A, full tiles: row l15 of row tile 0, slot group kq (rows < E0: no clamp)
         const int srow = E0 + (l15 & 3) < E ? E0 + (l15 & 3) : E - 1;
@@ -694,14 +704,14 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                     sacc = __builtin_amdgcn_mfma_f32_4x4x1f32(c < E ? hv : 0.f, bvr[s0], sacc, 0, 0, 0);
                 }
             }
-            if (nin) {                                     // false only for the padding columns of the last column tile
+            if (nin && !(diag & 4)) {                      // false only for the padding columns of the last column tile
                 const float fr = (float)sFrb[n];
                 unsigned gi = vo + 16u * (unsigned)tn;
 #pragma unroll
                 for (int i = 0; i < TF; ++i) {
                     const int e0 = 16 * i + 4 * kq;
                     float z[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (MODE >= 2 || (MODE == 1 && eznorm)) {
+                    if ((MODE >= 2 || (MODE == 1 && eznorm)) && !(diag & 8)) {
                         if (INJ) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) z[r] = zrp[gi + (unsigned)(r * K)];
@@ -758,7 +768,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
             }
             const int tn = tn0 + kq * nw;
             const int n = 16 * tn + l15;
-            if (tn < ntn && n < K) {
+            if (tn < ntn && n < K && !(diag & 4)) {
                 const float s_ = MODE == 0 ? ep.sscale : MODE == 1 ? 1.f : ep.pb;
                 const float sa = s_ * p.f_alpha, sb = s_ * p.f_beta, sg = s_ * p.f_gamma;
                 const float pa = ep.pa, pc = ep.pc;
@@ -766,7 +776,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                 const float fr = (float)sFrb[n];
                 const unsigned gi = (unsigned)(E0 * K + n);
                 float z[4] = {0.f, 0.f, 0.f, 0.f};
-                if (MODE >= 2 || (MODE == 1 && eznorm)) {
+                if ((MODE >= 2 || (MODE == 1 && eznorm)) && !(diag & 8)) {
                     if (INJ) {
                         const float* const zrp = na.zr + (size_t)b * E * K;
 #pragma unroll
@@ -821,6 +831,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
         f32x4 sp0 = zero4, sp1 = zero4, sp2 = zero4, sp3 = zero4;
         for (int tn = wave; tn < ntn; tn += nw, ++cnt) {
             if (cnt == pslot && pt < ntask) { run_tile(pt); pt += nw; }
+            if (diag & 16) continue;
             f32x4 sacc;
             switch (sel) {
                 case 0: case 1: sacc = coltile(std::integral_constant<int, 0>{}, NoInj{}, tn); break;
@@ -861,7 +872,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
         //  * masks: fl of the lane's four rows is one ds_read_b128 of sFl, fr one byte per column tile;
         //  * HBM: uniform base pointer + one per-lane 32-bit element offset, advanced by uniform row / tile strides.
         typedef float f32x4 __attribute__((ext_vector_type(4)));
-        const int wave = tid >> 6, nw = nth >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+        const int wave = wave_index(), nw = nth >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
         constexpr int TF = RS ? MT - 1 : MT;               // full blocks of the contraction index
         const bool padblk = RS == 0 && (E & 15) != 0;      // the last full block reaches beyond E: its A values are zeroed
         const int ar0 = (l15 < E ? l15 : E - 1) * ldh + 4 * kq;   // A: row l15 of row tile 0, slot group kq
@@ -1012,7 +1023,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
         for (; pt < ntask; pt += nw) run_tile(pt);
     } else {
         typedef float f32x4 __attribute__((ext_vector_type(4)));
-        const int wave = tid >> 6, nw = nth >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+        const int wave = wave_index(), nw = nth >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
         constexpr int KSE = 4 * MT;                        // ceil(16*MT / 4) k-steps cover E <= 16*MT
         float hA[MT][KSE];
 #pragma unroll

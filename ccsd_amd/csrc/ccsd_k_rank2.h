@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_gemm_h(const float* __restrict__ rank2,
     __shared__ __align__(16) float As[T_BM * H_LD];
     __shared__ __align__(16) float Bs[T_BN * H_LD];
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int tid = threadIdx.x, wave = wave_index(), lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const bool diag = tx == ty, vec = (K & 3) == 0;
     // thread -> (row, 4-float column group) of the 64 x 32 slab: two groups per thread and matrix
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void k_gemm_p0(const float* __restrict__ rank2
     __shared__ __align__(16) float As[T_BM * H_LD];
     __shared__ __align__(16) float Bs[16 * NT * H_LD];
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int tid = threadIdx.x, wave = wave_index(), lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.x * T_BM;
     const bool vec = (K & 3) == 0;
     const int r0 = tid >> 3, c4 = (tid & 7) * 4;           // (row, 4-float column group) of a 64 x 32 slab; rows r0, r0 + 32
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void k_gemm_pow(const float* __restrict__ Hp, 
 #ifdef CCSD_EMU
     const int wave = 0, nw = 1;
 #else
-    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int wave = wave_index(), nw = blockDim.x >> 6;
 #endif
     const float* A = Hp + (size_t)b * E * E;
     const float* Bm = H1 + (size_t)b * E * E;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
     __shared__ __align__(16) float Bs[H_BK * BLD];
     {
         typedef float f32x4 __attribute__((ext_vector_type(4)));
-        const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+        const int tid = threadIdx.x, wave = wave_index(), lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
         const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
         const bool vec = (K & 3) == 0;
         // A slab 64 x 32: thread -> (row ar + 8u, column ak), u < 8 (scalar: E is not 16-byte friendly in general)

@@ -34,7 +34,7 @@ __global__ void k_normsum(const float* __restrict__ norm2, const float* __restri
 #ifdef CCSD_EMU
     for (int i = 0; i < 6; ++i) sums[i] = acc[i];
 #else
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+    const int wave = wave_index(), lane = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         float v = acc[i];
@@ -449,7 +449,7 @@ __global__ void k_rank2_cells(const float* __restrict__ rank2, int E, int K, flo
     __shared__ int s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = wave_index(), lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     int mine = 0;
     for (int wd = wave; wd < W; wd += nw) {
         const int k = 64 * wd + lane, kc = k < K ? k : K - 1;

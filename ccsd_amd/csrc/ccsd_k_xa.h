@@ -96,7 +96,11 @@ CCSD_DEV XLateOut xnet_late_stage(int stage, const PlanD& p, const float* __rest
 #ifdef CCSD_EMU
     const int lane = 0, wsz = 1;
 #else
-    const int lane = threadIdx.x & 63, wsz = 64;
+    // (opaque, as in mlp_chain_tile: otherwise the lane-dependent address arithmetic of every stage is hoisted to the head of the
+    // enclosing region of the caller and spilled there)
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const int wsz = 64;
 #endif
     const float* s_flags = sm + p.o_flags;
     const float* s_x = sm + p.o_x;
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
 #ifdef CCSD_EMU
     const int wave_id = 0, n_waves = 1;
 #else
-    const int wave_id = tid >> 6, n_waves = nth >> 6;
+    const int wave_id = wave_index(), n_waves = nth >> 6;
 #endif
 
     stamp(xa.dbg, 0);
@@ -1070,10 +1074,15 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
             if (m.chain) {
                 // symmetric input channels, masked diagonal: the E unordered pairs suffice (see the edge MLP above)
                 auto epf = [&](int e, int f, float v) { (void)f; const int i = edge_i(e), j = edge_j(e); f0[i * N + j] = v; f0[j * N + i] = v; };
+                // (the two widest shapes set the register demand of this whole region: the small-graph XA_PLAIN / XA_GMH variants leave them
+                // to k_xa<false, XA_GEN> -- xa_variant() routes such plans there -- and run without them)
+                constexpr bool WIDE = GCH || VAR == XA_GEN || VAR == XA_HB;
                 if (m.chain == 3) mlp_chain<2, 4, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
                 else if (m.chain == 4) mlp_chain<3, 5, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
-                else if (m.chain == 5) mlp_chain<3, 6, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
-                else mlp_chain<4, 7, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
+                else if constexpr (WIDE) {
+                    if (m.chain == 5) mlp_chain<3, 6, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
+                    else mlp_chain<4, 7, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
+                }
                 if (x_late && wave_id == n_waves - 1) (void)xnet_late_stage(2, p, w, wp, sm, xa, na, b);
                 stamp(xa.dbg, 11);
             } else {
@@ -1085,7 +1094,11 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
             }
             __syncthreads();
             stamp(xa.dbg, 15);
-            for (int r = tid; r < rows; r += nth) {
+            int tid_e = tid;                       // opaque: the epilogue's per-thread index arithmetic stays here instead of being
+#ifndef CCSD_EMU
+            asm volatile("" : "+v"(tid_e));        // hoisted above the MLP (and spilled across it) as an invariant of the row-chunk loop
+#endif
+            for (int r = tid_e; r < rows; r += nth) {
                 const int ij = p0 + r;
                 int i, j;
                 dN.divmod(ij, i, j);
