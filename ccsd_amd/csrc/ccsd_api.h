@@ -21,12 +21,17 @@ static inline int xa_variant(const PlanD& p) {
     // the small-graph XA_PLAIN / XA_GMH variants are compiled without the two widest final-MLP chain shapes (ccsd_k_xa.h: they cost
     // them their registers -- 30 VGPRs spilled around the final MLP of every launch); the HodgeBaseline networks need them
     if (!p.chan_global && !p.hb_L && p.a_fin.chain >= 5) return XA_GEN;
-    return p.hb_L ? XA_HB : p.x_gmh ? XA_GMH : XA_PLAIN;
+    if (p.hb_L) return XA_HB;
+    if (p.x_gmh) return XA_GMH;
+    static const bool no9 = getenv("CCSD_NO_XA9") != nullptr;     // (A/B switch: the run-time-geometry instantiation instead)
+    if (!p.chan_global && p.N == 9 && p.F == 4 && p.E == 36 && p.ldn == 16 && !no9) return XA_PLAIN9;
+    return XA_PLAIN;
 }
 static inline const void* xa_kernel(const PlanD& p) {
     const int v = xa_variant(p);
 #define XA_FN(G_) (v == XA_HB ? (const void*)k_xa<G_, XA_HB> : v == XA_GMH ? (const void*)k_xa<G_, XA_GMH> : \
                    v == XA_GEN ? (const void*)k_xa<G_, XA_GEN> : (const void*)k_xa<G_, XA_PLAIN>)
+    if (v == XA_PLAIN9) return (const void*)k_xa<false, XA_PLAIN9>;
     return p.chan_global ? XA_FN(true) : XA_FN(false);
 #undef XA_FN
 }
@@ -138,7 +143,15 @@ static inline void r2_shape(const ccsd_plan* pl, int* MT, int* RS, bool* aff, bo
         else R2_CASE(1, 0, X) else R2_CASE(1, 1, X) else R2_CASE(1, 2, X) else R2_CASE(1, 3, X) \
         else R2_CASE(2, 2, X) else R2_CASE(2, 3, X) else R2_CASE(3, 0, X) else R2_CASE(3, 1, X) else R2_CASE(4, 2, X) \
     } while (0)
+// the instance with the qm9 geometry compiled in (k_r2<3, 1, true, false, true>) serves exactly that geometry
+static inline bool r2_qm9(const ccsd_plan* pl) {
+    static const bool off = getenv("CCSD_NO_R2Q") != nullptr;      // (A/B switch: the run-time-geometry instantiation instead)
+    const PlanD& p = pl->h;
+    const bool gen1 = p.h_L > 1 && p.hl[0].mval.n > 1;
+    return !off && p.f_affine && !gen1 && p.E == 36 && p.K == 466 && p.N == 9 && pl->r2_ldk == 488 && pl->r2_ldh == 36;
+}
 static inline const void* r2_kernel(const ccsd_plan* pl) {
+    if (r2_qm9(pl)) return (const void*)k_r2<3, 1, true, false, true>;
     const void* fn = nullptr;
 #define R2_PTR(MT_, RS_, A_, G_) fn = (const void*)k_r2<MT_, RS_, A_, G_>
     R2_DISPATCH(pl, R2_PTR);
@@ -518,6 +531,7 @@ static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Work
         if (variant == XA_HB) XA_GO(false, XA_HB, xa, xblk, xlds, stream);
         else if (variant == XA_GMH) XA_GO(false, XA_GMH, xa, xblk, xlds, stream);
         else if (variant == XA_GEN) XA_GO(false, XA_GEN, xa, xblk, xlds, stream);
+        else if (variant == XA_PLAIN9) XA_GO(false, XA_PLAIN9, xa, xblk, xlds, stream);
         else XA_GO(false, XA_PLAIN, xa, xblk, xlds, stream);
     }
 #undef XA_GO
@@ -585,6 +599,10 @@ static int launch_r2(const ccsd_plan* pl, int B, const float* rank2, const float
 #define R2_GO(MT_, RS_, A_, G_) \
     CCSD_LAUNCH((k_r2<MT_, RS_, A_, G_>), dim3(B), blk, pl->r2_lds, stream, (const PlanD*)pl->d, (const float*)pl->w, \
                 (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, ra, ep, na)
+    if (r2_qm9(pl)) {
+        CCSD_LAUNCH((k_r2<3, 1, true, false, true>), dim3(B), blk, pl->r2_lds, stream, (const PlanD*)pl->d, (const float*)pl->w,
+                    (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, ra, ep, na);
+    } else
     R2_DISPATCH(pl, R2_GO);
 #undef R2_GO
     prof_mark(const_cast<ccsd_plan*>(pl), KID_R2, stream);

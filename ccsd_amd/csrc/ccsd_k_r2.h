@@ -38,14 +38,16 @@ struct R2Args {
 // lane l = 16 kc + 4 cg + j takes strip row (l & 3) as A and column 4 cg + j as B of the block (column group cg, k class kc),
 // i.e. 4 rows x 16 columns x 4 k values per instruction -- the SAME operand addresses as the 16x16x4 tile code (B operand of
 // column l & 15, k slot group l >> 4), only the A row differs; the four k classes are summed with two lane swaps.
-template <int MT, int RS, bool AFFINE, bool GEN1>
+// QM9: the qm9 geometry (E = 36, K = 466, N = 9, LDS strides 488 / 36) as compile-time constants: the index arithmetic on these
+// strides folds into immediates (as k_xa<false, XA_PLAIN9>); the host selects the instance only when the plan matches (r2_qm9()).
+template <int MT, int RS, bool AFFINE, bool GEN1, bool QM9 = false>
 __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, const float* __restrict__ w,
                                             const unsigned char* __restrict__ edges,
                                             const unsigned long long* __restrict__ cells, R2Args ra, RankEpi ep,
                                             NoiseArgs na) {
     CCSD_DYN_SMEM(sm);
     const PlanD& p = *plan;
-    const int E = p.E, K = p.K, N = p.N, NN = N * N, ldk = ra.ldk, ldh = ra.ldh;
+    const int E = QM9 ? 36 : p.E, K = QM9 ? 466 : p.K, N = QM9 ? 9 : p.N, NN = N * N, ldk = QM9 ? 488 : ra.ldk, ldh = QM9 ? 36 : ra.ldh;
     const int b = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
     const int Kp4 = (K + 31) & ~31, Ep4 = (E + 3) & ~3;   // K is zero-padded to whole 8-step batches in LDS
     float* sF = sm;                        // [E][ldk]

@@ -9,6 +9,7 @@
 #define XA_PLAIN 0
 #define XA_HB 1
 #define XA_GMH 2
+#define XA_PLAIN9 4       /* XA_PLAIN with the qm9 geometry compiled in: N = 9, E = 36, F = 4, ldn = 16 (index arithmetic folds to constants) */
 #define XA_GEN 3          /* everything, selected at run time from the plan: both of the above together, conv = "MLP" */
 struct XaArgs {
     // inputs: the X-network and the A-network may see different (x, adj) when the Langevin
@@ -89,10 +90,11 @@ CCSD_DEV void xlate_wave_sync() {
     __builtin_amdgcn_wave_barrier();
 #endif
 }
+template <bool NFIX = false>     // NFIX: the qm9 geometry as compile-time constants (k_xa<false, XA_PLAIN9>)
 CCSD_DEV XLateOut xnet_late_stage(int stage, const PlanD& p, const float* __restrict__ w, const float* __restrict__ wp, float* sm,
                                   const XaArgs& xa, const NoiseArgs& na, int b) {
     XLateOut r{0.f, 0.f};
-    const int N = p.N, F = p.F, ldn = p.ldn, H = p.x_nhid;
+    const int N = NFIX ? 9 : p.N, F = NFIX ? 4 : p.F, ldn = NFIX ? 16 : p.ldn, H = p.x_nhid;
 #ifdef CCSD_EMU
     const int lane = 0, wsz = 1;
 #else
@@ -176,7 +178,10 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
     CCSD_DYN_SMEM(sm);
     const PlanD& p = *plan;
     constexpr bool HB = VAR == XA_HB || VAR == XA_GEN, GMH = VAR == XA_GMH || VAR == XA_GEN, CONVMLP = VAR == XA_GEN;
-    const int N = p.N, F = p.F, NN = N * N, E = p.E, ldn = p.ldn;
+    // XA_PLAIN9: a third of k_xa's vector instructions are 32-bit integer index arithmetic on strides the plan supplies at run
+    // time (PMC, profiles/r03_c_phase_mix.txt); for the headline geometry they are compile-time constants (xa_variant() checks them)
+    constexpr bool NFIX = VAR == XA_PLAIN9;
+    const int N = NFIX ? 9 : p.N, F = NFIX ? 4 : p.F, NN = N * N, E = NFIX ? 36 : p.E, ldn = NFIX ? 16 : p.ldn;
     const int b = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
     float* s_flags = sm + p.o_flags;
     float* s_x = sm + p.o_x;
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
 
     // ================= ScoreNetworkX (ScoreNetwork_X.py:102-132) =================
     // (see xnet_late_stage) both networks on the same inputs, plan permitting: only the input load + fused corrector stay here
-    const bool x_late = VAR == XA_PLAIN && !GCH && p.x_late && xa.do_x && xa.do_a && xa.xA == xa.xX && xa.adjA == xa.adjX;
+    const bool x_late = (VAR == XA_PLAIN || VAR == XA_PLAIN9) && !GCH && p.x_late && xa.do_x && xa.do_a && xa.xA == xa.xX && xa.adjA == xa.adjX;
     if (x_late) {
         for (int i = tid; i < N * F; i += nth) s_x[i] = xa.xX[(size_t)b * N * F + i];
         for (int i = tid; i < NN; i += nth) s_adj[i] = xa.adjX[(size_t)b * NN + i];
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
 #define ATTN_TAP(l) prio_phase(prio_k++)
 #define ATTN_MID(l) prio_phase(prio_k++)
 #define ATTN_IDLE(l)                                                                                  \
-    if (x_late && (l) < 2 && wave_id == n_waves - 1) (void)xnet_late_stage((l), p, w, wp, sm, xa, na, b);   \
+    if (x_late && (l) < 2 && wave_id == n_waves - 1) (void)xnet_late_stage<NFIX>((l), p, w, wp, sm, xa, na, b);   \
     if (hodge_idle && (l) == 2 && wave_id == n_waves - 1) hodge_early(tid - wave_id * (nth / n_waves), nth / n_waves);
 #include "ccsd_attn_stack.inc"
 #undef ATTN_LAYERS
@@ -1083,7 +1088,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                     if (m.chain == 5) mlp_chain<3, 6, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
                     else mlp_chain<4, 7, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
                 }
-                if (x_late && wave_id == n_waves - 1) (void)xnet_late_stage(2, p, w, wp, sm, xa, na, b);
+                if (x_late && wave_id == n_waves - 1) (void)xnet_late_stage<NFIX>(2, p, w, wp, sm, xa, na, b);
                 stamp(xa.dbg, 11);
             } else {
                 block_linear<1>(f0, ldf, s_chan + p0, NN, s_chan + p0, m.in, wf + m.w[0], wf + m.b[0], m.in, m.hid, rows);
@@ -1121,7 +1126,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                 }
             }
             if (x_late && wave_id == (n_waves > 1 ? n_waves - 2 : 0)) {      // (the wave with the least of the A-network's epilogue)
-                const XLateOut xr = xnet_late_stage(3, p, w, wp, sm, xa, na, b);
+                const XLateOut xr = xnet_late_stage<NFIX>(3, p, w, wp, sm, xa, na, b);
                 nx_net += xr.n2; nx_z += xr.z2;
             }
             __syncthreads();

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 # stamps every thread of the workgroup reaches, in program order (k_xa: slots of ccsd_k_xa.h / ccsd_attn_stack.inc; k_r2: ccsd_k_r2.h)
 XA_STOPS = [(1, "X-net"), (2, "-> L0 start"), (3, "L0 gcn/att"), (4, "L0 edge MLP"), (5, "-> L1 start"), (6, "L1 gcn/att"), (7, "L1 edge MLP"),
             (8, "-> L2 start"), (9, "L2 gcn/att"), (10, "L2 edge MLP"), (12, "-> hodge start"), (13, "hodge branch"), (15, "final MLP chain"), (14, "epilogue")]
-R2_STOPS = [(1, "block load"), (2, "tables/prep"), (3, "phase 1 (H, P tiles)"), (4, "phase 2 (HF tiles + epilogue)"), (5, "store")]
+R2_STOPS = [(8, "mask tables + first batch issued"), (9, "block load loop"), (1, "(adjacency powers) + barrier"), (2, "tables/prep"), (3, "phase 1 (H, P tiles)"), (4, "phase 2 (HF tiles + epilogue)"), (5, "store")]
 
 ABLATIONS = [(0, "full predictor launch"), (1, "- projection k loops"), (2, "- H k loops"), (8, "- noise in the epilogue"), (4, "- column-tile epilogue"),
              (16, "- column tiles"), (1 | 2 | 16, "- all tiles: load + tables + store left")]
