@@ -23,8 +23,7 @@ static inline int xa_variant(const PlanD& p) {
     if (!p.chan_global && !p.hb_L && p.a_fin.chain >= 5) return XA_GEN;
     if (p.hb_L) return XA_HB;
     if (p.x_gmh) return XA_GMH;
-    static const bool no9 = getenv("CCSD_NO_XA9") != nullptr;     // (A/B switch: the run-time-geometry instantiation instead)
-    if (!p.chan_global && p.N == 9 && p.F == 4 && p.E == 36 && p.ldn == 16 && !no9) return XA_PLAIN9;
+    if (!p.chan_global && p.N == 9 && p.F == 4 && p.E == 36 && p.ldn == 16 && !p.geo_off) return XA_PLAIN9;
     return XA_PLAIN;
 }
 static inline const void* xa_kernel(const PlanD& p) {
@@ -145,10 +144,9 @@ static inline void r2_shape(const ccsd_plan* pl, int* MT, int* RS, bool* aff, bo
     } while (0)
 // the instance with the qm9 geometry compiled in (k_r2<3, 1, true, false, true>) serves exactly that geometry
 static inline bool r2_qm9(const ccsd_plan* pl) {
-    static const bool off = getenv("CCSD_NO_R2Q") != nullptr;      // (A/B switch: the run-time-geometry instantiation instead)
     const PlanD& p = pl->h;
     const bool gen1 = p.h_L > 1 && p.hl[0].mval.n > 1;
-    return !off && p.f_affine && !gen1 && p.E == 36 && p.K == 466 && p.N == 9 && pl->r2_ldk == 488 && pl->r2_ldh == 36;
+    return !p.geo_off && p.f_affine && !gen1 && p.E == 36 && p.K == 466 && p.N == 9 && pl->r2_ldk == 488 && pl->r2_ldh == 36;
 }
 static inline const void* r2_kernel(const ccsd_plan* pl) {
     if (r2_qm9(pl)) return (const void*)k_r2<3, 1, true, false, true>;
@@ -244,6 +242,7 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     PlanBuilder pb;
     pl->nweights = ccsd_build_plan(cfg, &pl->h, pb);
     if (pb.status != CCSD_OK) { delete pl; return set_err(pb.status, pb.err); }
+    pl->h.geo_off = getenv("CCSD_NO_GEO") != nullptr;
     pl->npacked = (size_t)pb.pcur;
     if (pl->nweights != n_weights) {
         delete pl;
@@ -358,6 +357,8 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
 #ifndef CCSD_EMU
     if ((size_t)pl->h.xa_lds_floats * 4 > 64 * 1024)
         PC(rt_set_max_dyn_smem(xa_kernel(pl->h), (size_t)pl->h.xa_lds_floats * 4));
+        if (xa_variant(pl->h) == XA_PLAIN9)     // (its run-time-geometry twin serves launches with a diagnostic thread count)
+            PC(rt_set_max_dyn_smem((const void*)k_xa<false, XA_PLAIN>, (size_t)pl->h.xa_lds_floats * 4));
     if (pl->fused_r2 && pl->r2_lds > 64 * 1024) {
         PC(rt_set_max_dyn_smem(r2_kernel(pl), pl->r2_lds));
     }
@@ -521,7 +522,8 @@ static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Work
     const size_t xlds = (size_t)pl->h.xa_lds_floats * 4;
 #define XA_GO(G_, V_, XA_, BLK_, LDS_, STR_) CCSD_LAUNCH((k_xa<G_, V_>), dim3(B), BLK_, LDS_, STR_, (const PlanD*)pl->d, (const float*)pl->w, \
                                                          (const unsigned char*)pl->edges, XA_, na)
-    const int variant = xa_variant(pl->h);
+    int variant = xa_variant(pl->h);
+    if (variant == XA_PLAIN9 && xa_threads != 256) variant = XA_PLAIN;      // (XA_PLAIN9 has its 256 threads compiled in)
     if (pl->h.chan_global) {
         if (variant == XA_HB) XA_GO(true, XA_HB, xa, xblk, xlds, stream);
         else if (variant == XA_GMH) XA_GO(true, XA_GMH, xa, xblk, xlds, stream);

@@ -182,7 +182,10 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
     // time (PMC, profiles/r03_c_phase_mix.txt); for the headline geometry they are compile-time constants (xa_variant() checks them)
     constexpr bool NFIX = VAR == XA_PLAIN9;
     const int N = NFIX ? 9 : p.N, F = NFIX ? 4 : p.F, NN = N * N, E = NFIX ? 36 : p.E, ldn = NFIX ? 16 : p.ldn;
-    const int b = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+#ifndef CCSD_EMU
+    if (NFIX) __builtin_assume(blockDim.x == 256);     // (launch_xa starts XA_PLAIN9 with 256 threads only)
+#endif
+    const int b = blockIdx.x, tid = threadIdx.x, nth = (NFIX && CCSD_NTHREADS != 1) ? 256 : blockDim.x;
     float* s_flags = sm + p.o_flags;
     float* s_x = sm + p.o_x;
     float* s_adj = sm + p.o_adj;

@@ -4,6 +4,7 @@ the C ABI; `lib`/`device` select the backend: the HIP library on cuda:0, or the 
 same kernel source on cpu."""
 import contextlib
 import json
+import os
 
 import numpy as np
 import torch
@@ -797,3 +798,43 @@ def case_kat_hodge_layers(lib, device):
         want = ofn(*nets, flags)
     for p, g_, w_ in zip(names, got, want):
         assert_close(g_, w_, f"three hodge layers, Reverse + Langevin n_steps=2, {p}")
+
+
+def case_geometry_instances_bitwise(lib, device, B=64, steps=3):
+    """The instances of k_xa / k_r2 with the qm9 geometry compiled in (N = 9, E = 36, K = 466, the LDS strides: ccsd_k_xa.h XA_PLAIN9,
+    ccsd_k_r2.h QM9) against the run-time-geometry instances of the same kernels (a plan created with CCSD_NO_GEO set): the same
+    arithmetic in the same order -- only index computations fold -- so the production loop must agree BIT FOR BIT, and so must the
+    three scores.  Also checks that the qm9 plan really selects the specialised instances."""
+    meta, parts = load_ckpt_np("ccsd_qm9_CC")
+    cfg = meta["config"]
+    N, Fd = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
+    d_min, d_max = cfg["data"]["d_min"], cfg["data"]["d_max"]
+    flags = make_flags(B, N, [9, 9, 8, 7, 9, 5, 9, 3, 6, 9, 2, 9]).to(device)
+    kw = dict(shape_x=(B, N, Fd), shape_adj=(B, N, N), predictor="Reverse", corrector="Langevin", snr=0.2, scale_eps=0.7, n_steps=1,
+              probability_flow=False, continuous=True, denoise=True, eps=1e-4, is_cc=True, shape_rank2=(B, *rank2_dim(N, d_min, d_max)),
+              d_min=d_min, d_max=d_max)
+    sd = [loader.load_sde(cfg["sde"][p]) for p in ("x", "adj", "rank2")]
+    ms = [loader.load_model_from_ckpt(meta[f"params_{p}"], parts[p], device) for p in ("x", "adj", "rank2")]
+    outs, variants = [], []
+    old = os.environ.pop("CCSD_NO_GEO", None)
+    try:
+        for off in (False, True):
+            if off:
+                os.environ["CCSD_NO_GEO"] = "1"
+            fn = solver.get_pc_sampler(device=device, rng="philox", seed=11, max_steps=steps, lib=lib, sde_x=sd[0], sde_adj=sd[1], sde_rank2=sd[2], **kw)
+            res = fn(*ms, flags)
+            eng = fn.engine()
+            variants.append(eng.query("xa_variant"))
+            st = eng.alloc_state(B)
+            eng.init_state(flags, st, None, 3, 0)
+            scores = [eng.score(t, st[0], st[1], st[2], flags).clone() for t in range(3)]
+            outs.append([r.clone() for r in res[:3]] + scores)
+            os.environ.pop("CCSD_NO_GEO", None)
+    finally:
+        os.environ.pop("CCSD_NO_GEO", None)
+        if old is not None:
+            os.environ["CCSD_NO_GEO"] = old
+    if device != "cpu":
+        assert variants == [4, 0], f"k_xa variants selected: {variants} (expected the qm9-geometry instance, then the plain one)"
+    for k, (a, b) in enumerate(zip(*outs)):
+        assert torch.equal(a, b), f"tensor {k}: compile-time-geometry instance != run-time-geometry instance (max diff {(a - b).abs().max().item():.3e})"

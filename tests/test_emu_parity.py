@@ -154,3 +154,8 @@ def test_fused_r2_serves_nonaffine_shapes(lib):
 
 def test_zinc5b_production_loop_vs_oracle(lib):
     pc.case_zinc5b_production_loop(lib, DEV)
+
+
+def test_geometry_switch_is_inert_on_the_emulation(lib):
+    """CPU twin of the GPU test: the CCSD_NO_GEO plan option changes nothing in the results (the emulation compiles both forms too)."""
+    pc.case_geometry_instances_bitwise(lib, DEV, B=6, steps=2)

@@ -333,3 +333,8 @@ def test_rccl_single_rank_group(lib):
 
 def test_zinc5b_production_loop_vs_oracle(lib):
     pc.case_zinc5b_production_loop(lib, DEV)
+
+
+def test_geometry_instances_match_runtime_geometry_bitwise(lib):
+    """k_xa<false, XA_PLAIN9> / k_r2<3, 1, true, false, QM9> == the run-time-geometry instances, bit for bit (production loop + scores)."""
+    pc.case_geometry_instances_bitwise(lib, DEV)
