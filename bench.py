@@ -74,9 +74,13 @@ WORKLOADS = {
 # issue (on gfx950 an fp32 MFMA and VALU work share the SIMD's vector pipe), reported as `issue_frac`.
 KERNEL_BOUND = {"k_xa": "mfma", "k_r2": "mfma", "k_hf_score": "hbm", "k_gemm_h": "mfma", "k_gemm_p": "mfma", "k_langevin_apply": "hbm",
                 "k_s4_apply": "hbm", "k_ew1": "hbm"}
-KERNEL_LIMITER = {"k_r2": "vector-instruction issue: fp32 MFMA (32 cycles each) and VALU (2 cycles each) share one pipe per SIMD",
+KERNEL_LIMITER = {"k_r2": "vector-instruction issue: fp32 MFMA (32 cycles each) and VALU (>= 2.65 cycles each at 4 waves / SIMD) share one pipe per SIMD",
                   "k_xa": "latency of one graph's critical path (barrier intervals), then vector-instruction issue"}
 N_SIMDS, MAX_CLOCK_HZ = 1024, 2.4e9                       # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md chip table
+# cycles one wave64 VALU instruction occupies a SIMD that holds 4 waves (both kernels run at 4 waves / SIMD), measured:
+# tools/ubench/valu_rate.hip, profiles/r03_c_valu_rate.txt -- v_fma_f32 2.65, v_xor_b32 2.47, 32-bit integer multiplies 4.4,
+# transcendentals 8.3; the plain-FMA figure is used for every instruction, so issue_frac is a lower bound
+VALU_ISSUE_CYCLES = 2.65
 KERNEL_NAMES = ["k_xa", "k_r2", "k_hf_score", "k_gemm_h", "k_gemm_p", "k_langevin_apply", "k_s4_apply", "k_ew1"]
 PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json")]   # newest first
 KERNEL_SOURCES = [os.path.join(ROOT, "ccsd_amd", "csrc", f) for f in ("ccsd_dev.h", "ccsd_rank2_common.h", "ccsd_k_rank2.h", "ccsd_k_r2.h", "ccsd_k_xa.h", "ccsd_k_update.h", "ccsd_attn_stack.inc", "ccsd_plan.h", "ccsd_api.h")]
@@ -283,9 +287,10 @@ def roofline_obj(wname, kname, kt, B, dt, E, K):
             o["executed_frac"] = ex / PEAK_F32_MFMA_TFLOPS       # what the matrix pipe actually did (dead GEMMs skipped, padding included)
             va = c.get("SQ_INSTS_VALU")
             if va:
-                # vector-issue cycles per launch: 32 per fp32 16x16x4 MFMA + 2 per other VALU wave-instruction (SQ_INSTS_VALU counts
-                # the MFMAs too), over what 1024 SIMDs offer at the 2.4 GHz maximum clock in the launch's time
-                cyc = mf * 32.0 + max(va - mf, 0.0) * 2.0
+                # vector-issue cycles per launch: the matrix instructions' busy cycles (PMC; 32 per fp32 16x16x4 MFMA, 8.8 per 4x4x1)
+                # + VALU_ISSUE_CYCLES per other VALU wave-instruction (SQ_INSTS_VALU counts the MFMAs too), over what 1024 SIMDs offer
+                # at the 2.4 GHz maximum clock in the launch's time
+                cyc = (c.get("SQ_VALU_MFMA_BUSY_CYCLES") or mf * 32.0) + max(va - mf, 0.0) * VALU_ISSUE_CYCLES
                 o["issue_cycles_per_launch"] = cyc
                 o["issue_frac"] = cyc / (N_SIMDS * MAX_CLOCK_HZ * avg_s)
     if bound == "mfma" and flops:
