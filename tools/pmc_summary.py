@@ -1,4 +1,6 @@
-"""Per-kernel means of rocprofv3 --pmc counters: python tools/pmc_summary.py <dir with *_counter_collection.csv> [...]"""
+"""Per-kernel MEDIANS over the dispatches of rocprofv3 --pmc counters: python tools/pmc_summary.py <dir with *_counter_collection.csv> [...]
+(median, not mean: a sampler call launches k_r2 as norms-only, merged ... merged, predictor-only -- the median is the merged launch the
+bench line's launch time belongs to; for k_xa the norms and predictor launches differ by a few percent either way)"""
 import csv, glob, sys, collections, json, os
 
 out = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -13,5 +15,5 @@ for d in sys.argv[1:]:
             per[(k, r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
         for (k, _, c), v in per.items():
             out[k][c].append(v)
-res = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in out.items()}
+res = {k: {c: sorted(v)[len(v) // 2] for c, v in cs.items()} for k, cs in out.items()}
 print(json.dumps(res, indent=1))

@@ -1,5 +1,5 @@
 """profiles/<round>_pmc.json from the rocprofv3 --pmc passes of tools/pmc_run.sh:  python tools/pmc_traffic.py <round> <tag> [<tag> ...]
-Per-launch means for k_r2 / k_xa; HBM bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (gfx950 reports half of a wide coalesced
+Per-launch medians for k_r2 / k_xa (k_r2: the merged launch); HBM bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (gfx950 reports half of a wide coalesced
 read in FETCH_SIZE -- MI355X_MICROARCH.md, HBM / rocprofv3 section; WRITE_SIZE as is).  `_meta` records the commit and the
 hash of the kernel sources the passes ran on: bench.py replays these counters in its roofline objects and marks them stale
 when the sources have changed since."""
@@ -26,7 +26,7 @@ try:
 except Exception:
     commit = os.environ.get("CCSD_COMMIT", "unknown")
 out["_meta"] = {"workload": "qm9_CC", "commit": commit, "kernel_src_sha16": bench.kernel_source_hash(),
-                "note": "means over the launches of a 10-step bench run (bench.py --steps 10 --warmup 2); hbm_bytes = 2*FETCH_SIZE*1024 + "
+                "note": "medians over the launches of a 10-step bench run (bench.py --steps 10 --warmup 2); hbm_bytes = 2*FETCH_SIZE*1024 + "
                         "WRITE_SIZE*1024 (gfx950 FETCH_SIZE half-count correction, MI355X_MICROARCH.md); separate --pmc passes"}
 json.dump(out, open(os.path.join(root, "profiles", f"{rnd}_pmc.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
