@@ -371,6 +371,8 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
 // ---------------- workspace ----------------
 struct Workspace {
     unsigned long long* offbits;
+    unsigned char *mfr, *mfl;       // flag masks of every complex as byte tables (k_masktab): [B][Kp], [B][Ep]
+    int Kp, Ep;
     float *H, *P0, *P1, *U1, *acoef, *net_x, *net_adj, *net_r, *norm2, *part, *sums, *chan, *zpart, *part2;
     float *P0b, *P1b, *U1b;         // second set of hodge projections (merged k_r2 launch: the next norms pass's)
     int ntiles, nchunk;
@@ -384,6 +386,9 @@ static Workspace carve_ws(const ccsd_plan* pl, int B, void* base) {
     auto take = [&](size_t nbytes) { size_t r = o; o += (nbytes + 255) / 256 * 256; return base ? (char*)base + r : (char*)nullptr; };
     w.offbits = (unsigned long long*)take((size_t)B * 8);
     const size_t E = p.E, K = p.K;
+    w.Kp = p.is_cc ? (p.K + 3) & ~3 : 0; w.Ep = p.is_cc ? (p.E + 3) & ~3 : 0;
+    w.mfr = (unsigned char*)take((size_t)B * w.Kp);
+    w.mfl = (unsigned char*)take((size_t)B * w.Ep);
     w.H = (float*)take(p.is_cc ? (size_t)B * E * E * 4 * (p.f_cnum > 2 ? p.f_cnum - 1 : 1) : 0);   // H, H^2, ... (cnum > 2: one slab per power)
     w.P0 = (float*)take(p.h_L > 0 ? (size_t)B * E * p.hl[0].wc * 4 : 0);
     w.P1 = (float*)take(p.h_L > 1 ? (size_t)B * E * p.h_pw * 4 : 0);
@@ -434,6 +439,12 @@ static int check_state(const ccsd_plan* pl, const ccsd_state_t* s, const char* w
 static int launch_flagbits(const ccsd_plan* pl, int B, const float* flags, Workspace& w, void* stream) {
     CCSD_LAUNCH(k_flagbits, dim3(grid_for(B, 256)), dim3(CCSD_NTHREADS), 0, stream, flags, w.offbits, B, pl->h.N);
     LAUNCH_CHECK();
+    if (pl->h.is_cc) {      // (consumers: k_ew1, k_langevin_apply, k_noise_norm; the fused rank-2 kernel builds its own masks in LDS)
+        CCSD_LAUNCH(k_masktab, dim3(grid_for((long long)B * (w.Kp + w.Ep), 256)), dim3(CCSD_NTHREADS), 0, stream,
+                    (const unsigned long long*)w.offbits, (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, w.mfr, w.mfl,
+                    B, pl->h.E, pl->h.K, w.Kp, w.Ep);
+        LAUNCH_CHECK();
+    }
     return CCSD_OK;
 }
 
@@ -546,7 +557,7 @@ static int launch_hf(const ccsd_plan* pl, int B, const float* rank2, RankEpi& ep
     dim3 g(xcd_grid(B, ((p.K + T_BN - 1) / T_BN) * ((p.E + T_BM - 1) / T_BM)));
     prof_mark(const_cast<ccsd_plan*>(pl), KID_HF, stream);
 #define HF_ARGS (const PlanD*)pl->d, (const float*)pl->w, rank2, (const float*)w.H, (const unsigned long long*)w.offbits, \
-                (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, ep, na, B
+                (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, ep, na, B, (MaskTab{w.mfr, w.mfl, w.Kp, w.Ep})
     const int fw = fnet_width(p);
 #define HF_GO(NP_) \
     do { \
@@ -573,10 +584,9 @@ static int launch_ew1(const ccsd_plan* pl, int B, const float* rank2, RankEpi& e
     a.mode = ep.mode; a.apply = (cf && cf->on) ? 1 : 0;
     a.sscale = ep.sscale; a.pa = ep.pa; a.pb = ep.pb; a.pc = ep.pc; a.alpha = p.f_alpha; a.gamma = p.f_gamma;
     if (a.apply) { a.sums = cf->sums; a.ss = cf->ss[2]; a.sde_alpha = cf->alpha[2]; a.snr = cf->snr; a.seps = cf->seps; a.draw_corr = cf->draw_r; }
-    a.E = p.E; a.K = p.K;
+    a.E = p.E; a.K = p.K; a.mt = MaskTab{w.mfr, w.mfl, w.Kp, w.Ep};
     prof_mark(const_cast<ccsd_plan*>(pl), KID_EW1, stream);
-    CCSD_LAUNCH(k_ew1, dim3(w.nchunk, B), dim3(CCSD_NTHREADS), 0, stream, a, na, (const unsigned long long*)w.offbits,
-                (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells);
+    CCSD_LAUNCH(k_ew1, dim3(w.nchunk, B), dim3(CCSD_NTHREADS), 0, stream, a, na);
     prof_mark(const_cast<ccsd_plan*>(pl), KID_EW1, stream);
     LAUNCH_CHECK();
     return CCSD_OK;
@@ -787,8 +797,7 @@ static int corrector_norms(ccsd_plan* pl, int B, int step, int it, const ccsd_st
         // k_hf_score and its chunk partials are reduced per sample first (one workgroup per sample), then over the batch
         const bool zk = na.flat_r && !na.zr && !pl->ew1;
         if (zk) {
-            CCSD_LAUNCH(k_noise_norm, dim3(w.nchunk, B), dim3(CCSD_NTHREADS), 0, stream, na, (const unsigned long long*)w.offbits,
-                        (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, p.E, p.K, w.zpart);
+            CCSD_LAUNCH(k_noise_norm, dim3(w.nchunk, B), dim3(CCSD_NTHREADS), 0, stream, na, (MaskTab{w.mfr, w.mfl, w.Kp, w.Ep}), p.E, p.K, w.zpart);
             LAUNCH_CHECK();
         }
         if (zk || ntiles > 8) {
@@ -821,8 +830,7 @@ static int corrector_apply(ccsd_plan* pl, int B, int step, int it, const ccsd_st
     a.B = B; a.N = p.N; a.F = p.F; a.E = p.E; a.K = p.K; a.is_cc = p.is_cc;
     const long long total = (long long)B * (p.N * p.F + p.N * p.N) + (p.is_cc ? (long long)B * (((long long)p.E * p.K + 3) / 4) : 0);
     prof_mark(pl, KID_LANGEVIN, stream);
-    CCSD_LAUNCH(k_langevin_apply, dim3(grid_for(total, 256)), dim3(CCSD_NTHREADS), 0, stream, a, na,
-                (const unsigned long long*)w.offbits, (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells);
+    CCSD_LAUNCH(k_langevin_apply, dim3(grid_for(total, 256)), dim3(CCSD_NTHREADS), 0, stream, a, na, (MaskTab{w.mfr, w.mfl, w.Kp, w.Ep}));
     prof_mark(pl, KID_LANGEVIN, stream);
     LAUNCH_CHECK();
     return CCSD_OK;

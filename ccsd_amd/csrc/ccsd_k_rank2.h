@@ -15,6 +15,24 @@ __global__ void k_flagbits(const float* __restrict__ flags, unsigned long long* 
         offbits[b] = m;
     }
 }
+// k_masktab: the two flag masks of every complex as BYTE tables in the workspace -- mfr[b][k] = flags_right (cell k switched on),
+// mfl[b][e] = flags_left (edge e switched on); get_rank2_flags, cc_utils.py:527-591.  The element-wise kernels of the general path
+// (k_ew1, k_langevin_apply, k_noise_norm) then read one 32-bit word of mfr per 16-byte group of rank2 and one byte of mfl instead of
+// an 8-byte cell word and two edge-table bytes PER ELEMENT.  Rows are padded to multiples of 4 (Kp, Ep), padding = 0.
+__global__ void k_masktab(const unsigned long long* __restrict__ offbits, const unsigned char* __restrict__ edges,
+                          const unsigned long long* __restrict__ cells, unsigned char* __restrict__ mfr, unsigned char* __restrict__ mfl,
+                          int B, int E, int K, int Kp, int Ep) {
+    const long long per = Kp + Ep, n = (long long)B * per;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(t / per), r = (int)(t - (long long)b * per);
+        const unsigned long long off = offbits[b];
+        if (r < Kp) mfr[(size_t)b * Kp + r] = (r < K && !(cells[r] & off)) ? 1 : 0;
+        else {
+            const int e = r - Kp;
+            mfl[(size_t)b * Ep + e] = (e < E && !(((off >> edges[2 * e]) | (off >> edges[2 * e + 1])) & 1ull)) ? 1 : 0;
+        }
+    }
+}
 // Tiles of the tiled rank-2 kernels are numbered so that ALL tiles of one complex run on ONE XCD: workgroups are dealt round-robin
 // over the 8 XCDs (linear block id mod 8), each with its own 4 MB L2, and the tiles of a complex share its operands (k_gemm_h:
 // every 64-row slab of F feeds 3-4 tiles; k_hf_score: every row tile of a column block reads the same E x 64 slab of F, every
@@ -333,7 +351,7 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
                                                   const unsigned long long* __restrict__ offbits,
                                                   const unsigned char* __restrict__ edges,
                                                   const unsigned long long* __restrict__ cells, RankEpi ep,
-                                                  NoiseArgs na, int B) {
+                                                  NoiseArgs na, int B, MaskTab mt) {
     __shared__ float red[64];
     const PlanD& p = *plan;
     const int E = p.E, K = p.K;
@@ -441,13 +459,15 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
     }
 #endif
     }
-    const unsigned long long off = offbits[b];
+    const unsigned char* const frb = mt.mfr + (size_t)b * mt.Kp;      // mask byte tables of this complex (k_masktab)
+    const unsigned char* const flb = mt.mfl + (size_t)b * mt.Ep;
     float s_net = 0.f, s_z = 0.f;
     const bool znorm = !na.flat_r || na.zr != nullptr;   // host-supplied draws are read per element, whatever the group layout
     tile_foreach4n<NP>(accs, [&](int ml, int nl, const float (*hfp)[4]) {
         const int k = n0 + nl, e0 = m0 + ml;
         if (k >= K || e0 >= E) return;
-        const float fr = cell_on(off, cells, k);
+        const float fr = (float)frb[k];
+        const unsigned fl4 = *reinterpret_cast<const unsigned*>(flb + e0);     // e0 is a multiple of 4, rows are padded to Ep
         float z[4] = {0.f, 0.f, 0.f, 0.f};
         // (norms launch of a flat-keyed corrector draw with in-kernel Philox: its noise norm comes from k_noise_norm)
         if (ep.mode == MODE_PRED || (ep.mode == MODE_NORMS && znorm)) raw_noise_r4(na, b, e0 >> 2, k, E, K, z);
@@ -457,7 +477,7 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
             if (e >= E) continue;
             const size_t gi = ((size_t)b * E + e) * K + k;
             const float f = Fb[(size_t)e * K + k];
-            const float m = edge_on(off, edges, e) * fr;          // flags_left * flags_right, cc_utils.py:590
+            const float m = (float)((fl4 >> (8 * s)) & 0xffu) * fr;          // flags_left * flags_right, cc_utils.py:590
             const float hf[CCSD_MAXCN - 1] = {hfp[0][s], NP > 1 ? hfp[NP > 1 ? 1 : 0][s] : 0.f, NP > 2 ? hfp[NP > 2 ? 2 : 0][s] : 0.f};
             const float net = fnet_element<AFFINE, FW>(p, w, f, hf, m);
             const float zz = z[s] * m;                            // gen_noise_rank2, cc_utils.py:613-615

@@ -76,11 +76,9 @@ __global__ void k_normpart(const float* __restrict__ part, int ntiles, const flo
 // cheaply; pure arithmetic, no rank2 traffic).  zpart[b][chunk] = sum over the chunk's groups of (z fl fr)^2
 // (gen_noise_rank2 + torch.norm, cc_utils.py:613-615, solver.py:793-797).  grid (nchunk, B); CH groups per workgroup.
 #define CCSD_NN_CH 4096
-__global__ void k_noise_norm(NoiseArgs na, const unsigned long long* __restrict__ offbits, const unsigned char* __restrict__ edges,
-                             const unsigned long long* __restrict__ cells, int E, int K, float* __restrict__ zpart) {
+__global__ void k_noise_norm(NoiseArgs na, MaskTab mt, int E, int K, float* __restrict__ zpart) {
     __shared__ float red[64];
     const int b = blockIdx.y, EK = E * K, ng = (EK + 3) >> 2;
-    const unsigned long long off = offbits[b];
     const int g0 = blockIdx.x * CCSD_NN_CH, g1 = g0 + CCSD_NN_CH < ng ? g0 + CCSD_NN_CH : ng;
     const FastDiv dK(K);
     float acc = 0.f;
@@ -89,13 +87,14 @@ __global__ void k_noise_norm(NoiseArgs na, const unsigned long long* __restrict_
         raw_noise_rflat4(na, b, g, EK, z);
         int e, k;
         dK.divmod(4 * g, e, k);
+        float m[4];
+        group_masks(mt, b, E, K, e, k, m);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if (4 * g + s < EK) {
-                const float zz = z[s] * edge_on(off, edges, e) * cell_on(off, cells, k);
+                const float zz = z[s] * m[s];
                 acc = fmaf(zz, zz, acc);
             }
-            if (++k == K) { k = 0; ++e; }
         }
     }
     const float t = block_sum(acc, red);
@@ -125,8 +124,7 @@ CCSD_DEV void langevin_coef(const LangArgs& a, int t, float* c1, float* c2) {
     *c1 = step * a.ss[t];
     *c2 = sqrtf(step * 2.f) * a.seps;
 }
-__global__ void k_langevin_apply(LangArgs a, NoiseArgs na, const unsigned long long* __restrict__ offbits,
-                                 const unsigned char* __restrict__ edges, const unsigned long long* __restrict__ cells) {
+__global__ void k_langevin_apply(LangArgs a, NoiseArgs na, MaskTab mt) {
     const long long nxe = (long long)a.B * a.N * a.F, nae = (long long)a.B * a.N * a.N;
     // rank2: one thread per flat Philox group = four consecutive elements of the sample's (E, K) block (NoiseArgs::flat_r): with
     // E K a multiple of 4 every group is one aligned 16-byte load of the state, one of the raw score and one 16-byte store
@@ -157,16 +155,14 @@ __global__ void k_langevin_apply(LangArgs a, NoiseArgs na, const unsigned long l
                 }
             }
             raw_noise_rflat4(na, b, g, EK, z);
-            const unsigned long long off = offbits[b];
             int e, k;
             dK.divmod(4 * g, e, k);
-            float o[4];
+            float o[4], m[4];
+            group_masks(mt, b, a.E, a.K, e, k, m);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int ec = e < a.E ? e : a.E - 1;           // (beyond the block only in a ragged last group: never stored)
-                const float zz = z[s] * edge_on(off, edges, ec) * cell_on(off, cells, k);
+                const float zz = z[s] * m[s];
                 o[s] = fmaf(c2r, zz, fmaf(c1r, nv[s], v[s]));
-                if (++k == a.K) { k = 0; ++e; }
             }
             if (vec) *reinterpret_cast<float4*>(a.orr + base) = make_float4(o[0], o[1], o[2], o[3]);
             else {
@@ -205,12 +201,11 @@ struct Ew1Args {
     float sscale, pa, pb, pc, alpha, gamma;
     const float* sums; float ss, sde_alpha, snr, seps; unsigned int draw_corr;
     int E, K;
+    MaskTab mt;                       // mask byte tables (k_masktab)
 };
-__global__ void k_ew1(Ew1Args a, NoiseArgs na, const unsigned long long* __restrict__ offbits, const unsigned char* __restrict__ edges,
-                      const unsigned long long* __restrict__ cells) {
+__global__ void k_ew1(Ew1Args a, NoiseArgs na) {
     __shared__ float red[64];
     const int b = blockIdx.y, EK = a.E * a.K, ng = (EK + 3) >> 2;
-    const unsigned long long off = offbits[b];
     const int g0 = blockIdx.x * CCSD_NN_CH, g1 = g0 + CCSD_NN_CH < ng ? g0 + CCSD_NN_CH : ng;
     const FastDiv dK(a.K);
     const bool vec = (EK & 3) == 0;
@@ -235,13 +230,8 @@ __global__ void k_ew1(Ew1Args a, NoiseArgs na, const unsigned long long* __restr
         }
         int e, k;
         dK.divmod(4 * g, e, k);
-        float m[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int ec = e < a.E ? e : a.E - 1;
-            m[s] = edge_on(off, edges, ec) * cell_on(off, cells, k);           // flags_left * flags_right, cc_utils.py:590
-            if (++k == a.K) { k = 0; ++e; }
-        }
+        float m[4];                                                            // flags_left * flags_right, cc_utils.py:590
+        group_masks(a.mt, b, a.E, a.K, e, k, m);
         float o[4], mu[4], w1[4], nt[4];
         float zc[4] = {0.f, 0.f, 0.f, 0.f}, zp[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.mode == MODE_NORMS || (a.mode == MODE_PRED && a.apply)) raw_noise_rflat4(nc, b, g, EK, zc);

@@ -11,6 +11,25 @@ CCSD_DEV float cell_on(unsigned long long off, const unsigned long long* __restr
     return (cells[k] & off) ? 0.f : 1.f;
 }
 
+// The masks flags_left[e] * flags_right[k] of the four consecutive elements of flat group (e, k) .. of a sample's (E, K) block from
+// the byte tables of k_masktab (rows mfr + b Kp, mfl + b Ep): with K a multiple of 4 the group lies inside one row and k is a
+// multiple of 4 -- one 32-bit word of mfr and one byte of mfl; otherwise byte by byte across the row end.
+struct MaskTab { const unsigned char* mfr; const unsigned char* mfl; int Kp, Ep; };
+CCSD_DEV void group_masks(const MaskTab& mt, int b, int E, int K, int e, int k, float* m) {
+    const unsigned char* fr = mt.mfr + (size_t)b * mt.Kp;
+    const unsigned char* fl = mt.mfl + (size_t)b * mt.Ep;
+    if ((K & 3) == 0) {
+        const unsigned f4 = *reinterpret_cast<const unsigned*>(fr + k);
+        const float l = (float)fl[e < E ? e : E - 1];
+        m[0] = l * (float)(f4 & 0xffu); m[1] = l * (float)((f4 >> 8) & 0xffu); m[2] = l * (float)((f4 >> 16) & 0xffu); m[3] = l * (float)(f4 >> 24);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            m[s] = (float)fl[e < E ? e : E - 1] * (float)fr[k];      // (beyond the block only in a ragged last group: never used)
+            if (++k == K) { k = 0; ++e; }
+        }
+    }
+}
 
 enum { MODE_SCORE = 0, MODE_NORMS = 1, MODE_PRED = 2 };
 
