@@ -24,6 +24,8 @@ static inline int xa_variant(const PlanD& p) {
     if (p.hb_L) return XA_HB;
     if (p.x_gmh) return XA_GMH;
     if (!p.chan_global && p.N == 9 && p.F == 4 && p.E == 36 && p.ldn == 16 && !p.geo_off) return XA_PLAIN9;
+    if (p.chan_global && p.N == 20 && p.E == 190 && p.ldn == 24 && !p.geo_off) return XA_PLAIN20;
+    if (p.chan_global && p.N == 38 && p.E == 703 && p.ldn == 40 && !p.geo_off) return XA_PLAIN38;
     return XA_PLAIN;
 }
 static inline const void* xa_kernel(const PlanD& p) {
@@ -31,6 +33,8 @@ static inline const void* xa_kernel(const PlanD& p) {
 #define XA_FN(G_) (v == XA_HB ? (const void*)k_xa<G_, XA_HB> : v == XA_GMH ? (const void*)k_xa<G_, XA_GMH> : \
                    v == XA_GEN ? (const void*)k_xa<G_, XA_GEN> : (const void*)k_xa<G_, XA_PLAIN>)
     if (v == XA_PLAIN9) return (const void*)k_xa<false, XA_PLAIN9>;
+    if (v == XA_PLAIN20) return (const void*)k_xa<true, XA_PLAIN20>;
+    if (v == XA_PLAIN38) return (const void*)k_xa<true, XA_PLAIN38>;
     return p.chan_global ? XA_FN(true) : XA_FN(false);
 #undef XA_FN
 }
@@ -539,6 +543,8 @@ static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Work
         if (variant == XA_HB) XA_GO(true, XA_HB, xa, xblk, xlds, stream);
         else if (variant == XA_GMH) XA_GO(true, XA_GMH, xa, xblk, xlds, stream);
         else if (variant == XA_GEN) XA_GO(true, XA_GEN, xa, xblk, xlds, stream);
+        else if (variant == XA_PLAIN20) XA_GO(true, XA_PLAIN20, xa, xblk, xlds, stream);
+        else if (variant == XA_PLAIN38) XA_GO(true, XA_PLAIN38, xa, xblk, xlds, stream);
         else XA_GO(true, XA_PLAIN, xa, xblk, xlds, stream);
     } else {
         if (variant == XA_HB) XA_GO(false, XA_HB, xa, xblk, xlds, stream);

@@ -10,6 +10,11 @@
 #define XA_HB 1
 #define XA_GMH 2
 #define XA_PLAIN9 4       /* XA_PLAIN with the qm9 geometry compiled in: N = 9, E = 36, F = 4, ldn = 16 (index arithmetic folds to constants) */
+#define XA_PLAIN20 5      /* XA_PLAIN, channel stack in HBM, community_small geometry: N = 20, E = 190, ldn = 24 */
+#define XA_PLAIN38 6      /* XA_PLAIN, channel stack in HBM, zinc250k geometry: N = 38, E = 703, ldn = 40 */
+// node count a variant has compiled in (0: run-time geometry); E = N (N - 1) / 2 and the node-row stride round_ld(N) follow
+static constexpr int xa_geo_n(int var) { return var == XA_PLAIN9 ? 9 : var == XA_PLAIN20 ? 20 : var == XA_PLAIN38 ? 38 : 0; }
+static constexpr int xa_geo_ld(int n) { return ((n + 7) / 8 * 8) % 32 == 0 ? (n + 7) / 8 * 8 + 8 : (n + 7) / 8 * 8; }   // == round_ld (ccsd_plan.h)
 #define XA_GEN 3          /* everything, selected at run time from the plan: both of the above together, conv = "MLP" */
 struct XaArgs {
     // inputs: the X-network and the A-network may see different (x, adj) when the Langevin
@@ -180,8 +185,9 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
     constexpr bool HB = VAR == XA_HB || VAR == XA_GEN, GMH = VAR == XA_GMH || VAR == XA_GEN, CONVMLP = VAR == XA_GEN;
     // XA_PLAIN9: a third of k_xa's vector instructions are 32-bit integer index arithmetic on strides the plan supplies at run
     // time (PMC, profiles/r03_c_phase_mix.txt); for the headline geometry they are compile-time constants (xa_variant() checks them)
-    constexpr bool NFIX = VAR == XA_PLAIN9;
-    const int N = NFIX ? 9 : p.N, F = NFIX ? 4 : p.F, NN = N * N, E = NFIX ? 36 : p.E, ldn = NFIX ? 16 : p.ldn;
+    constexpr bool NFIX = VAR == XA_PLAIN9;          // everything fixed incl. F and the thread count
+    constexpr int GN = xa_geo_n(VAR);                // node count compiled in (XA_PLAIN9 / XA_PLAIN20 / XA_PLAIN38), else 0
+    const int N = GN ? GN : p.N, F = NFIX ? 4 : p.F, NN = N * N, E = GN ? GN * (GN - 1) / 2 : p.E, ldn = GN ? xa_geo_ld(GN) : p.ldn;
 #ifndef CCSD_EMU
     if (NFIX) __builtin_assume(blockDim.x == 256);     // (launch_xa starts XA_PLAIN9 with 256 threads only)
 #endif

@@ -800,17 +800,18 @@ def case_kat_hodge_layers(lib, device):
         assert_close(g_, w_, f"three hodge layers, Reverse + Langevin n_steps=2, {p}")
 
 
-def case_geometry_instances_bitwise(lib, device, B=64, steps=3):
+def case_geometry_instances_bitwise(lib, device, B=64, steps=3, name="ccsd_qm9_CC", counts=(9, 9, 8, 7, 9, 5, 9, 3, 6, 9, 2, 9), expect=(4, 0),
+                                    predictor="Reverse", snr=0.2):
     """The instances of k_xa / k_r2 with the qm9 geometry compiled in (N = 9, E = 36, K = 466, the LDS strides: ccsd_k_xa.h XA_PLAIN9,
     ccsd_k_r2.h QM9) against the run-time-geometry instances of the same kernels (a plan created with CCSD_NO_GEO set): the same
     arithmetic in the same order -- only index computations fold -- so the production loop must agree BIT FOR BIT, and so must the
     three scores.  Also checks that the qm9 plan really selects the specialised instances."""
-    meta, parts = load_ckpt_np("ccsd_qm9_CC")
+    meta, parts = load_ckpt_np(name)
     cfg = meta["config"]
     N, Fd = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
     d_min, d_max = cfg["data"]["d_min"], cfg["data"]["d_max"]
-    flags = make_flags(B, N, [9, 9, 8, 7, 9, 5, 9, 3, 6, 9, 2, 9]).to(device)
-    kw = dict(shape_x=(B, N, Fd), shape_adj=(B, N, N), predictor="Reverse", corrector="Langevin", snr=0.2, scale_eps=0.7, n_steps=1,
+    flags = make_flags(B, N, list(counts)).to(device)
+    kw = dict(shape_x=(B, N, Fd), shape_adj=(B, N, N), predictor=predictor, corrector="Langevin", snr=snr, scale_eps=0.7, n_steps=1,
               probability_flow=False, continuous=True, denoise=True, eps=1e-4, is_cc=True, shape_rank2=(B, *rank2_dim(N, d_min, d_max)),
               d_min=d_min, d_max=d_max)
     sd = [loader.load_sde(cfg["sde"][p]) for p in ("x", "adj", "rank2")]
@@ -835,6 +836,6 @@ def case_geometry_instances_bitwise(lib, device, B=64, steps=3):
         if old is not None:
             os.environ["CCSD_NO_GEO"] = old
     if device != "cpu":
-        assert variants == [4, 0], f"k_xa variants selected: {variants} (expected the qm9-geometry instance, then the plain one)"
+        assert variants == list(expect), f"k_xa variants selected: {variants} (expected the compile-time-geometry instance, then the plain one)"
     for k, (a, b) in enumerate(zip(*outs)):
         assert torch.equal(a, b), f"tensor {k}: compile-time-geometry instance != run-time-geometry instance (max diff {(a - b).abs().max().item():.3e})"

@@ -338,3 +338,7 @@ def test_zinc5b_production_loop_vs_oracle(lib):
 def test_geometry_instances_match_runtime_geometry_bitwise(lib):
     """k_xa<false, XA_PLAIN9> / k_r2<3, 1, true, false, QM9> == the run-time-geometry instances, bit for bit (production loop + scores)."""
     pc.case_geometry_instances_bitwise(lib, DEV)
+    # k_xa<true, XA_PLAIN20> (community_small geometry, channel stack in HBM) against k_xa<true, XA_PLAIN>
+    # (B = 512: the batch at which the plan keeps the channel stack in HBM)
+    pc.case_geometry_instances_bitwise(lib, DEV, B=512, steps=2, name="ccsd_community_small_CC", counts=(20, 12, 16, 18, 14, 20), expect=(5, 0),
+                                       predictor="Euler", snr=0.05)
