@@ -23,7 +23,14 @@ static inline int xa_variant(const PlanD& p) {
     if (!p.chan_global && !p.hb_L && p.a_fin.chain >= 5) return XA_GEN;
     if (p.hb_L) return XA_HB;
     if (p.x_gmh) return XA_GMH;
-    if (!p.chan_global && p.N == 9 && p.F == 4 && p.E == 36 && p.ldn == 16 && !p.geo_off) return XA_PLAIN9;
+    if (!p.chan_global && p.N == 9 && p.F == 4 && p.E == 36 && p.ldn == 16 && !p.geo_off) {
+        if (CCSD_BAKED_QM9_SIZE == sizeof(PlanD)) {       // the whole plan as a compile-time constant, if it is THE baked one
+            unsigned char bytes[sizeof(PlanD)];
+            ccsd_plan_arch_bytes(p, bytes);
+            if (memcmp(bytes, CCSD_BAKED_QM9_PLAN, sizeof(PlanD)) == 0) return XA_BAKED9;
+        }
+        return XA_PLAIN9;
+    }
     if (p.chan_global && p.N == 20 && p.E == 190 && p.ldn == 24 && !p.geo_off) return XA_PLAIN20;
     if (p.chan_global && p.N == 38 && p.E == 703 && p.ldn == 40 && !p.geo_off) return XA_PLAIN38;
     return XA_PLAIN;
@@ -33,6 +40,7 @@ static inline const void* xa_kernel(const PlanD& p) {
 #define XA_FN(G_) (v == XA_HB ? (const void*)k_xa<G_, XA_HB> : v == XA_GMH ? (const void*)k_xa<G_, XA_GMH> : \
                    v == XA_GEN ? (const void*)k_xa<G_, XA_GEN> : (const void*)k_xa<G_, XA_PLAIN>)
     if (v == XA_PLAIN9) return (const void*)k_xa<false, XA_PLAIN9>;
+    if (v == XA_BAKED9) return (const void*)k_xa<false, XA_BAKED9>;
     if (v == XA_PLAIN20) return (const void*)k_xa<true, XA_PLAIN20>;
     if (v == XA_PLAIN38) return (const void*)k_xa<true, XA_PLAIN38>;
     return p.chan_global ? XA_FN(true) : XA_FN(false);
@@ -146,14 +154,22 @@ static inline void r2_shape(const ccsd_plan* pl, int* MT, int* RS, bool* aff, bo
         else R2_CASE(1, 0, X) else R2_CASE(1, 1, X) else R2_CASE(1, 2, X) else R2_CASE(1, 3, X) \
         else R2_CASE(2, 2, X) else R2_CASE(2, 3, X) else R2_CASE(3, 0, X) else R2_CASE(3, 1, X) else R2_CASE(4, 2, X) \
     } while (0)
-// the instance with the qm9 geometry compiled in (k_r2<3, 1, true, false, true>) serves exactly that geometry
-static inline bool r2_qm9(const ccsd_plan* pl) {
+// the instances with the qm9 geometry compiled in: 1 = k_r2<3, 1, true, false, 1> (geometry only), 2 = <..., 2> (the whole baked plan:
+// only when the plan's architecture bytes equal ccsd_baked_qm9.h), 0 = the run-time-geometry instances
+static inline int r2_qm9(const ccsd_plan* pl) {
     const PlanD& p = pl->h;
     const bool gen1 = p.h_L > 1 && p.hl[0].mval.n > 1;
-    return !p.geo_off && p.f_affine && !gen1 && p.E == 36 && p.K == 466 && p.N == 9 && pl->r2_ldk == 488 && pl->r2_ldh == 36;
+    if (p.geo_off || !p.f_affine || gen1 || p.E != 36 || p.K != 466 || p.N != 9 || pl->r2_ldk != 488 || pl->r2_ldh != 36) return 0;
+    if (CCSD_BAKED_QM9_SIZE == sizeof(PlanD)) {
+        unsigned char bytes[sizeof(PlanD)];
+        ccsd_plan_arch_bytes(p, bytes);
+        if (memcmp(bytes, CCSD_BAKED_QM9_PLAN, sizeof(PlanD)) == 0) return 2;
+    }
+    return 1;
 }
 static inline const void* r2_kernel(const ccsd_plan* pl) {
-    if (r2_qm9(pl)) return (const void*)k_r2<3, 1, true, false, true>;
+    if (r2_qm9(pl) == 2) return (const void*)k_r2<3, 1, true, false, 2>;
+    if (r2_qm9(pl) == 1) return (const void*)k_r2<3, 1, true, false, 1>;
     const void* fn = nullptr;
 #define R2_PTR(MT_, RS_, A_, G_) fn = (const void*)k_r2<MT_, RS_, A_, G_>
     R2_DISPATCH(pl, R2_PTR);
@@ -361,13 +377,26 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
 #ifndef CCSD_EMU
     if ((size_t)pl->h.xa_lds_floats * 4 > 64 * 1024)
         PC(rt_set_max_dyn_smem(xa_kernel(pl->h), (size_t)pl->h.xa_lds_floats * 4));
-        if (xa_variant(pl->h) == XA_PLAIN9)     // (its run-time-geometry twin serves launches with a diagnostic thread count)
+        if (xa_variant(pl->h) == XA_PLAIN9 || xa_variant(pl->h) == XA_BAKED9)     // (its run-time-geometry twin serves launches with a diagnostic thread count)
             PC(rt_set_max_dyn_smem((const void*)k_xa<false, XA_PLAIN>, (size_t)pl->h.xa_lds_floats * 4));
     if (pl->fused_r2 && pl->r2_lds > 64 * 1024) {
         PC(rt_set_max_dyn_smem(r2_kernel(pl), pl->r2_lds));
     }
 #endif
 #undef PC
+    if (const char* path = getenv("CCSD_DUMP_PLAN")) {     // tools/bake_plan.py: the plan's architecture bytes as a C header
+        std::vector<unsigned char> bytes(sizeof(PlanD));
+        ccsd_plan_arch_bytes(pl->h, bytes.data());
+        if (FILE* f = fopen(path, "w")) {
+            fprintf(f, "// ccsd_baked_qm9.h -- GENERATED by tools/bake_plan.py (do not edit): the PlanD of the qm9_CC configuration at batch 1024\n"
+                       "// (architecture bytes: ccsd_plan_arch_bytes, the weight-derived affine fold zeroed).  k_xa<false, XA_BAKED9> reads its plan\n"
+                       "// from this constant instead of from memory; the host selects it only for plans whose architecture bytes are equal.\n"
+                       "#pragma once\n#define CCSD_BAKED_QM9_SIZE %zu\nalignas(16) static constexpr unsigned char CCSD_BAKED_QM9_PLAN[CCSD_BAKED_QM9_SIZE] = {", sizeof(PlanD));
+            for (size_t i = 0; i < bytes.size(); ++i) fprintf(f, "%s%u,", (i % 40) ? "" : "\n    ", (unsigned)bytes[i]);
+            fprintf(f, "\n};\n");
+            fclose(f);
+        }
+    }
     *out = pl;
     return CCSD_OK;
 }
@@ -538,7 +567,7 @@ static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Work
 #define XA_GO(G_, V_, XA_, BLK_, LDS_, STR_) CCSD_LAUNCH((k_xa<G_, V_>), dim3(B), BLK_, LDS_, STR_, (const PlanD*)pl->d, (const float*)pl->w, \
                                                          (const unsigned char*)pl->edges, XA_, na)
     int variant = xa_variant(pl->h);
-    if (variant == XA_PLAIN9 && xa_threads != 256) variant = XA_PLAIN;      // (XA_PLAIN9 has its 256 threads compiled in)
+    if ((variant == XA_PLAIN9 || variant == XA_BAKED9) && xa_threads != 256) variant = XA_PLAIN;      // (they have their 256 threads compiled in)
     if (pl->h.chan_global) {
         if (variant == XA_HB) XA_GO(true, XA_HB, xa, xblk, xlds, stream);
         else if (variant == XA_GMH) XA_GO(true, XA_GMH, xa, xblk, xlds, stream);
@@ -551,6 +580,7 @@ static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Work
         else if (variant == XA_GMH) XA_GO(false, XA_GMH, xa, xblk, xlds, stream);
         else if (variant == XA_GEN) XA_GO(false, XA_GEN, xa, xblk, xlds, stream);
         else if (variant == XA_PLAIN9) XA_GO(false, XA_PLAIN9, xa, xblk, xlds, stream);
+        else if (variant == XA_BAKED9) XA_GO(false, XA_BAKED9, xa, xblk, xlds, stream);
         else XA_GO(false, XA_PLAIN, xa, xblk, xlds, stream);
     }
 #undef XA_GO
@@ -617,8 +647,12 @@ static int launch_r2(const ccsd_plan* pl, int B, const float* rank2, const float
 #define R2_GO(MT_, RS_, A_, G_) \
     CCSD_LAUNCH((k_r2<MT_, RS_, A_, G_>), dim3(B), blk, pl->r2_lds, stream, (const PlanD*)pl->d, (const float*)pl->w, \
                 (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, ra, ep, na)
-    if (r2_qm9(pl)) {
-        CCSD_LAUNCH((k_r2<3, 1, true, false, true>), dim3(B), blk, pl->r2_lds, stream, (const PlanD*)pl->d, (const float*)pl->w,
+    const int qm9 = r2_qm9(pl);
+    if (qm9 == 2) {
+        CCSD_LAUNCH((k_r2<3, 1, true, false, 2>), dim3(B), blk, pl->r2_lds, stream, (const PlanD*)pl->d, (const float*)pl->w,
+                    (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, ra, ep, na);
+    } else if (qm9 == 1) {
+        CCSD_LAUNCH((k_r2<3, 1, true, false, 1>), dim3(B), blk, pl->r2_lds, stream, (const PlanD*)pl->d, (const float*)pl->w,
                     (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, ra, ep, na);
     } else
     R2_DISPATCH(pl, R2_GO);

@@ -13,7 +13,8 @@
 // shapes; ccsd_r2d.hip: the non-affine ScoreNetworkF path) so that the units compile in parallel
 #ifdef CCSD_INST_R2_A
 CCSD_R2_ONE(3, 1)
-CCSD_INST __global__ void k_r2<3, 1, true, false, true> CCSD_R2_SIG;     // the qm9 geometry compiled in (QM9)
+CCSD_INST __global__ void k_r2<3, 1, true, false, 1> CCSD_R2_SIG;     // the qm9 geometry compiled in (QM9 = 1)
+CCSD_INST __global__ void k_r2<3, 1, true, false, 2> CCSD_R2_SIG;     // ... and the whole baked plan (QM9 = 2)
 #endif
 #ifdef CCSD_INST_R2_B
 CCSD_R2_ONE(3, 0) CCSD_R2_ONE(4, 2) CCSD_R2_ONE(2, 2) CCSD_R2_ONE(2, 3)
@@ -31,6 +32,7 @@ CCSD_INST __global__ void k_xa<false, XA_HB> CCSD_XA_SIG;
 CCSD_INST __global__ void k_xa<false, XA_GMH> CCSD_XA_SIG;
 CCSD_INST __global__ void k_xa<false, XA_GEN> CCSD_XA_SIG;
 CCSD_INST __global__ void k_xa<false, XA_PLAIN9> CCSD_XA_SIG;
+CCSD_INST __global__ void k_xa<false, XA_BAKED9> CCSD_XA_SIG;
 CCSD_INST __global__ void k_xa<true, XA_PLAIN> CCSD_XA_SIG;
 CCSD_INST __global__ void k_xa<true, XA_HB> CCSD_XA_SIG;
 CCSD_INST __global__ void k_xa<true, XA_GMH> CCSD_XA_SIG;

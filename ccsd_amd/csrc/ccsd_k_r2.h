@@ -1,6 +1,7 @@
 // ccsd_k_r2.h -- k_r2: the fused rank-2 kernel (one complex per workgroup, rank2 block LDS-resident)
 // Part of the kernel source of libccsd_hip.so (see ccsd_kernels.h for the map).
 #pragma once
+#include "ccsd_baked_qm9.h"
 #include "ccsd_rank2_common.h"
 
 #ifndef CCSD_R2_LB
@@ -38,15 +39,19 @@ struct R2Args {
 // lane l = 16 kc + 4 cg + j takes strip row (l & 3) as A and column 4 cg + j as B of the block (column group cg, k class kc),
 // i.e. 4 rows x 16 columns x 4 k values per instruction -- the SAME operand addresses as the 16x16x4 tile code (B operand of
 // column l & 15, k slot group l >> 4), only the A row differs; the four k classes are summed with two lane swaps.
-// QM9: the qm9 geometry (E = 36, K = 466, N = 9, LDS strides 488 / 36) as compile-time constants: the index arithmetic on these
+// QM9 (1, 2): the qm9 geometry (E = 36, K = 466, N = 9, LDS strides 488 / 36) as compile-time constants: the index arithmetic on these
 // strides folds into immediates (as k_xa<false, XA_PLAIN9>); the host selects the instance only when the plan matches (r2_qm9()).
-template <int MT, int RS, bool AFFINE, bool GEN1, bool QM9 = false>
+template <int MT, int RS, bool AFFINE, bool GEN1, int QM9 = 0>
 __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, const float* __restrict__ w,
                                             const unsigned char* __restrict__ edges,
                                             const unsigned long long* __restrict__ cells, R2Args ra, RankEpi ep,
                                             NoiseArgs na) {
     CCSD_DYN_SMEM(sm);
-    const PlanD& p = *plan;
+    // QM9 with a baked plan (ccsd_baked_qm9.h; r2_qm9() == 2 when the plan's architecture bytes equal the baked ones): every plan
+    // field but the weight-derived affine fold -- read through `pw` -- is a compile-time constant
+    constexpr bool BAKED = QM9 == 2 && CCSD_BAKED_QM9_SIZE == sizeof(PlanD);
+    const PlanD& pw = *plan;
+    const PlanD& p = BAKED ? *reinterpret_cast<const PlanD*>(CCSD_BAKED_QM9_PLAN) : *plan;
     const int E = QM9 ? 36 : p.E, K = QM9 ? 466 : p.K, N = QM9 ? 9 : p.N, NN = N * N, ldk = QM9 ? 488 : ra.ldk, ldh = QM9 ? 36 : ra.ldh;
     // (the thread count stays a run-time value even in the QM9 instance: as a constant the block-load and tile loops were unrolled and
     // rescheduled into a slower kernel, 158 -> 178 us)
@@ -588,7 +593,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
             const float f = sF[e * ldk + k];
             const float m = sFl[e] * fr;                         // flags_left * flags_right, cc_utils.py:590
             const float hf1[CCSD_MAXCN - 1] = {hf[r], 0.f, 0.f};      // (cnum > 2 takes the tiled kernels: ccsd_plan::fused_r2)
-            const float net = fnet_element<AFFINE>(p, w, f, hf1, m);
+            const float net = fnet_element<AFFINE>(pw, w, f, hf1, m);
             const size_t gi = ((size_t)b * E + e) * K + k;
             if (ep.mode == MODE_SCORE) {
                 ep.out[gi] = ep.sscale * net;
@@ -650,7 +655,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
             constexpr int MODE = decltype(MODE_)::value;   // 0 score, 1 norms, 2 predictor, 3 predictor + mean output
             constexpr bool INJ = decltype(INJ_)::value;    // host-supplied raw draws instead of Philox
             const float s_ = MODE == 0 ? ep.sscale : MODE == 1 ? 1.f : ep.pb;
-            const float sa = s_ * p.f_alpha, sb = s_ * p.f_beta, sg = s_ * p.f_gamma;
+            const float sa = s_ * pw.f_alpha, sb = s_ * pw.f_beta, sg = s_ * pw.f_gamma;
             const float pa = ep.pa, pc = ep.pc;
             float* const meanp = MODE == 3 ? ep.mean + (size_t)b * E * K : nullptr;
             const float* const zrp = INJ ? na.zr + (size_t)b * E * K : nullptr;
@@ -774,7 +779,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
             const int n = 16 * tn + l15;
             if (tn < ntn && n < K && !(diag & 4)) {
                 const float s_ = MODE == 0 ? ep.sscale : MODE == 1 ? 1.f : ep.pb;
-                const float sa = s_ * p.f_alpha, sb = s_ * p.f_beta, sg = s_ * p.f_gamma;
+                const float sa = s_ * pw.f_alpha, sb = s_ * pw.f_beta, sg = s_ * pw.f_gamma;
                 const float pa = ep.pa, pc = ep.pc;
                 float* const meanp = MODE == 3 ? ep.mean + (size_t)b * E * K : nullptr;
                 const float fr = (float)sFrb[n];
@@ -889,7 +894,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
             constexpr bool INJ = decltype(INJ_)::value;    // host-supplied raw draws instead of Philox
             // net' = s * net with s = sscale (score), 1 (norms), pb (predictor): folded into the three affine constants
             const float s_ = MODE == 0 ? ep.sscale : MODE == 1 ? 1.f : ep.pb;
-            const float sa = s_ * p.f_alpha, sb = s_ * p.f_beta, sg = s_ * p.f_gamma;
+            const float sa = s_ * pw.f_alpha, sb = s_ * pw.f_beta, sg = s_ * pw.f_gamma;
             const float pa = ep.pa, pc = ep.pc;
             float* const outp = ep.out + (size_t)b * E * K;
             float* const meanp = MODE == 3 ? ep.mean + (size_t)b * E * K : nullptr;

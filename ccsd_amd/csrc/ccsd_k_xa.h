@@ -1,6 +1,7 @@
 // ccsd_k_xa.h -- k_xa: ScoreNetworkX + ScoreNetworkA / ScoreNetworkA_CC for one graph per workgroup
 // Part of the kernel source of libccsd_hip.so (see ccsd_kernels.h for the map).
 #pragma once
+#include "ccsd_baked_qm9.h"
 #include "ccsd_rank2_common.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -10,10 +11,11 @@
 #define XA_HB 1
 #define XA_GMH 2
 #define XA_PLAIN9 4       /* XA_PLAIN with the qm9 geometry compiled in: N = 9, E = 36, F = 4, ldn = 16 (index arithmetic folds to constants) */
+#define XA_BAKED9 7       /* XA_PLAIN9 with the WHOLE plan of the qm9_CC configuration (batch 1024) as a compile-time constant (ccsd_baked_qm9.h) */
 #define XA_PLAIN20 5      /* XA_PLAIN, channel stack in HBM, community_small geometry: N = 20, E = 190, ldn = 24 */
 #define XA_PLAIN38 6      /* XA_PLAIN, channel stack in HBM, zinc250k geometry: N = 38, E = 703, ldn = 40 */
 // node count a variant has compiled in (0: run-time geometry); E = N (N - 1) / 2 and the node-row stride round_ld(N) follow
-static constexpr int xa_geo_n(int var) { return var == XA_PLAIN9 ? 9 : var == XA_PLAIN20 ? 20 : var == XA_PLAIN38 ? 38 : 0; }
+static constexpr int xa_geo_n(int var) { return (var == XA_PLAIN9 || var == XA_BAKED9) ? 9 : var == XA_PLAIN20 ? 20 : var == XA_PLAIN38 ? 38 : 0; }
 static constexpr int xa_geo_ld(int n) { return ((n + 7) / 8 * 8) % 32 == 0 ? (n + 7) / 8 * 8 + 8 : (n + 7) / 8 * 8; }   // == round_ld (ccsd_plan.h)
 #define XA_GEN 3          /* everything, selected at run time from the plan: both of the above together, conv = "MLP" */
 struct XaArgs {
@@ -181,11 +183,14 @@ template <bool GCH, int VAR>
 __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict__ plan, const float* __restrict__ w,
                                             const unsigned char* __restrict__ edges, XaArgs xa, NoiseArgs na) {
     CCSD_DYN_SMEM(sm);
-    const PlanD& p = *plan;
+    // XA_BAKED9: every plan field is a constant of the instance (the host selects it only for plans whose architecture bytes equal
+    // the baked ones; the placeholder header of a tree without a bake leaves it reading the plan from memory like XA_PLAIN9)
+    constexpr bool BAKED = VAR == XA_BAKED9 && CCSD_BAKED_QM9_SIZE == sizeof(PlanD);
+    const PlanD& p = BAKED ? *reinterpret_cast<const PlanD*>(CCSD_BAKED_QM9_PLAN) : *plan;
     constexpr bool HB = VAR == XA_HB || VAR == XA_GEN, GMH = VAR == XA_GMH || VAR == XA_GEN, CONVMLP = VAR == XA_GEN;
     // XA_PLAIN9: a third of k_xa's vector instructions are 32-bit integer index arithmetic on strides the plan supplies at run
     // time (PMC, profiles/r03_c_phase_mix.txt); for the headline geometry they are compile-time constants (xa_variant() checks them)
-    constexpr bool NFIX = VAR == XA_PLAIN9;          // everything fixed incl. F and the thread count
+    constexpr bool NFIX = VAR == XA_PLAIN9 || VAR == XA_BAKED9;          // everything fixed incl. F and the thread count
     constexpr int GN = xa_geo_n(VAR);                // node count compiled in (XA_PLAIN9 / XA_PLAIN20 / XA_PLAIN38), else 0
     const int N = GN ? GN : p.N, F = NFIX ? 4 : p.F, NN = N * N, E = GN ? GN * (GN - 1) / 2 : p.E, ldn = GN ? xa_geo_ld(GN) : p.ldn;
 #ifndef CCSD_EMU
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
 
     // ================= ScoreNetworkX (ScoreNetwork_X.py:102-132) =================
     // (see xnet_late_stage) both networks on the same inputs, plan permitting: only the input load + fused corrector stay here
-    const bool x_late = (VAR == XA_PLAIN || VAR == XA_PLAIN9) && !GCH && p.x_late && xa.do_x && xa.do_a && xa.xA == xa.xX && xa.adjA == xa.adjX;
+    const bool x_late = (VAR == XA_PLAIN || NFIX) && !GCH && p.x_late && xa.do_x && xa.do_a && xa.xA == xa.xX && xa.adjA == xa.adjX;
     if (x_late) {
         for (int i = tid; i < N * F; i += nth) s_x[i] = xa.xX[(size_t)b * N * F + i];
         for (int i = tid; i < NN; i += nth) s_adj[i] = xa.adjX[(size_t)b * NN + i];

@@ -128,6 +128,16 @@ static inline HodgeLayerD& ccsd_hl_mut(PlanD& p, int l) { return l < CCSD_MAXHL 
 #include <string>
 #include <vector>
 
+// The plan without its weight-derived fields (the affine fold of ScoreNetworkF): what the configuration alone determines.  A
+// kernel instance with a BAKED plan (ccsd_baked_qm9.h) serves exactly the plans whose architecture bytes equal the baked ones.
+static inline void ccsd_plan_arch_bytes(const PlanD& p, unsigned char* out) {
+    PlanD q;
+    memcpy(&q, &p, sizeof(PlanD));
+    q.f_alpha = q.f_beta = q.f_gamma = 0.f;
+    for (int j = 0; j < CCSD_MAXCN; ++j) q.f_betas[j] = 0.f;
+    memcpy(out, &q, sizeof(PlanD));
+}
+
 static inline int64_t ccsd_comb(int n, int k) {
     if (k < 0 || k > n) return 0;
     long double r = 1;

@@ -159,3 +159,28 @@ def test_zinc5b_production_loop_vs_oracle(lib):
 def test_geometry_switch_is_inert_on_the_emulation(lib):
     """CPU twin of the GPU test: the CCSD_NO_GEO plan option changes nothing in the results (the emulation compiles both forms too)."""
     pc.case_geometry_instances_bitwise(lib, DEV, B=6, steps=2)
+
+
+def test_baked_plan_header_is_current(lib, tmp_path, monkeypatch):
+    """ccsd_amd/csrc/ccsd_baked_qm9.h (the qm9_CC plan at batch 1024 as a compile-time constant, tools/bake_plan.py) equals what the
+    planner produces today: a change to PlanD or the planner without a re-bake would silently retire the baked kernel instances (the
+    host falls back to the run-time-plan ones), so it is caught here."""
+    import os
+    import bench
+    from ccsd_amd import loader
+    from ccsd_amd.engine import PCEngine
+    from tests.helpers import load_ckpt_np
+    wl = bench.WORKLOADS["qm9_CC"]
+    meta, parts = load_ckpt_np(wl["ckpt"])
+    cfg = meta["config"]
+    sdes = [loader.load_sde(cfg["sde"][p]) for p in ("x", "adj", "rank2")]
+    out = tmp_path / "baked.h"
+    monkeypatch.setenv("CCSD_DUMP_PLAN", str(out))
+    eng = PCEngine(meta["params_x"], parts["x"], meta["params_adj"], parts["adj"], meta["params_rank2"], parts["rank2"],
+                   N=cfg["data"]["max_node_num"], F=cfg["data"]["max_feat_num"], is_cc=True, d_min=cfg["data"]["d_min"],
+                   d_max=cfg["data"]["d_max"], sdes=sdes, predictor=wl["predictor"], corrector=wl["corrector"], snr=wl["snr"],
+                   scale_eps=wl["scale_eps"], n_steps=1, denoise=True, eps=1e-4, device="cpu", batch_hint=wl["batch"], lib=lib)
+    monkeypatch.delenv("CCSD_DUMP_PLAN")
+    committed = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ccsd_amd", "csrc", "ccsd_baked_qm9.h")).read()
+    assert out.read_text() == committed, "re-run python tools/bake_plan.py"
+    assert eng.query("xa_variant") == 7, "the headline plan does not select the baked k_xa instance"

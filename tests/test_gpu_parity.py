@@ -337,7 +337,11 @@ def test_zinc5b_production_loop_vs_oracle(lib):
 
 def test_geometry_instances_match_runtime_geometry_bitwise(lib):
     """k_xa<false, XA_PLAIN9> / k_r2<3, 1, true, false, QM9> == the run-time-geometry instances, bit for bit (production loop + scores)."""
-    pc.case_geometry_instances_bitwise(lib, DEV)
+    # another snr than the baked plan's: the geometry-only instances k_xa<false, XA_PLAIN9> / k_r2<3, 1, true, false, 1>
+    pc.case_geometry_instances_bitwise(lib, DEV, snr=0.25, expect=(4, 0))
+    # the bench line's configuration: the plan equals the baked one -- k_xa<false, XA_BAKED9> / k_r2<3, 1, true, false, 2>, every plan
+    # field a compile-time constant
+    pc.case_geometry_instances_bitwise(lib, DEV, B=1024, steps=3, expect=(7, 0))
     # k_xa<true, XA_PLAIN20> (community_small geometry, channel stack in HBM) against k_xa<true, XA_PLAIN>
     # (B = 512: the batch at which the plan keeps the channel stack in HBM)
     pc.case_geometry_instances_bitwise(lib, DEV, B=512, steps=2, name="ccsd_community_small_CC", counts=(20, 12, 16, 18, 14, 20), expect=(5, 0),

@@ -1,0 +1,46 @@
+"""Regenerate ccsd_amd/csrc/ccsd_baked_qm9.h: the plan (PlanD) of the qm9_CC configuration at batch 1024 as a compile-time constant.
+
+    python tools/bake_plan.py            (CPU only: uses the host emulation of the kernel source, tests/emu)
+
+k_xa<false, XA_BAKED9> reads every plan field from this constant (index arithmetic, loop bounds and LDS offsets fold into
+immediates); the host selects that instance only for a plan whose architecture bytes (ccsd_plan_arch_bytes: the plan with the
+weight-derived affine fold zeroed) equal the baked ones, so any other configuration, batch or planner version simply runs the
+run-time-plan instances.  Re-run after changing PlanD or the planner (ccsd_plan.h); tests/test_gpu_parity.py checks that the
+headline plan really selects the baked instance and that it agrees bit for bit with the run-time-plan instance.
+The configuration is read from the shipped checkpoint's own config (tests/golden) with the sampler settings of
+config/sample_qm9_CC.yaml (bench.py WORKLOADS["qm9_CC"])."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "ccsd_amd", "csrc", "ccsd_baked_qm9.h")
+
+import bench  # noqa: E402
+from ccsd_amd import loader  # noqa: E402
+from ccsd_amd.engine import PCEngine  # noqa: E402
+from tests.emu_util import emu_library  # noqa: E402
+from tests.helpers import load_ckpt_np  # noqa: E402
+
+
+def main():
+    wl = bench.WORKLOADS["qm9_CC"]
+    meta, parts = load_ckpt_np(wl["ckpt"])
+    cfg = meta["config"]
+    sdes = [loader.load_sde(cfg["sde"][p]) for p in ("x", "adj", "rank2")]
+    lib = emu_library()
+    os.environ["CCSD_DUMP_PLAN"] = OUT + ".tmp"
+    try:
+        eng = PCEngine(meta["params_x"], parts["x"], meta["params_adj"], parts["adj"], meta["params_rank2"], parts["rank2"],
+                       N=cfg["data"]["max_node_num"], F=cfg["data"]["max_feat_num"], is_cc=True, d_min=cfg["data"]["d_min"],
+                       d_max=cfg["data"]["d_max"], sdes=sdes, predictor=wl["predictor"], corrector=wl["corrector"], snr=wl["snr"],
+                       scale_eps=wl["scale_eps"], n_steps=1, denoise=True, eps=1e-4, device="cpu", batch_hint=wl["batch"], lib=lib)
+        del eng
+    finally:
+        os.environ.pop("CCSD_DUMP_PLAN", None)
+    os.replace(OUT + ".tmp", OUT)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()
