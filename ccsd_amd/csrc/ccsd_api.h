@@ -23,7 +23,7 @@ static inline int xa_variant(const PlanD& p) {
     if (!p.chan_global && !p.hb_L && p.a_fin.chain >= 5) return XA_GEN;
     if (p.hb_L) return XA_HB;
     if (p.x_gmh) return XA_GMH;
-    if (!p.chan_global && p.N == 9 && p.F == 4 && p.E == 36 && p.ldn == 16 && !p.geo_off) {
+    if (!p.chan_global && p.N == 9 && p.F == 4 && p.E == 36 && p.ldn == 16 && p.geo_off != 1) {
         if (CCSD_BAKED_QM9_SIZE == sizeof(PlanD)) {       // the whole plan as a compile-time constant, if it is THE baked one
             unsigned char bytes[sizeof(PlanD)];
             ccsd_plan_arch_bytes(p, bytes);
@@ -31,8 +31,8 @@ static inline int xa_variant(const PlanD& p) {
         }
         return XA_PLAIN9;
     }
-    if (p.chan_global && p.N == 20 && p.E == 190 && p.ldn == 24 && !p.geo_off) return XA_PLAIN20;
-    if (p.chan_global && p.N == 38 && p.E == 703 && p.ldn == 40 && !p.geo_off) return XA_PLAIN38;
+    if (p.chan_global && p.N == 20 && p.E == 190 && p.ldn == 24 && p.geo_off != 1) return XA_PLAIN20;
+    if (p.chan_global && p.N == 38 && p.E == 703 && p.ldn == 40 && p.geo_off != 1) return XA_PLAIN38;
     return XA_PLAIN;
 }
 static inline const void* xa_kernel(const PlanD& p) {
@@ -159,7 +159,7 @@ static inline void r2_shape(const ccsd_plan* pl, int* MT, int* RS, bool* aff, bo
 static inline int r2_qm9(const ccsd_plan* pl) {
     const PlanD& p = pl->h;
     const bool gen1 = p.h_L > 1 && p.hl[0].mval.n > 1;
-    if (p.geo_off || !p.f_affine || gen1 || p.E != 36 || p.K != 466 || p.N != 9 || pl->r2_ldk != 488 || pl->r2_ldh != 36) return 0;
+    if (p.geo_off == 1 || !p.f_affine || gen1 || p.E != 36 || p.K != 466 || p.N != 9 || pl->r2_ldk != 488 || pl->r2_ldh != 36) return 0;
     if (CCSD_BAKED_QM9_SIZE == sizeof(PlanD)) {
         unsigned char bytes[sizeof(PlanD)];
         ccsd_plan_arch_bytes(p, bytes);
@@ -262,7 +262,7 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     PlanBuilder pb;
     pl->nweights = ccsd_build_plan(cfg, &pl->h, pb);
     if (pb.status != CCSD_OK) { delete pl; return set_err(pb.status, pb.err); }
-    pl->h.geo_off = getenv("CCSD_NO_GEO") != nullptr;
+    pl->h.geo_off = getenv("CCSD_NO_GEO") ? 1 : getenv("CCSD_NO_BAKE") ? 2 : 0;      // 2: geometry instances yes, baked-plan instances no
     pl->npacked = (size_t)pb.pcur;
     if (pl->nweights != n_weights) {
         delete pl;

@@ -109,7 +109,7 @@ struct PlanD {
     // layers >= 1: P1 = [E][h_pw] with layer l's wc_l columns at h_poff[l] (each earlier layer padded to 16), U1 = [h_pw]
     HodgeLayerD hlx[CCSD_MAXHLX];
     int h_pw, h_poff[CCSD_MAXHL + CCSD_MAXHLX];
-    int geo_off;                  // CCSD_NO_GEO set when the plan was created: never the compile-time-geometry instances (A/B, parity tests)
+    int geo_off;                  // 1: CCSD_NO_GEO set when the plan was created -- never the compile-time-geometry instances; 2: CCSD_NO_BAKE -- never the baked-plan ones (A/B, parity tests)
     int x_late, o_lx;             // ScoreNetworkX in the idle wave of the A-network's MLP-chain intervals (k_xa); its own LDS region
     int o_h2m, o_hM, o_hX;        // k_xa LDS (h_L > 2): second dense hodge buffer; M_j = sum_c w_c H_c of layers 1..h_L-2; two [E][wc] buffers
     // ScoreNetworkX_GMH (x_gmh = 1): x_depth AttentionLayers gl[] on g_cinit adjacency powers, g_nch channels in all
