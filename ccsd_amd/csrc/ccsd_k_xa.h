@@ -187,6 +187,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
     // the baked ones; the placeholder header of a tree without a bake leaves it reading the plan from memory like XA_PLAIN9)
     constexpr bool BAKED = VAR == XA_BAKED9 && CCSD_BAKED_QM9_SIZE == sizeof(PlanD);
     const PlanD& p = BAKED ? *reinterpret_cast<const PlanD*>(CCSD_BAKED_QM9_PLAN) : *plan;
+    constexpr int BAKED_UNROLL = BAKED ? 3 : 1;      // unroll count of the AttentionLayer loop (ccsd_attn_stack.inc)
     constexpr bool HB = VAR == XA_HB || VAR == XA_GEN, GMH = VAR == XA_GMH || VAR == XA_GEN, CONVMLP = VAR == XA_GEN;
     // XA_PLAIN9: a third of k_xa's vector instructions are 32-bit integer index arithmetic on strides the plan supplies at run
     // time (PMC, profiles/r03_c_phase_mix.txt); for the headline geometry they are compile-time constants (xa_variant() checks them)
