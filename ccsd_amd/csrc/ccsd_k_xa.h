@@ -246,9 +246,44 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
     // (see xnet_late_stage) both networks on the same inputs, plan permitting: only the input load + fused corrector stay here
     const bool x_late = (VAR == XA_PLAIN || NFIX) && !GCH && p.x_late && xa.do_x && xa.do_a && xa.xA == xa.xX && xa.adjA == xa.adjX;
     if (x_late) {
-        for (int i = tid; i < N * F; i += nth) s_x[i] = xa.xX[(size_t)b * N * F + i];
-        for (int i = tid; i < NN; i += nth) s_adj[i] = xa.adjX[(size_t)b * NN + i];
-        if (xa.cf.on) { __syncthreads(); corr_apply_xa(xa.cf, na, b, N, F, s_x, s_adj, s_flags); }
+        // Everything the launch reads from HBM at its start is requested in ONE batch and meets ONE barrier: the inputs, the raw
+        // scores and norm sums of the fused corrector apply (same expressions as corr_apply_xa, the flags read from global memory
+        // instead of waiting for their LDS copy), the edge table -- and the A-network's own staging (s_xcur, channel 0) is written
+        // from the same registers.  (Was: load, barrier, apply, barrier, edge table, barrier, copy, barrier.)
+        float c1x = 0.f, c2x = 0.f, c1a = 0.f, c2a = 0.f;
+        NoiseArgs nc = na;
+        const bool cfon = xa.cf.on != 0;
+        if (cfon) {
+            corr_coef(xa.cf, 0, &c1x, &c2x);
+            corr_coef(xa.cf, 1, &c1a, &c2a);
+            nc.zx = nullptr; nc.zadj = nullptr; nc.draw_x = xa.cf.draw_x; nc.draw_adj = xa.cf.draw_adj;
+        }
+        float* const xcur0 = sm + p.o_xcur;
+        float* const chan0 = sm + p.o_chan;
+        int* const edge0 = reinterpret_cast<int*>(sm + p.o_edge);
+        const float* const fg = xa.flags + (size_t)b * N;
+        for (int t = tid; t < N * F; t += nth) {
+            float v = xa.xX[(size_t)b * N * F + t];
+            int i, f;
+            dF.divmod(t, i, f);
+            if (cfon) {
+                const float z = raw_noise_x(nc, b, t, N * F) * fg[i];
+                v = fmaf(c2x, z, fmaf(c1x, xa.cf.net_x[(size_t)b * N * F + t], v));
+            }
+            s_x[t] = v;
+            xcur0[f * ldn + i] = v;
+        }
+        for (int t = tid; t < NN; t += nth) {
+            float v = xa.adjX[(size_t)b * NN + t];
+            if (cfon) {
+                const int i = t / N, j = t % N;
+                const float z = raw_noise_adj(nc, b, i, j, N) * fg[i] * fg[j];
+                v = fmaf(c2a, z, fmaf(c1a, xa.cf.net_adj[(size_t)b * NN + t], v));
+            }
+            s_adj[t] = v;
+            chan0[t] = v;
+        }
+        for (int e = tid; e < E; e += nth) edge0[e] = ((int)edges[2 * e] << 8) | (int)edges[2 * e + 1];
         __syncthreads();
     } else
     if (xa.do_x) {
@@ -373,7 +408,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
         // unordered pair e -> (i, j), i < j: the edge table, copied to LDS once (the global copy costs an L2 round trip
         // at the head of every per-pair phase)
         int* s_edge = reinterpret_cast<int*>(sm + p.o_edge);
-        for (int e = tid; e < E; e += nth) s_edge[e] = ((int)edges[2 * e] << 8) | (int)edges[2 * e + 1];
+        if (!x_late) for (int e = tid; e < E; e += nth) s_edge[e] = ((int)edges[2 * e] << 8) | (int)edges[2 * e + 1];
         auto edge_i = [&](int e) { return s_edge[e] >> 8; };
         auto edge_j = [&](int e) { return s_edge[e] & 255; };
         auto pair_off = [&](int e) { const int v = s_edge[e]; return (v >> 8) * N + (v & 255); };
@@ -381,7 +416,9 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
         float* s_xcur = sm + p.o_xcur;
         float* s_xnext = sm + p.o_xnext;
         float* s_mch = sm + p.o_vcat;
-        if (xa.cf.on) {
+        if (x_late) {
+            // (staged, with the corrector applied, by the launch's first batch above; the barrier there covers it)
+        } else if (xa.cf.on) {
             // fused corrector: the A-network sees the corrected (x, adj).  When the X-network phase of this launch has just
             // built them from the same inputs (predictor launches: xA == xX, adjA == adjX) they are still in LDS.
             const bool reuse = xa.do_x && xa.xA == xa.xX && xa.adjA == xa.adjX;
@@ -404,7 +441,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
             }
             for (int i = tid; i < NN; i += nth) { const float v = xa.adjA[(size_t)b * NN + i]; s_adj[i] = v; s_chan[i] = v; }
         }
-        __syncthreads();
+        if (!x_late) __syncthreads();
         // pow_tensor: channel c = channel(c-1) @ adj   (graph_utils.py:285-292)
         for (int c = 1; c < p.a_cinit; ++c) {
             for (int t = tid; t < NN; t += nth) {
