@@ -31,7 +31,14 @@ static inline int xa_variant(const PlanD& p) {
         }
         return XA_PLAIN9;
     }
-    if (p.chan_global && p.N == 20 && p.E == 190 && p.ldn == 24 && p.geo_off != 1) return XA_PLAIN20;
+    if (p.chan_global && p.N == 20 && p.E == 190 && p.ldn == 24 && p.geo_off != 1) {
+        if (CCSD_BAKED_CS_SIZE == sizeof(PlanD)) {        // community_small_CC at batch 512: the whole plan baked
+            unsigned char bytes[sizeof(PlanD)];
+            ccsd_plan_arch_bytes(p, bytes);
+            if (memcmp(bytes, CCSD_BAKED_CS_PLAN, sizeof(PlanD)) == 0) return XA_BAKED20;
+        }
+        return XA_PLAIN20;
+    }
     if (p.chan_global && p.N == 38 && p.E == 703 && p.ldn == 40 && p.geo_off != 1) return XA_PLAIN38;
     return XA_PLAIN;
 }
@@ -42,6 +49,7 @@ static inline const void* xa_kernel(const PlanD& p) {
     if (v == XA_PLAIN9) return (const void*)k_xa<false, XA_PLAIN9>;
     if (v == XA_BAKED9) return (const void*)k_xa<false, XA_BAKED9>;
     if (v == XA_PLAIN20) return (const void*)k_xa<true, XA_PLAIN20>;
+    if (v == XA_BAKED20) return (const void*)k_xa<true, XA_BAKED20>;
     if (v == XA_PLAIN38) return (const void*)k_xa<true, XA_PLAIN38>;
     return p.chan_global ? XA_FN(true) : XA_FN(false);
 #undef XA_FN
@@ -385,13 +393,16 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
 #endif
 #undef PC
     if (const char* path = getenv("CCSD_DUMP_PLAN")) {     // tools/bake_plan.py: the plan's architecture bytes as a C header
+        const char* nm = getenv("CCSD_DUMP_PLAN_NAME");      // QM9 (default), CS
+        if (!nm) nm = "QM9";
         std::vector<unsigned char> bytes(sizeof(PlanD));
         ccsd_plan_arch_bytes(pl->h, bytes.data());
         if (FILE* f = fopen(path, "w")) {
-            fprintf(f, "// ccsd_baked_qm9.h -- GENERATED by tools/bake_plan.py (do not edit): the PlanD of the qm9_CC configuration at batch 1024\n"
-                       "// (architecture bytes: ccsd_plan_arch_bytes, the weight-derived affine fold zeroed).  k_xa<false, XA_BAKED9> reads its plan\n"
-                       "// from this constant instead of from memory; the host selects it only for plans whose architecture bytes are equal.\n"
-                       "#pragma once\n#define CCSD_BAKED_QM9_SIZE %zu\nalignas(16) static constexpr unsigned char CCSD_BAKED_QM9_PLAN[CCSD_BAKED_QM9_SIZE] = {", sizeof(PlanD));
+            fprintf(f, "// GENERATED by tools/bake_plan.py (do not edit): the PlanD of a shipped configuration at its bench batch as a compile-time\n"
+                       "// constant (architecture bytes: ccsd_plan_arch_bytes, the weight-derived affine fold zeroed).  The baked kernel instances read\n"
+                       "// their plan from it instead of from memory; the host selects them only for plans whose architecture bytes are equal.\n"
+                       "#pragma once\n#define CCSD_BAKED_%s_SIZE %zu\n#define CCSD_BAKED_%s_A_L %d      /* AttentionLayers of ScoreNetworkA: unroll count */\n"
+                       "alignas(16) static constexpr unsigned char CCSD_BAKED_%s_PLAN[CCSD_BAKED_%s_SIZE] = {", nm, sizeof(PlanD), nm, pl->h.a_L, nm, nm);
             for (size_t i = 0; i < bytes.size(); ++i) fprintf(f, "%s%u,", (i % 40) ? "" : "\n    ", (unsigned)bytes[i]);
             fprintf(f, "\n};\n");
             fclose(f);
@@ -573,6 +584,7 @@ static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Work
         else if (variant == XA_GMH) XA_GO(true, XA_GMH, xa, xblk, xlds, stream);
         else if (variant == XA_GEN) XA_GO(true, XA_GEN, xa, xblk, xlds, stream);
         else if (variant == XA_PLAIN20) XA_GO(true, XA_PLAIN20, xa, xblk, xlds, stream);
+        else if (variant == XA_BAKED20) XA_GO(true, XA_BAKED20, xa, xblk, xlds, stream);
         else if (variant == XA_PLAIN38) XA_GO(true, XA_PLAIN38, xa, xblk, xlds, stream);
         else XA_GO(true, XA_PLAIN, xa, xblk, xlds, stream);
     } else {

@@ -38,5 +38,6 @@ CCSD_INST __global__ void k_xa<true, XA_HB> CCSD_XA_SIG;
 CCSD_INST __global__ void k_xa<true, XA_GMH> CCSD_XA_SIG;
 CCSD_INST __global__ void k_xa<true, XA_GEN> CCSD_XA_SIG;
 CCSD_INST __global__ void k_xa<true, XA_PLAIN20> CCSD_XA_SIG;
+CCSD_INST __global__ void k_xa<true, XA_BAKED20> CCSD_XA_SIG;
 CCSD_INST __global__ void k_xa<true, XA_PLAIN38> CCSD_XA_SIG;
 #endif

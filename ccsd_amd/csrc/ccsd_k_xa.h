@@ -2,6 +2,7 @@
 // Part of the kernel source of libccsd_hip.so (see ccsd_kernels.h for the map).
 #pragma once
 #include "ccsd_baked_qm9.h"
+#include "ccsd_baked_cs.h"
 #include "ccsd_rank2_common.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -12,10 +13,11 @@
 #define XA_GMH 2
 #define XA_PLAIN9 4       /* XA_PLAIN with the qm9 geometry compiled in: N = 9, E = 36, F = 4, ldn = 16 (index arithmetic folds to constants) */
 #define XA_BAKED9 7       /* XA_PLAIN9 with the WHOLE plan of the qm9_CC configuration (batch 1024) as a compile-time constant (ccsd_baked_qm9.h) */
+#define XA_BAKED20 8      /* XA_PLAIN20 with the whole plan of the community_small_CC configuration (batch 512) baked (ccsd_baked_cs.h) */
 #define XA_PLAIN20 5      /* XA_PLAIN, channel stack in HBM, community_small geometry: N = 20, E = 190, ldn = 24 */
 #define XA_PLAIN38 6      /* XA_PLAIN, channel stack in HBM, zinc250k geometry: N = 38, E = 703, ldn = 40 */
 // node count a variant has compiled in (0: run-time geometry); E = N (N - 1) / 2 and the node-row stride round_ld(N) follow
-static constexpr int xa_geo_n(int var) { return (var == XA_PLAIN9 || var == XA_BAKED9) ? 9 : var == XA_PLAIN20 ? 20 : var == XA_PLAIN38 ? 38 : 0; }
+static constexpr int xa_geo_n(int var) { return (var == XA_PLAIN9 || var == XA_BAKED9) ? 9 : (var == XA_PLAIN20 || var == XA_BAKED20) ? 20 : var == XA_PLAIN38 ? 38 : 0; }
 static constexpr int xa_geo_ld(int n) { return ((n + 7) / 8 * 8) % 32 == 0 ? (n + 7) / 8 * 8 + 8 : (n + 7) / 8 * 8; }   // == round_ld (ccsd_plan.h)
 #define XA_GEN 3          /* everything, selected at run time from the plan: both of the above together, conv = "MLP" */
 struct XaArgs {
@@ -185,9 +187,11 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
     CCSD_DYN_SMEM(sm);
     // XA_BAKED9: every plan field is a constant of the instance (the host selects it only for plans whose architecture bytes equal
     // the baked ones; the placeholder header of a tree without a bake leaves it reading the plan from memory like XA_PLAIN9)
-    constexpr bool BAKED = VAR == XA_BAKED9 && CCSD_BAKED_QM9_SIZE == sizeof(PlanD);
-    const PlanD& p = BAKED ? *reinterpret_cast<const PlanD*>(CCSD_BAKED_QM9_PLAN) : *plan;
-    constexpr int BAKED_UNROLL = BAKED ? 3 : 1;      // unroll count of the AttentionLayer loop (ccsd_attn_stack.inc)
+    constexpr bool BAKED9 = VAR == XA_BAKED9 && CCSD_BAKED_QM9_SIZE == sizeof(PlanD);
+    constexpr bool BAKED20 = VAR == XA_BAKED20 && CCSD_BAKED_CS_SIZE == sizeof(PlanD);
+    constexpr bool BAKED = BAKED9 || BAKED20;
+    const PlanD& p = BAKED9 ? *reinterpret_cast<const PlanD*>(CCSD_BAKED_QM9_PLAN) : BAKED20 ? *reinterpret_cast<const PlanD*>(CCSD_BAKED_CS_PLAN) : *plan;
+    constexpr int BAKED_UNROLL = BAKED9 ? CCSD_BAKED_QM9_A_L : BAKED20 ? CCSD_BAKED_CS_A_L : 1;      // unroll count of the AttentionLayer loop (ccsd_attn_stack.inc)
     constexpr bool HB = VAR == XA_HB || VAR == XA_GEN, GMH = VAR == XA_GMH || VAR == XA_GEN, CONVMLP = VAR == XA_GEN;
     // XA_PLAIN9: a third of k_xa's vector instructions are 32-bit integer index arithmetic on strides the plan supplies at run
     // time (PMC, profiles/r03_c_phase_mix.txt); for the headline geometry they are compile-time constants (xa_variant() checks them)

@@ -161,26 +161,19 @@ def test_geometry_switch_is_inert_on_the_emulation(lib):
     pc.case_geometry_instances_bitwise(lib, DEV, B=6, steps=2)
 
 
-def test_baked_plan_header_is_current(lib, tmp_path, monkeypatch):
-    """ccsd_amd/csrc/ccsd_baked_qm9.h (the qm9_CC plan at batch 1024 as a compile-time constant, tools/bake_plan.py) equals what the
-    planner produces today: a change to PlanD or the planner without a re-bake would silently retire the baked kernel instances (the
-    host falls back to the run-time-plan ones), so it is caught here."""
+def test_baked_plan_headers_are_current(lib, tmp_path):
+    """ccsd_amd/csrc/ccsd_baked_*.h (the plans of the qm9_CC and community_small_CC bench configurations as compile-time constants,
+    tools/bake_plan.py) equal what the planner produces today: a change to PlanD or the planner without a re-bake would silently
+    retire the baked kernel instances (the host falls back to the run-time-plan ones), so it is caught here."""
     import os
-    import bench
-    from ccsd_amd import loader
-    from ccsd_amd.engine import PCEngine
-    from tests.helpers import load_ckpt_np
-    wl = bench.WORKLOADS["qm9_CC"]
-    meta, parts = load_ckpt_np(wl["ckpt"])
-    cfg = meta["config"]
-    sdes = [loader.load_sde(cfg["sde"][p]) for p in ("x", "adj", "rank2")]
-    out = tmp_path / "baked.h"
-    monkeypatch.setenv("CCSD_DUMP_PLAN", str(out))
-    eng = PCEngine(meta["params_x"], parts["x"], meta["params_adj"], parts["adj"], meta["params_rank2"], parts["rank2"],
-                   N=cfg["data"]["max_node_num"], F=cfg["data"]["max_feat_num"], is_cc=True, d_min=cfg["data"]["d_min"],
-                   d_max=cfg["data"]["d_max"], sdes=sdes, predictor=wl["predictor"], corrector=wl["corrector"], snr=wl["snr"],
-                   scale_eps=wl["scale_eps"], n_steps=1, denoise=True, eps=1e-4, device="cpu", batch_hint=wl["batch"], lib=lib)
-    monkeypatch.delenv("CCSD_DUMP_PLAN")
-    committed = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ccsd_amd", "csrc", "ccsd_baked_qm9.h")).read()
-    assert out.read_text() == committed, "re-run python tools/bake_plan.py"
-    assert eng.query("xa_variant") == 7, "the headline plan does not select the baked k_xa instance"
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import bake_plan
+    for name, workload, header in bake_plan.TARGETS:
+        out = tmp_path / header
+        bake_plan.bake(name, workload, str(out), lib)
+        committed = open(os.path.join(root, "ccsd_amd", "csrc", header)).read()
+        assert out.read_text() == committed, f"{header}: re-run python tools/bake_plan.py"
+    assert bake_plan.make_engine("qm9_CC", lib).query("xa_variant") == 7, "the headline plan does not select the baked k_xa instance"
+    assert bake_plan.make_engine("community_small_CC", lib).query("xa_variant") == 8

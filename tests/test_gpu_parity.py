@@ -343,6 +343,9 @@ def test_geometry_instances_match_runtime_geometry_bitwise(lib):
     # field a compile-time constant
     pc.case_geometry_instances_bitwise(lib, DEV, B=1024, steps=3, expect=(7, 0))
     # k_xa<true, XA_PLAIN20> (community_small geometry, channel stack in HBM) against k_xa<true, XA_PLAIN>
-    # (B = 512: the batch at which the plan keeps the channel stack in HBM)
-    pc.case_geometry_instances_bitwise(lib, DEV, B=512, steps=2, name="ccsd_community_small_CC", counts=(20, 12, 16, 18, 14, 20), expect=(5, 0),
+    # (B = 512: the batch at which the plan keeps the channel stack in HBM.)  The bench configuration selects the baked instance
+    # k_xa<true, XA_BAKED20> (ccsd_baked_cs.h, five AttentionLayers unrolled), another snr the geometry-only k_xa<true, XA_PLAIN20>
+    pc.case_geometry_instances_bitwise(lib, DEV, B=512, steps=2, name="ccsd_community_small_CC", counts=(20, 12, 16, 18, 14, 20), expect=(8, 0),
                                        predictor="Euler", snr=0.05)
+    pc.case_geometry_instances_bitwise(lib, DEV, B=512, steps=2, name="ccsd_community_small_CC", counts=(20, 12, 16, 18, 14, 20), expect=(5, 0),
+                                       predictor="Euler", snr=0.06)

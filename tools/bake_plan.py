@@ -14,7 +14,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-OUT = os.path.join(ROOT, "ccsd_amd", "csrc", "ccsd_baked_qm9.h")
+# (macro name, bench workload, header): the configurations whose k_xa / k_r2 instances have the plan compiled in
+TARGETS = [("QM9", "qm9_CC", "ccsd_baked_qm9.h"), ("CS", "community_small_CC", "ccsd_baked_cs.h")]
 
 import bench  # noqa: E402
 from ccsd_amd import loader  # noqa: E402
@@ -23,23 +24,36 @@ from tests.emu_util import emu_library  # noqa: E402
 from tests.helpers import load_ckpt_np  # noqa: E402
 
 
-def main():
-    wl = bench.WORKLOADS["qm9_CC"]
+def make_engine(workload, lib):
+    """The engine (hence the plan) of a bench workload at its bench batch, on the host emulation."""
+    wl = bench.WORKLOADS[workload]
     meta, parts = load_ckpt_np(wl["ckpt"])
     cfg = meta["config"]
     sdes = [loader.load_sde(cfg["sde"][p]) for p in ("x", "adj", "rank2")]
-    lib = emu_library()
-    os.environ["CCSD_DUMP_PLAN"] = OUT + ".tmp"
+    return PCEngine(meta["params_x"], parts["x"], meta["params_adj"], parts["adj"], meta["params_rank2"], parts["rank2"],
+                    N=cfg["data"]["max_node_num"], F=cfg["data"]["max_feat_num"], is_cc=True, d_min=cfg["data"]["d_min"],
+                    d_max=cfg["data"]["d_max"], sdes=sdes, predictor=wl["predictor"], corrector=wl["corrector"], snr=wl["snr"],
+                    scale_eps=wl["scale_eps"], n_steps=1, denoise=True, eps=1e-4, device="cpu", batch_hint=wl["batch"], lib=lib)
+
+
+def bake(name, workload, out_path, lib):
+    os.environ["CCSD_DUMP_PLAN"] = out_path
+    os.environ["CCSD_DUMP_PLAN_NAME"] = name
     try:
-        eng = PCEngine(meta["params_x"], parts["x"], meta["params_adj"], parts["adj"], meta["params_rank2"], parts["rank2"],
-                       N=cfg["data"]["max_node_num"], F=cfg["data"]["max_feat_num"], is_cc=True, d_min=cfg["data"]["d_min"],
-                       d_max=cfg["data"]["d_max"], sdes=sdes, predictor=wl["predictor"], corrector=wl["corrector"], snr=wl["snr"],
-                       scale_eps=wl["scale_eps"], n_steps=1, denoise=True, eps=1e-4, device="cpu", batch_hint=wl["batch"], lib=lib)
+        eng = make_engine(workload, lib)
         del eng
     finally:
         os.environ.pop("CCSD_DUMP_PLAN", None)
-    os.replace(OUT + ".tmp", OUT)
-    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+        os.environ.pop("CCSD_DUMP_PLAN_NAME", None)
+
+
+def main():
+    lib = emu_library()
+    for name, workload, header in TARGETS:
+        out = os.path.join(ROOT, "ccsd_amd", "csrc", header)
+        bake(name, workload, out + ".tmp", lib)
+        os.replace(out + ".tmp", out)
+        print("wrote", out, os.path.getsize(out), "bytes")
 
 
 if __name__ == "__main__":
