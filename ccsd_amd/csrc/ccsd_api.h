@@ -499,7 +499,10 @@ static int launch_h(const ccsd_plan* pl, int B, const float* rank2, Workspace& w
     const int nth_ = (p.E + T_BM - 1) / T_BM;
     dim3 g(xcd_grid(B, nth_ * (nth_ + 1) / 2));
     prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_H, stream);
-    CCSD_LAUNCH(k_gemm_h, g, dim3(CCSD_NTHREADS), 0, stream, rank2, w.H, p.E, p.K, p.f_hmask, B);
+    if (p.E == 190 && p.K == 1140 && p.geo_off != 1)     // (the community_small geometry as constants of the instance)
+        CCSD_LAUNCH((k_gemm_h<190, 1140>), g, dim3(CCSD_NTHREADS), 0, stream, rank2, w.H, p.E, p.K, p.f_hmask, B);
+    else
+        CCSD_LAUNCH((k_gemm_h<0, 0>), g, dim3(CCSD_NTHREADS), 0, stream, rank2, w.H, p.E, p.K, p.f_hmask, B);
     prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_H, stream);
     LAUNCH_CHECK();
     for (int j = 2; j < p.f_cnum; ++j) {       // H^j = H^(j-1) . H  (pow_tensor_cc, cc_utils.py:972-977)
@@ -609,7 +612,8 @@ static int launch_hf(const ccsd_plan* pl, int B, const float* rank2, RankEpi& ep
     const int fw = fnet_width(p);
 #define HF_GO(NP_) \
     do { \
-        if (p.f_affine) CCSD_LAUNCH((k_hf_score<true, 8, NP_>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS); \
+        if (p.f_affine && NP_ == 1 && p.E == 190 && p.K == 1140 && p.geo_off != 1) CCSD_LAUNCH((k_hf_score<true, 8, 1, 190, 1140>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS); \
+        else if (p.f_affine) CCSD_LAUNCH((k_hf_score<true, 8, NP_>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS); \
         else if (fw <= 8) CCSD_LAUNCH((k_hf_score<false, 8, NP_>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS); \
         else if (fw <= CCSD_FW) CCSD_LAUNCH((k_hf_score<false, CCSD_FW, NP_>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS); \
         else CCSD_LAUNCH((k_hf_score<false, CCSD_FWMAX, NP_>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS); \

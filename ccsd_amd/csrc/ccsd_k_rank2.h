@@ -52,8 +52,11 @@ static inline int xcd_grid(int B, int T) { return ((B + 7) / 8) * 8 * T; }
 // ---------------------------------------------------------------------------------------------
 #define H_BK 32   // k per slab (two 16-wide MFMA k blocks)
 #define H_LD 40   // LDS row stride in floats: 16-byte aligned rows, == 8 mod 32 -> conflict-free ds_read_b128 fragments
-__global__ __launch_bounds__(256) void k_gemm_h(const float* __restrict__ rank2, float* __restrict__ H, int E, int K,
+// EC, KC: E and K as compile-time constants (0: the run-time arguments) -- the instance for the community_small geometry
+template <int EC = 0, int KC = 0>
+__global__ __launch_bounds__(256) void k_gemm_h(const float* __restrict__ rank2, float* __restrict__ H, int E_, int K_,
                                                 int zero_diag, int B) {
+    const int E = EC ? EC : E_, K = KC ? KC : K_;
     const int nt = (E + T_BM - 1) / T_BM;
     int b, t;
     if (!xcd_sample_tile((int)blockIdx.x, nt * (nt + 1) / 2, B, &b, &t)) return;
@@ -345,7 +348,8 @@ __global__ void k_edgecoef(const float* __restrict__ adj, float* __restrict__ ac
 // grid xcd_grid(B, ceil(K/64) ceil(E/64))
 // ---------------------------------------------------------------------------------------------
 // NP: Hodge powers the instantiation can hold (1: cnum <= 2, the common case -- one accumulator, no loop; CCSD_MAXCN - 1 otherwise)
-template <bool AFFINE, int FW, int NP>
+// EC, KC: E and K as compile-time constants (0: from the plan)
+template <bool AFFINE, int FW, int NP, int EC = 0, int KC = 0>
 __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan, const float* __restrict__ w,
                                                   const float* __restrict__ rank2, const float* __restrict__ H,
                                                   const unsigned long long* __restrict__ offbits,
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
                                                   NoiseArgs na, int B, MaskTab mt) {
     __shared__ float red[64];
     const PlanD& p = *plan;
-    const int E = p.E, K = p.K;
+    const int E = EC ? EC : p.E, K = KC ? KC : p.K;
     const int ncb = (K + T_BN - 1) / T_BN, nrt = (E + T_BM - 1) / T_BM;
     int b, tile;
     if (!xcd_sample_tile((int)blockIdx.x, ncb * nrt, B, &b, &tile)) return;       // (see xcd_sample_tile: a complex's tiles share an XCD)
