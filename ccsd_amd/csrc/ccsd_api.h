@@ -412,6 +412,17 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     return CCSD_OK;
 }
 
+// (E, K) of the shipped geometries the general-path kernels have instances for: X(EC, KC) is expanded with the plan's pair as
+// compile-time constants when it is one of them (loop bounds, row strides and divisions fold), with (0, 0) = run-time values otherwise
+#define GEO_EK(p_, X) \
+    do { \
+        if ((p_).geo_off == 1) { X(0, 0); } \
+        else if ((p_).E == 190 && (p_).K == 1140) { X(190, 1140); }    /* community_small (d_min 2 .. d_max) */ \
+        else if ((p_).E == 703 && (p_).K == 8436) { X(703, 8436); }    /* N = 38 (zinc250k), the 5b substitute's cells */ \
+        else if ((p_).E == 66 && (p_).K == 715) { X(66, 715); }        /* ENZYMES_small */ \
+        else { X(0, 0); } \
+    } while (0)
+
 // ---------------- workspace ----------------
 struct Workspace {
     unsigned long long* offbits;
@@ -499,10 +510,9 @@ static int launch_h(const ccsd_plan* pl, int B, const float* rank2, Workspace& w
     const int nth_ = (p.E + T_BM - 1) / T_BM;
     dim3 g(xcd_grid(B, nth_ * (nth_ + 1) / 2));
     prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_H, stream);
-    if (p.E == 190 && p.K == 1140 && p.geo_off != 1)     // (the community_small geometry as constants of the instance)
-        CCSD_LAUNCH((k_gemm_h<190, 1140>), g, dim3(CCSD_NTHREADS), 0, stream, rank2, w.H, p.E, p.K, p.f_hmask, B);
-    else
-        CCSD_LAUNCH((k_gemm_h<0, 0>), g, dim3(CCSD_NTHREADS), 0, stream, rank2, w.H, p.E, p.K, p.f_hmask, B);
+#define H_GO(EC_, KC_) CCSD_LAUNCH((k_gemm_h<EC_, KC_>), g, dim3(CCSD_NTHREADS), 0, stream, rank2, w.H, p.E, p.K, p.f_hmask, B)
+    GEO_EK(p, H_GO);
+#undef H_GO
     prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_H, stream);
     LAUNCH_CHECK();
     for (int j = 2; j < p.f_cnum; ++j) {       // H^j = H^(j-1) . H  (pow_tensor_cc, cc_utils.py:972-977)
@@ -542,7 +552,11 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
             const dim3 g0((rows + T_BM - 1) / T_BM);
             const float* WT = (const float*)pl->wp + h.wcatT;
             switch (nt) {
-                case 1: hipLaunchKernelGGL(k_gemm_p0<1>, g0, dim3(256), 0, (hipStream_t)stream, rank2, WT, w.P0, rows, p.K, Kp, h.wc); break;
+                case 1:
+                    if (p.K == 1140 && p.geo_off != 1) hipLaunchKernelGGL((k_gemm_p0<1, 1140>), g0, dim3(256), 0, (hipStream_t)stream, rank2, WT, w.P0, rows, p.K, Kp, h.wc);
+                    else if (p.K == 8436 && p.geo_off != 1) hipLaunchKernelGGL((k_gemm_p0<1, 8436>), g0, dim3(256), 0, (hipStream_t)stream, rank2, WT, w.P0, rows, p.K, Kp, h.wc);
+                    else hipLaunchKernelGGL(k_gemm_p0<1>, g0, dim3(256), 0, (hipStream_t)stream, rank2, WT, w.P0, rows, p.K, Kp, h.wc);
+                    break;
                 case 2: hipLaunchKernelGGL(k_gemm_p0<2>, g0, dim3(256), 0, (hipStream_t)stream, rank2, WT, w.P0, rows, p.K, Kp, h.wc); break;
                 case 3: hipLaunchKernelGGL(k_gemm_p0<3>, g0, dim3(256), 0, (hipStream_t)stream, rank2, WT, w.P0, rows, p.K, Kp, h.wc); break;
                 default: hipLaunchKernelGGL(k_gemm_p0<4>, g0, dim3(256), 0, (hipStream_t)stream, rank2, WT, w.P0, rows, p.K, Kp, h.wc); break;
@@ -610,16 +624,21 @@ static int launch_hf(const ccsd_plan* pl, int B, const float* rank2, RankEpi& ep
 #define HF_ARGS (const PlanD*)pl->d, (const float*)pl->w, rank2, (const float*)w.H, (const unsigned long long*)w.offbits, \
                 (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, ep, na, B, (MaskTab{w.mfr, w.mfl, w.Kp, w.Ep})
     const int fw = fnet_width(p);
+#define HF_AFF1(EC_, KC_) CCSD_LAUNCH((k_hf_score<true, 8, 1, EC_, KC_>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS)
+#define HF_GEN1(EC_, KC_) CCSD_LAUNCH((k_hf_score<false, 8, 1, EC_, KC_>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS)
 #define HF_GO(NP_) \
     do { \
-        if (p.f_affine && NP_ == 1 && p.E == 190 && p.K == 1140 && p.geo_off != 1) CCSD_LAUNCH((k_hf_score<true, 8, 1, 190, 1140>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS); \
+        if (p.f_affine && NP_ == 1) GEO_EK(p, HF_AFF1); \
         else if (p.f_affine) CCSD_LAUNCH((k_hf_score<true, 8, NP_>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS); \
+        else if (fw <= 8 && NP_ == 1) GEO_EK(p, HF_GEN1); \
         else if (fw <= 8) CCSD_LAUNCH((k_hf_score<false, 8, NP_>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS); \
         else if (fw <= CCSD_FW) CCSD_LAUNCH((k_hf_score<false, CCSD_FW, NP_>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS); \
         else CCSD_LAUNCH((k_hf_score<false, CCSD_FWMAX, NP_>), g, dim3(CCSD_NTHREADS), 0, stream, HF_ARGS); \
     } while (0)
     if (p.f_cnum <= 2) HF_GO(1); else HF_GO(CCSD_MAXCN - 1);
 #undef HF_GO
+#undef HF_AFF1
+#undef HF_GEN1
 #undef HF_ARGS
     prof_mark(const_cast<ccsd_plan*>(pl), KID_HF, stream);
     LAUNCH_CHECK();
@@ -638,7 +657,9 @@ static int launch_ew1(const ccsd_plan* pl, int B, const float* rank2, RankEpi& e
     if (a.apply) { a.sums = cf->sums; a.ss = cf->ss[2]; a.sde_alpha = cf->alpha[2]; a.snr = cf->snr; a.seps = cf->seps; a.draw_corr = cf->draw_r; }
     a.E = p.E; a.K = p.K; a.mt = MaskTab{w.mfr, w.mfl, w.Kp, w.Ep};
     prof_mark(const_cast<ccsd_plan*>(pl), KID_EW1, stream);
-    CCSD_LAUNCH(k_ew1, dim3(w.nchunk, B), dim3(CCSD_NTHREADS), 0, stream, a, na);
+#define EW1_GO(EC_, KC_) CCSD_LAUNCH((k_ew1<EC_, KC_>), dim3(w.nchunk, B), dim3(CCSD_NTHREADS), 0, stream, a, na)
+    GEO_EK(p, EW1_GO);
+#undef EW1_GO
     prof_mark(const_cast<ccsd_plan*>(pl), KID_EW1, stream);
     LAUNCH_CHECK();
     return CCSD_OK;
@@ -853,7 +874,9 @@ static int corrector_norms(ccsd_plan* pl, int B, int step, int it, const ccsd_st
         // k_hf_score and its chunk partials are reduced per sample first (one workgroup per sample), then over the batch
         const bool zk = na.flat_r && !na.zr && !pl->ew1;
         if (zk) {
-            CCSD_LAUNCH(k_noise_norm, dim3(w.nchunk, B), dim3(CCSD_NTHREADS), 0, stream, na, (MaskTab{w.mfr, w.mfl, w.Kp, w.Ep}), p.E, p.K, w.zpart);
+#define NN_GO(EC_, KC_) CCSD_LAUNCH((k_noise_norm<EC_, KC_>), dim3(w.nchunk, B), dim3(CCSD_NTHREADS), 0, stream, na, (MaskTab{w.mfr, w.mfl, w.Kp, w.Ep}), p.E, p.K, w.zpart)
+            GEO_EK(p, NN_GO);
+#undef NN_GO
             LAUNCH_CHECK();
         }
         if (zk || ntiles > 8) {
@@ -886,7 +909,9 @@ static int corrector_apply(ccsd_plan* pl, int B, int step, int it, const ccsd_st
     a.B = B; a.N = p.N; a.F = p.F; a.E = p.E; a.K = p.K; a.is_cc = p.is_cc;
     const long long total = (long long)B * (p.N * p.F + p.N * p.N) + (p.is_cc ? (long long)B * (((long long)p.E * p.K + 3) / 4) : 0);
     prof_mark(pl, KID_LANGEVIN, stream);
-    CCSD_LAUNCH(k_langevin_apply, dim3(grid_for(total, 256)), dim3(CCSD_NTHREADS), 0, stream, a, na, (MaskTab{w.mfr, w.mfl, w.Kp, w.Ep}));
+#define LA_GO(EC_, KC_) CCSD_LAUNCH((k_langevin_apply<EC_, KC_>), dim3(grid_for(total, 256)), dim3(CCSD_NTHREADS), 0, stream, a, na, (MaskTab{w.mfr, w.mfl, w.Kp, w.Ep}))
+    GEO_EK(p, LA_GO);
+#undef LA_GO
     prof_mark(pl, KID_LANGEVIN, stream);
     LAUNCH_CHECK();
     return CCSD_OK;

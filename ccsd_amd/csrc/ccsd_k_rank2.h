@@ -220,9 +220,10 @@ __global__ __launch_bounds__(256) void k_gemm_p(const float* __restrict__ rank2,
 // 16w..16w+15 and every 16-column tile, so no MFMA is spent on the 64-column padding of the general tile engine.
 // ---------------------------------------------------------------------------------------------
 #ifndef CCSD_EMU
-template <int NT>
+template <int NT, int KC = 0>          // KC: K as a compile-time constant (0: the argument); Kp follows
 __global__ __launch_bounds__(256) void k_gemm_p0(const float* __restrict__ rank2, const float* __restrict__ WT, float* __restrict__ P,
-                                                 int rows, int K, int Kp, int wc) {
+                                                 int rows, int K_, int Kp_, int wc) {
+    const int K = KC ? KC : K_, Kp = KC ? ((KC + 31) & ~31) : Kp_;
     __shared__ __align__(16) float As[T_BM * H_LD];
     __shared__ __align__(16) float Bs[16 * NT * H_LD];
     typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -76,8 +76,10 @@ __global__ void k_normpart(const float* __restrict__ part, int ntiles, const flo
 // cheaply; pure arithmetic, no rank2 traffic).  zpart[b][chunk] = sum over the chunk's groups of (z fl fr)^2
 // (gen_noise_rank2 + torch.norm, cc_utils.py:613-615, solver.py:793-797).  grid (nchunk, B); CH groups per workgroup.
 #define CCSD_NN_CH 4096
-__global__ void k_noise_norm(NoiseArgs na, MaskTab mt, int E, int K, float* __restrict__ zpart) {
+template <int EC = 0, int KC = 0>       // E, K as compile-time constants (0: the arguments): GEO_EK in ccsd_api.h
+__global__ void k_noise_norm(NoiseArgs na, MaskTab mt, int E_, int K_, float* __restrict__ zpart) {
     __shared__ float red[64];
+    const int E = EC ? EC : E_, K = KC ? KC : K_;
     const int b = blockIdx.y, EK = E * K, ng = (EK + 3) >> 2;
     const int g0 = blockIdx.x * CCSD_NN_CH, g1 = g0 + CCSD_NN_CH < ng ? g0 + CCSD_NN_CH : ng;
     const FastDiv dK(K);
@@ -124,7 +126,9 @@ CCSD_DEV void langevin_coef(const LangArgs& a, int t, float* c1, float* c2) {
     *c1 = step * a.ss[t];
     *c2 = sqrtf(step * 2.f) * a.seps;
 }
+template <int EC = 0, int KC = 0>       // E, K as compile-time constants (0: LangArgs'): GEO_EK in ccsd_api.h
 __global__ void k_langevin_apply(LangArgs a, NoiseArgs na, MaskTab mt) {
+    if (EC) { a.E = EC; a.K = KC; }
     const long long nxe = (long long)a.B * a.N * a.F, nae = (long long)a.B * a.N * a.N;
     // rank2: one thread per flat Philox group = four consecutive elements of the sample's (E, K) block (NoiseArgs::flat_r): with
     // E K a multiple of 4 every group is one aligned 16-byte load of the state, one of the raw score and one 16-byte store
@@ -203,8 +207,10 @@ struct Ew1Args {
     int E, K;
     MaskTab mt;                       // mask byte tables (k_masktab)
 };
+template <int EC = 0, int KC = 0>       // E, K as compile-time constants (0: Ew1Args'): GEO_EK in ccsd_api.h
 __global__ void k_ew1(Ew1Args a, NoiseArgs na) {
     __shared__ float red[64];
+    if (EC) { a.E = EC; a.K = KC; }
     const int b = blockIdx.y, EK = a.E * a.K, ng = (EK + 3) >> 2;
     const int g0 = blockIdx.x * CCSD_NN_CH, g1 = g0 + CCSD_NN_CH < ng ? g0 + CCSD_NN_CH : ng;
     const FastDiv dK(a.K);
