@@ -83,7 +83,7 @@ N_SIMDS, MAX_CLOCK_HZ = 1024, 2.4e9                       # 256 CUs x 4 SIMDs; M
 VALU_ISSUE_CYCLES = 2.65
 KERNEL_NAMES = ["k_xa", "k_r2", "k_hf_score", "k_gemm_h", "k_gemm_p", "k_langevin_apply", "k_s4_apply", "k_ew1"]
 PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json")]   # newest first
-KERNEL_SOURCES = [os.path.join(ROOT, "ccsd_amd", "csrc", f) for f in ("ccsd_dev.h", "ccsd_rank2_common.h", "ccsd_k_rank2.h", "ccsd_k_r2.h", "ccsd_k_xa.h", "ccsd_k_update.h", "ccsd_attn_stack.inc", "ccsd_plan.h", "ccsd_api.h", "ccsd_baked_qm9.h", "ccsd_baked_cs.h")]
+KERNEL_SOURCES = [os.path.join(ROOT, "ccsd_amd", "csrc", f) for f in ("ccsd_dev.h", "ccsd_rank2_common.h", "ccsd_k_rank2.h", "ccsd_k_r2.h", "ccsd_k_xa.h", "ccsd_k_update.h", "ccsd_attn_stack.inc", "ccsd_plan.h", "ccsd_api.h", "ccsd_baked_qm9.h", "ccsd_baked_cs.h", "ccsd_baked_z.h", "ccsd_baked_enz.h")]
 
 
 def kernel_source_hash() -> str:

@@ -13,7 +13,13 @@ static thread_local std::string g_last_error;
 static int set_err(int st, const std::string& m) { g_last_error = m; return st; }
 
 // the k_xa variant a plan needs, and its instantiation (for hipFuncSetAttribute)
-static inline int xa_variant(const PlanD& p) {
+static inline bool plan_is_baked(const PlanD& p, const unsigned char* baked, size_t baked_size) {
+    if (baked_size != sizeof(PlanD) || p.geo_off != 0) return false;
+    unsigned char bytes[sizeof(PlanD)];
+    ccsd_plan_arch_bytes(p, bytes);
+    return memcmp(bytes, baked, sizeof(PlanD)) == 0;
+}
+static inline int xa_variant_sem(const PlanD& p) {          // what the network needs: XA_PLAIN / XA_HB / XA_GMH / XA_GEN
     bool conv_mlp = false;
     for (int l = 0; l < p.a_L; ++l) conv_mlp = conv_mlp || p.al[l].conv_mlp;
     if (p.x_gmh) for (int l = 0; l < p.x_depth; ++l) conv_mlp = conv_mlp || p.gl[l].conv_mlp;
@@ -23,23 +29,21 @@ static inline int xa_variant(const PlanD& p) {
     if (!p.chan_global && !p.hb_L && p.a_fin.chain >= 5) return XA_GEN;
     if (p.hb_L) return XA_HB;
     if (p.x_gmh) return XA_GMH;
-    if (!p.chan_global && p.N == 9 && p.F == 4 && p.E == 36 && p.ldn == 16 && p.geo_off != 1) {
-        if (CCSD_BAKED_QM9_SIZE == sizeof(PlanD)) {       // the whole plan as a compile-time constant, if it is THE baked one
-            unsigned char bytes[sizeof(PlanD)];
-            ccsd_plan_arch_bytes(p, bytes);
-            if (memcmp(bytes, CCSD_BAKED_QM9_PLAN, sizeof(PlanD)) == 0) return XA_BAKED9;
-        }
-        return XA_PLAIN9;
-    }
-    if (p.chan_global && p.N == 20 && p.E == 190 && p.ldn == 24 && p.geo_off != 1) {
-        if (CCSD_BAKED_CS_SIZE == sizeof(PlanD)) {        // community_small_CC at batch 512: the whole plan baked
-            unsigned char bytes[sizeof(PlanD)];
-            ccsd_plan_arch_bytes(p, bytes);
-            if (memcmp(bytes, CCSD_BAKED_CS_PLAN, sizeof(PlanD)) == 0) return XA_BAKED20;
-        }
-        return XA_PLAIN20;
-    }
-    if (p.chan_global && p.N == 38 && p.E == 703 && p.ldn == 40 && p.geo_off != 1) return XA_PLAIN38;
+    return XA_PLAIN;
+}
+static inline int xa_variant(const PlanD& p) {
+    const int sem = xa_variant_sem(p);
+    // instances with the WHOLE plan as a compile-time constant: only for a plan whose architecture bytes equal a baked one's
+    // (tools/bake_plan.py; ccsd_baked_*.h), and only in the instantiation the bake was made for
+    if (sem == XA_PLAIN && !p.chan_global && plan_is_baked(p, CCSD_BAKED_QM9_PLAN, CCSD_BAKED_QM9_SIZE)) return XA_BAKED9;
+    if (sem == XA_PLAIN && p.chan_global && plan_is_baked(p, CCSD_BAKED_CS_PLAN, CCSD_BAKED_CS_SIZE)) return XA_BAKED20;
+    if (sem == XA_PLAIN && p.chan_global && plan_is_baked(p, CCSD_BAKED_Z_PLAN, CCSD_BAKED_Z_SIZE)) return XA_BAKED38;
+    if (sem == XA_GEN && !p.chan_global && plan_is_baked(p, CCSD_BAKED_ENZ_PLAN, CCSD_BAKED_ENZ_SIZE)) return XA_BAKEDENZ;
+    if (sem != XA_PLAIN || p.geo_off == 1) return sem;
+    // instances with the dataset geometry compiled in
+    if (!p.chan_global && p.N == 9 && p.F == 4 && p.E == 36 && p.ldn == 16) return XA_PLAIN9;
+    if (p.chan_global && p.N == 20 && p.E == 190 && p.ldn == 24) return XA_PLAIN20;
+    if (p.chan_global && p.N == 38 && p.E == 703 && p.ldn == 40) return XA_PLAIN38;
     return XA_PLAIN;
 }
 static inline const void* xa_kernel(const PlanD& p) {
@@ -48,9 +52,11 @@ static inline const void* xa_kernel(const PlanD& p) {
                    v == XA_GEN ? (const void*)k_xa<G_, XA_GEN> : (const void*)k_xa<G_, XA_PLAIN>)
     if (v == XA_PLAIN9) return (const void*)k_xa<false, XA_PLAIN9>;
     if (v == XA_BAKED9) return (const void*)k_xa<false, XA_BAKED9>;
+    if (v == XA_BAKEDENZ) return (const void*)k_xa<false, XA_BAKEDENZ>;
     if (v == XA_PLAIN20) return (const void*)k_xa<true, XA_PLAIN20>;
     if (v == XA_BAKED20) return (const void*)k_xa<true, XA_BAKED20>;
     if (v == XA_PLAIN38) return (const void*)k_xa<true, XA_PLAIN38>;
+    if (v == XA_BAKED38) return (const void*)k_xa<true, XA_BAKED38>;
     return p.chan_global ? XA_FN(true) : XA_FN(false);
 #undef XA_FN
 }
@@ -168,12 +174,7 @@ static inline int r2_qm9(const ccsd_plan* pl) {
     const PlanD& p = pl->h;
     const bool gen1 = p.h_L > 1 && p.hl[0].mval.n > 1;
     if (p.geo_off == 1 || !p.f_affine || gen1 || p.E != 36 || p.K != 466 || p.N != 9 || pl->r2_ldk != 488 || pl->r2_ldh != 36) return 0;
-    if (CCSD_BAKED_QM9_SIZE == sizeof(PlanD)) {
-        unsigned char bytes[sizeof(PlanD)];
-        ccsd_plan_arch_bytes(p, bytes);
-        if (memcmp(bytes, CCSD_BAKED_QM9_PLAN, sizeof(PlanD)) == 0) return 2;
-    }
-    return 1;
+    return plan_is_baked(p, CCSD_BAKED_QM9_PLAN, CCSD_BAKED_QM9_SIZE) ? 2 : 1;
 }
 static inline const void* r2_kernel(const ccsd_plan* pl) {
     if (r2_qm9(pl) == 2) return (const void*)k_r2<3, 1, true, false, 2>;
@@ -603,6 +604,7 @@ static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Work
         else if (variant == XA_PLAIN20) XA_GO(true, XA_PLAIN20, xa, xblk, xlds, stream);
         else if (variant == XA_BAKED20) XA_GO(true, XA_BAKED20, xa, xblk, xlds, stream);
         else if (variant == XA_PLAIN38) XA_GO(true, XA_PLAIN38, xa, xblk, xlds, stream);
+        else if (variant == XA_BAKED38) XA_GO(true, XA_BAKED38, xa, xblk, xlds, stream);
         else XA_GO(true, XA_PLAIN, xa, xblk, xlds, stream);
     } else {
         if (variant == XA_HB) XA_GO(false, XA_HB, xa, xblk, xlds, stream);
@@ -610,6 +612,7 @@ static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Work
         else if (variant == XA_GEN) XA_GO(false, XA_GEN, xa, xblk, xlds, stream);
         else if (variant == XA_PLAIN9) XA_GO(false, XA_PLAIN9, xa, xblk, xlds, stream);
         else if (variant == XA_BAKED9) XA_GO(false, XA_BAKED9, xa, xblk, xlds, stream);
+        else if (variant == XA_BAKEDENZ) XA_GO(false, XA_BAKEDENZ, xa, xblk, xlds, stream);
         else XA_GO(false, XA_PLAIN, xa, xblk, xlds, stream);
     }
 #undef XA_GO

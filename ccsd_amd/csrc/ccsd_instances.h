@@ -33,11 +33,13 @@ CCSD_INST __global__ void k_xa<false, XA_GMH> CCSD_XA_SIG;
 CCSD_INST __global__ void k_xa<false, XA_GEN> CCSD_XA_SIG;
 CCSD_INST __global__ void k_xa<false, XA_PLAIN9> CCSD_XA_SIG;
 CCSD_INST __global__ void k_xa<false, XA_BAKED9> CCSD_XA_SIG;
+CCSD_INST __global__ void k_xa<false, XA_BAKEDENZ> CCSD_XA_SIG;
 CCSD_INST __global__ void k_xa<true, XA_PLAIN> CCSD_XA_SIG;
 CCSD_INST __global__ void k_xa<true, XA_HB> CCSD_XA_SIG;
 CCSD_INST __global__ void k_xa<true, XA_GMH> CCSD_XA_SIG;
 CCSD_INST __global__ void k_xa<true, XA_GEN> CCSD_XA_SIG;
 CCSD_INST __global__ void k_xa<true, XA_PLAIN20> CCSD_XA_SIG;
 CCSD_INST __global__ void k_xa<true, XA_BAKED20> CCSD_XA_SIG;
+CCSD_INST __global__ void k_xa<true, XA_BAKED38> CCSD_XA_SIG;
 CCSD_INST __global__ void k_xa<true, XA_PLAIN38> CCSD_XA_SIG;
 #endif

@@ -3,6 +3,8 @@
 #pragma once
 #include "ccsd_baked_qm9.h"
 #include "ccsd_baked_cs.h"
+#include "ccsd_baked_z.h"
+#include "ccsd_baked_enz.h"
 #include "ccsd_rank2_common.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -11,15 +13,19 @@
 #define XA_PLAIN 0
 #define XA_HB 1
 #define XA_GMH 2
+#define XA_GEN 3          /* everything, selected at run time from the plan: both of the above together, conv = "MLP" */
 #define XA_PLAIN9 4       /* XA_PLAIN with the qm9 geometry compiled in: N = 9, E = 36, F = 4, ldn = 16 (index arithmetic folds to constants) */
 #define XA_BAKED9 7       /* XA_PLAIN9 with the WHOLE plan of the qm9_CC configuration (batch 1024) as a compile-time constant (ccsd_baked_qm9.h) */
+#define XA_BAKED38 9      /* XA_PLAIN38 with the whole plan of the zinc250k configuration (graph-only, batch 256) baked (ccsd_baked_z.h) */
+#define XA_BAKEDENZ 10    /* XA_GEN with the whole plan of the ENZYMES_small_CC configuration (S4 sampler, batch 64) baked (ccsd_baked_enz.h) */
 #define XA_BAKED20 8      /* XA_PLAIN20 with the whole plan of the community_small_CC configuration (batch 512) baked (ccsd_baked_cs.h) */
 #define XA_PLAIN20 5      /* XA_PLAIN, channel stack in HBM, community_small geometry: N = 20, E = 190, ldn = 24 */
 #define XA_PLAIN38 6      /* XA_PLAIN, channel stack in HBM, zinc250k geometry: N = 38, E = 703, ldn = 40 */
 // node count a variant has compiled in (0: run-time geometry); E = N (N - 1) / 2 and the node-row stride round_ld(N) follow
-static constexpr int xa_geo_n(int var) { return (var == XA_PLAIN9 || var == XA_BAKED9) ? 9 : (var == XA_PLAIN20 || var == XA_BAKED20) ? 20 : var == XA_PLAIN38 ? 38 : 0; }
+static constexpr int xa_geo_n(int var) { return (var == XA_PLAIN9 || var == XA_BAKED9) ? 9 : (var == XA_PLAIN20 || var == XA_BAKED20) ? 20 : (var == XA_PLAIN38 || var == XA_BAKED38) ? 38 : 0; }
+// what a variant IS (which network features it carries), baked or not
+static constexpr int xa_sem(int var) { return var == XA_BAKEDENZ ? XA_GEN : (var == XA_HB || var == XA_GMH || var == XA_GEN) ? var : XA_PLAIN; }
 static constexpr int xa_geo_ld(int n) { return ((n + 7) / 8 * 8) % 32 == 0 ? (n + 7) / 8 * 8 + 8 : (n + 7) / 8 * 8; }   // == round_ld (ccsd_plan.h)
-#define XA_GEN 3          /* everything, selected at run time from the plan: both of the above together, conv = "MLP" */
 struct XaArgs {
     // inputs: the X-network and the A-network may see different (x, adj) when the Langevin
     // corrector runs more than one inner step (solver.py:759-784)
@@ -189,10 +195,15 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
     // the baked ones; the placeholder header of a tree without a bake leaves it reading the plan from memory like XA_PLAIN9)
     constexpr bool BAKED9 = VAR == XA_BAKED9 && CCSD_BAKED_QM9_SIZE == sizeof(PlanD);
     constexpr bool BAKED20 = VAR == XA_BAKED20 && CCSD_BAKED_CS_SIZE == sizeof(PlanD);
-    constexpr bool BAKED = BAKED9 || BAKED20;
-    const PlanD& p = BAKED9 ? *reinterpret_cast<const PlanD*>(CCSD_BAKED_QM9_PLAN) : BAKED20 ? *reinterpret_cast<const PlanD*>(CCSD_BAKED_CS_PLAN) : *plan;
-    constexpr int BAKED_UNROLL = BAKED9 ? CCSD_BAKED_QM9_A_L : BAKED20 ? CCSD_BAKED_CS_A_L : 1;      // unroll count of the AttentionLayer loop (ccsd_attn_stack.inc)
-    constexpr bool HB = VAR == XA_HB || VAR == XA_GEN, GMH = VAR == XA_GMH || VAR == XA_GEN, CONVMLP = VAR == XA_GEN;
+    constexpr bool BAKED38 = VAR == XA_BAKED38 && CCSD_BAKED_Z_SIZE == sizeof(PlanD);
+    constexpr bool BAKEDENZ = VAR == XA_BAKEDENZ && CCSD_BAKED_ENZ_SIZE == sizeof(PlanD);
+    constexpr bool BAKED = BAKED9 || BAKED20 || BAKED38 || BAKEDENZ;
+    const PlanD& p = BAKED9 ? *reinterpret_cast<const PlanD*>(CCSD_BAKED_QM9_PLAN) : BAKED20 ? *reinterpret_cast<const PlanD*>(CCSD_BAKED_CS_PLAN)
+                   : BAKED38 ? *reinterpret_cast<const PlanD*>(CCSD_BAKED_Z_PLAN) : BAKEDENZ ? *reinterpret_cast<const PlanD*>(CCSD_BAKED_ENZ_PLAN) : *plan;
+    // unroll count of the AttentionLayer loop (ccsd_attn_stack.inc)
+    constexpr int BAKED_UNROLL = BAKED9 ? CCSD_BAKED_QM9_A_L : BAKED20 ? CCSD_BAKED_CS_A_L : BAKED38 ? CCSD_BAKED_Z_A_L : BAKEDENZ ? CCSD_BAKED_ENZ_A_L : 1;
+    constexpr int SEM = xa_sem(VAR);
+    constexpr bool HB = SEM == XA_HB || SEM == XA_GEN, GMH = SEM == XA_GMH || SEM == XA_GEN, CONVMLP = SEM == XA_GEN;
     // XA_PLAIN9: a third of k_xa's vector instructions are 32-bit integer index arithmetic on strides the plan supplies at run
     // time (PMC, profiles/r03_c_phase_mix.txt); for the headline geometry they are compile-time constants (xa_variant() checks them)
     constexpr bool NFIX = VAR == XA_PLAIN9 || VAR == XA_BAKED9;          // everything fixed incl. F and the thread count
@@ -248,7 +259,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
 
     // ================= ScoreNetworkX (ScoreNetwork_X.py:102-132) =================
     // (see xnet_late_stage) both networks on the same inputs, plan permitting: only the input load + fused corrector stay here
-    const bool x_late = (VAR == XA_PLAIN || NFIX) && !GCH && p.x_late && xa.do_x && xa.do_a && xa.xA == xa.xX && xa.adjA == xa.adjX;
+    const bool x_late = SEM == XA_PLAIN && !GCH && p.x_late && xa.do_x && xa.do_a && xa.xA == xa.xX && xa.adjA == xa.adjX;
     if (x_late) {
         // Everything the launch reads from HBM at its start is requested in ONE batch and meets ONE barrier: the inputs, the raw
         // scores and norm sums of the fused corrector apply (same expressions as corr_apply_xa, the flags read from global memory
@@ -468,7 +479,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
             const HodgeLayerD& h0 = p.hl[0];
             stage_mlp_blocks(p.hl[0].matt, w, s_hw, t0, ts);
             if (p.h_L > 1) stage_mlp_blocks(p.hl[1].matt, w, s_hw + p.hw_stride, t0, ts);
-            if (VAR == XA_GEN) for (int l = 2; l < p.h_L; ++l) stage_mlp_blocks(ccsd_hl(p, l).matt, w, s_hw + l * p.hw_stride, t0, ts);
+            if (SEM == XA_GEN) for (int l = 2; l < p.h_L; ++l) stage_mlp_blocks(ccsd_hl(p, l).matt, w, s_hw + l * p.hw_stride, t0, ts);
             // adj_to_hodgedual (cc_utils.py:1525-1536): diagonal hodge adjacency = upper triangle of the adjacency powers;
             // DenseHCNConv on a diagonal matrix (hodge_layers.py:185-193) is a row scaling
             for (int t = t0; t < p.a_cinit * E; t += ts) {
@@ -489,7 +500,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                 }
             }
         };
-        const bool hodge_on = VAR != XA_HB && p.h_L > 0;
+        const bool hodge_on = SEM != XA_HB && p.h_L > 0;
         const bool hodge_idle = hodge_on && x_late && p.a_L >= 3;
         if (hodge_on && !hodge_idle) hodge_early(tid, nth);
 #define ATTN_LAYERS p.al
@@ -509,7 +520,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
         stamp(xa.dbg, 12);
         prio_phase(prio_k++);
         // ---- hodge branch of ScoreNetworkA_CC (ScoreNetwork_A_CC.py:295-316)
-        if (VAR != XA_HB && p.h_L > 0) {
+        if (SEM != XA_HB && p.h_L > 0) {
             float* s_hd = sm + p.o_hd;          // [hodge channel][E]: diagonals that reach the final MLP
             float* s_hq = sm + p.o_hq;          // [channel][E][2*adim]
             float* s_h1m = s_R;                 // [cout0][E][E] dense output of the first hodge layer
@@ -521,7 +532,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
             const int qw0 = 2 * h0.adim;
             // row stride of the first layer's Q|K rows: odd (qw0 is even), so that the lanes of the dense pair loop -- consecutive
             // edges e2 -- read a Q|K element from 32 different banks instead of 4 (the general layer loop keeps the packed rows)
-            const int ldq0 = VAR == XA_GEN ? qw0 : qw0 + 1;
+            const int ldq0 = SEM == XA_GEN ? qw0 : qw0 + 1;
             const FastDiv dqw0(qw0), dEqw0(E * qw0);
             const float* P0b = xa.P0 + (size_t)b * E * h0.wc;
             float* s_p1c = s_hd + p.a_nch_hodge * E;
@@ -556,7 +567,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                         if (o < h0.cout) { const float tv = tanh_f(out[o] * fh * fh); s_hd[(p.a_cinit + o) * E + e] = tv + tv; }
                 }
                 __syncthreads();
-            } else if (VAR != XA_GEN || p.h_L == 2) {
+            } else if (SEM != XA_GEN || p.h_L == 2) {
                 // dense E x E attention of every channel, mlp_attention, mask, tanh, + transpose (hodge_attention.py:315-320):
                 // one thread per unordered pair (e <= e2) from the pair table, both halves stored
                 const HodgeLayerD& h1 = p.hl[1];
@@ -673,7 +684,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                             }
                     }
                 };
-                if (VAR != XA_GEN && h0.cin == 2 && h0.cout == 4 && h0.adim == 4 && h0.nchunk == 2 && h0.dsplit == 2 && h0.matt.n == 1 && w4_0)
+                if (SEM != XA_GEN && h0.cin == 2 && h0.cout == 4 && h0.adim == 4 && h0.nchunk == 2 && h0.dsplit == 2 && h0.matt.n == 1 && w4_0)
                     dense_pairs(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});     // (the qm9_CC shape)
                 else
                     dense_pairs(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -817,7 +828,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                         if (o < h1.cout) { const float tv = tanh_f(out[o] * fh * fh); s_hd[(p.a_cinit + h0.cout + o) * E + e] = tv + tv; }
                 }
                 __syncthreads();
-            } else if constexpr (VAR == XA_GEN) {
+            } else if constexpr (SEM == XA_GEN) {
                 // ---- three or four HodgeAdjAttentionLayers (num_linears_h == 1): the general layer loop.
                 // Layer l >= 1 sees the dense hodge adjacency H^l [cin_l][E][E] (the previous layer's output) and the rank-2
                 // features R_l = the l-fold mlp_value image of rank2 (hodge_attention.py:322-323):
@@ -1137,7 +1148,7 @@ __global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict
                 auto epf = [&](int e, int f, float v) { (void)f; const int i = edge_i(e), j = edge_j(e); f0[i * N + j] = v; f0[j * N + i] = v; };
                 // (the two widest shapes set the register demand of this whole region: the small-graph XA_PLAIN / XA_GMH variants leave them
                 // to k_xa<false, XA_GEN> -- xa_variant() routes such plans there -- and run without them)
-                constexpr bool WIDE = GCH || VAR == XA_GEN || VAR == XA_HB;
+                constexpr bool WIDE = GCH || SEM == XA_GEN || SEM == XA_HB;
                 if (m.chain == 3) mlp_chain<2, 4, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
                 else if (m.chain == 4) mlp_chain<3, 5, 1>(m, wp, s_chan, NN, s_chan, m.in, E, pair_off, epf);
                 else if constexpr (WIDE) {

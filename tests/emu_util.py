@@ -7,7 +7,7 @@ from ccsd_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "emu", "ccsd_emu.cpp")
 OUT = os.path.join(ROOT, "tests", "emu", "_build", "libccsd_emu.so")
-DEPS = [SRC] + [os.path.join(ROOT, "ccsd_amd", "csrc", f) for f in ("ccsd_rt.h", "ccsd_plan.h", "ccsd_kernels.h", "ccsd_dev.h", "ccsd_rank2_common.h", "ccsd_k_rank2.h", "ccsd_k_r2.h", "ccsd_k_xa.h", "ccsd_k_update.h", "ccsd_attn_stack.inc", "ccsd_api.h", "ccsd_baked_qm9.h", "ccsd_baked_cs.h", "ccsd_instances.h")] + \
+DEPS = [SRC] + [os.path.join(ROOT, "ccsd_amd", "csrc", f) for f in ("ccsd_rt.h", "ccsd_plan.h", "ccsd_kernels.h", "ccsd_dev.h", "ccsd_rank2_common.h", "ccsd_k_rank2.h", "ccsd_k_r2.h", "ccsd_k_xa.h", "ccsd_k_update.h", "ccsd_attn_stack.inc", "ccsd_api.h", "ccsd_baked_qm9.h", "ccsd_baked_cs.h", "ccsd_baked_z.h", "ccsd_baked_enz.h", "ccsd_instances.h")] + \
        [os.path.join(ROOT, "include", "ccsd_hip.h")]
 
 _emu = None

@@ -801,41 +801,47 @@ def case_kat_hodge_layers(lib, device):
 
 
 def case_geometry_instances_bitwise(lib, device, B=64, steps=3, name="ccsd_qm9_CC", counts=(9, 9, 8, 7, 9, 5, 9, 3, 6, 9, 2, 9), expect=(4, 0),
-                                    predictor="Reverse", snr=0.2):
-    """The instances of k_xa / k_r2 with the qm9 geometry compiled in (N = 9, E = 36, K = 466, the LDS strides: ccsd_k_xa.h XA_PLAIN9,
-    ccsd_k_r2.h QM9) against the run-time-geometry instances of the same kernels (a plan created with CCSD_NO_GEO set): the same
-    arithmetic in the same order -- only index computations fold -- so the production loop must agree BIT FOR BIT, and so must the
-    three scores.  Also checks that the qm9 plan really selects the specialised instances."""
+                                    predictor="Reverse", snr=0.2, corrector="Langevin", scale_eps=0.7):
+    """The kernel instances with compile-time geometry or a compile-time plan (k_xa XA_PLAIN9 / XA_BAKED*, k_r2 QM9, the (E, K)
+    instances of the general-path kernels) against the run-time instances of the same source (a plan created with CCSD_NO_GEO set):
+    the same arithmetic in the same order -- only index computations, loop bounds and branches fold -- so the production loop must
+    agree BIT FOR BIT, and so must the scores.  Also checks which k_xa instance the plan selects (`expect`: specialised, plain)."""
     meta, parts = load_ckpt_np(name)
-    cfg = meta["config"]
+    cfg, is_cc = meta["config"], meta["is_cc"]
     N, Fd = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
-    d_min, d_max = cfg["data"]["d_min"], cfg["data"]["d_max"]
+    names = ["x", "adj"] + (["rank2"] if is_cc else [])
     flags = make_flags(B, N, list(counts)).to(device)
-    kw = dict(shape_x=(B, N, Fd), shape_adj=(B, N, N), predictor=predictor, corrector="Langevin", snr=snr, scale_eps=0.7, n_steps=1,
-              probability_flow=False, continuous=True, denoise=True, eps=1e-4, is_cc=True, shape_rank2=(B, *rank2_dim(N, d_min, d_max)),
-              d_min=d_min, d_max=d_max)
-    sd = [loader.load_sde(cfg["sde"][p]) for p in ("x", "adj", "rank2")]
-    ms = [loader.load_model_from_ckpt(meta[f"params_{p}"], parts[p], device) for p in ("x", "adj", "rank2")]
+    kw = dict(shape_x=(B, N, Fd), shape_adj=(B, N, N), predictor=predictor, corrector=corrector, snr=snr, scale_eps=scale_eps, n_steps=1,
+              probability_flow=False, continuous=True, denoise=True, eps=1e-4)
+    if is_cc:
+        d_min, d_max = cfg["data"]["d_min"], cfg["data"]["d_max"]
+        kw.update(is_cc=True, shape_rank2=(B, *rank2_dim(N, d_min, d_max)), d_min=d_min, d_max=d_max)
+    sd = [loader.load_sde(cfg["sde"][p]) for p in names]
+    ms = [loader.load_model_from_ckpt(meta[f"params_{p}"], parts[p], device) for p in names]
+    skw = dict(sde_x=sd[0], sde_adj=sd[1])
+    if is_cc:
+        skw["sde_rank2"] = sd[2]
+    make = solver.S4_solver if predictor == "S4" else solver.get_pc_sampler
     outs, variants = [], []
     old = os.environ.pop("CCSD_NO_GEO", None)
     try:
         for off in (False, True):
             if off:
                 os.environ["CCSD_NO_GEO"] = "1"
-            fn = solver.get_pc_sampler(device=device, rng="philox", seed=11, max_steps=steps, lib=lib, sde_x=sd[0], sde_adj=sd[1], sde_rank2=sd[2], **kw)
+            fn = make(device=device, rng="philox", seed=11, max_steps=steps, lib=lib, **skw, **kw)
             res = fn(*ms, flags)
             eng = fn.engine()
             variants.append(eng.query("xa_variant"))
             st = eng.alloc_state(B)
             eng.init_state(flags, st, None, 3, 0)
-            scores = [eng.score(t, st[0], st[1], st[2], flags).clone() for t in range(3)]
-            outs.append([r.clone() for r in res[:3]] + scores)
+            scores = [eng.score(t, st[0], st[1], st[2] if is_cc else None, flags).clone() for t in range(len(names))]
+            outs.append([r.clone() for r in res[:len(names)]] + scores)
             os.environ.pop("CCSD_NO_GEO", None)
     finally:
         os.environ.pop("CCSD_NO_GEO", None)
         if old is not None:
             os.environ["CCSD_NO_GEO"] = old
     if device != "cpu":
-        assert variants == list(expect), f"k_xa variants selected: {variants} (expected the compile-time-geometry instance, then the plain one)"
+        assert variants == list(expect), f"k_xa variants selected: {variants} (expected the specialised instance, then the plain one)"
     for k, (a, b) in enumerate(zip(*outs)):
-        assert torch.equal(a, b), f"tensor {k}: compile-time-geometry instance != run-time-geometry instance (max diff {(a - b).abs().max().item():.3e})"
+        assert torch.equal(a, b), f"{name} tensor {k}: specialised instance != run-time instance (max diff {(a - b).abs().max().item():.3e})"

@@ -1,6 +1,8 @@
 """GPU suite (-m gpu): the HIP library on a real MI355X through the C ABI, against the reference goldens
 (captured from the reference on CPU) and the CPU oracle on the same seeded inputs."""
 import pytest
+
+import bench
 import torch
 
 from tests import parity_cases as pc
@@ -349,3 +351,10 @@ def test_geometry_instances_match_runtime_geometry_bitwise(lib):
                                        predictor="Euler", snr=0.05)
     pc.case_geometry_instances_bitwise(lib, DEV, B=512, steps=2, name="ccsd_community_small_CC", counts=(20, 12, 16, 18, 14, 20), expect=(5, 0),
                                        predictor="Euler", snr=0.06)
+    # zinc250k (graph-only, N = 38, batch 256): k_xa<true, XA_BAKED38>;  ENZYMES_small_CC (S4 sampler, batch 64): k_xa<false, XA_BAKEDENZ>
+    # (the general variant, baked) and the (66, 715) instances of the tiled rank-2 kernels
+    wz, we = bench.WORKLOADS["zinc250k"], bench.WORKLOADS["enzymes_small_CC"]
+    pc.case_geometry_instances_bitwise(lib, DEV, B=256, steps=2, name="gdss_zinc250k", counts=(38, 30, 24, 36, 20), expect=(9, 0),
+                                       predictor=wz["predictor"], corrector=wz["corrector"], snr=wz["snr"], scale_eps=wz["scale_eps"])
+    pc.case_geometry_instances_bitwise(lib, DEV, B=64, steps=2, name="ccsd_enzymes_small_CC", counts=(12, 10, 8, 11, 6), expect=(10, 3),
+                                       predictor=we["predictor"], corrector=we["corrector"], snr=we["snr"], scale_eps=we["scale_eps"])

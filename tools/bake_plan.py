@@ -15,7 +15,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 # (macro name, bench workload, header): the configurations whose k_xa / k_r2 instances have the plan compiled in
-TARGETS = [("QM9", "qm9_CC", "ccsd_baked_qm9.h"), ("CS", "community_small_CC", "ccsd_baked_cs.h")]
+TARGETS = [("QM9", "qm9_CC", "ccsd_baked_qm9.h"), ("CS", "community_small_CC", "ccsd_baked_cs.h"), ("Z", "zinc250k", "ccsd_baked_z.h"),
+           ("ENZ", "enzymes_small_CC", "ccsd_baked_enz.h")]
+# (not qm9_Base_CC: with the plan baked hipcc unrolls the HodgeBaseline layers into 300 spilled VGPRs)
 
 import bench  # noqa: E402
 from ccsd_amd import loader  # noqa: E402
@@ -28,12 +30,14 @@ def make_engine(workload, lib):
     """The engine (hence the plan) of a bench workload at its bench batch, on the host emulation."""
     wl = bench.WORKLOADS[workload]
     meta, parts = load_ckpt_np(wl["ckpt"])
-    cfg = meta["config"]
-    sdes = [loader.load_sde(cfg["sde"][p]) for p in ("x", "adj", "rank2")]
-    return PCEngine(meta["params_x"], parts["x"], meta["params_adj"], parts["adj"], meta["params_rank2"], parts["rank2"],
-                    N=cfg["data"]["max_node_num"], F=cfg["data"]["max_feat_num"], is_cc=True, d_min=cfg["data"]["d_min"],
-                    d_max=cfg["data"]["d_max"], sdes=sdes, predictor=wl["predictor"], corrector=wl["corrector"], snr=wl["snr"],
-                    scale_eps=wl["scale_eps"], n_steps=1, denoise=True, eps=1e-4, device="cpu", batch_hint=wl["batch"], lib=lib)
+    cfg, is_cc = meta["config"], meta["is_cc"]
+    names = ["x", "adj"] + (["rank2"] if is_cc else [])
+    sdes = [loader.load_sde(cfg["sde"][p]) for p in names]
+    kw = dict(d_min=cfg["data"]["d_min"], d_max=cfg["data"]["d_max"]) if is_cc else {}
+    return PCEngine(meta["params_x"], parts["x"], meta["params_adj"], parts["adj"], meta.get("params_rank2") if is_cc else None,
+                    parts.get("rank2") if is_cc else None, N=cfg["data"]["max_node_num"], F=cfg["data"]["max_feat_num"], is_cc=is_cc, sdes=sdes,
+                    predictor=wl["predictor"], corrector=wl["corrector"], snr=wl["snr"], scale_eps=wl["scale_eps"], n_steps=1, denoise=True,
+                    eps=1e-4, device="cpu", batch_hint=wl["batch"], lib=lib, **kw)
 
 
 def bake(name, workload, out_path, lib):
