@@ -173,12 +173,14 @@ static inline void r2_shape(const ccsd_plan* pl, int* MT, int* RS, bool* aff, bo
 static inline int r2_qm9(const ccsd_plan* pl) {
     const PlanD& p = pl->h;
     const bool gen1 = p.h_L > 1 && p.hl[0].mval.n > 1;
-    if (p.geo_off == 1 || !p.f_affine || gen1 || p.E != 36 || p.K != 466 || p.N != 9 || pl->r2_ldk != 488 || pl->r2_ldh != 36) return 0;
+    if (p.geo_off == 1 || gen1 || p.E != 36 || p.K != 466 || p.N != 9 || pl->r2_ldk != 488 || pl->r2_ldh != 36) return 0;
+    if (!p.f_affine) return 3;                           // k_r2<3, 0, false, false, 1>: the non-affine network on the qm9 geometry
     return plan_is_baked(p, CCSD_BAKED_QM9_PLAN, CCSD_BAKED_QM9_SIZE) ? 2 : 1;
 }
 static inline const void* r2_kernel(const ccsd_plan* pl) {
     if (r2_qm9(pl) == 2) return (const void*)k_r2<3, 1, true, false, 2>;
     if (r2_qm9(pl) == 1) return (const void*)k_r2<3, 1, true, false, 1>;
+    if (r2_qm9(pl) == 3) return (const void*)k_r2<3, 0, false, false, 1>;
     const void* fn = nullptr;
 #define R2_PTR(MT_, RS_, A_, G_) fn = (const void*)k_r2<MT_, RS_, A_, G_>
     R2_DISPATCH(pl, R2_PTR);
@@ -693,6 +695,9 @@ static int launch_r2(const ccsd_plan* pl, int B, const float* rank2, const float
                     (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, ra, ep, na);
     } else if (qm9 == 1) {
         CCSD_LAUNCH((k_r2<3, 1, true, false, 1>), dim3(B), blk, pl->r2_lds, stream, (const PlanD*)pl->d, (const float*)pl->w,
+                    (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, ra, ep, na);
+    } else if (qm9 == 3) {
+        CCSD_LAUNCH((k_r2<3, 0, false, false, 1>), dim3(B), blk, pl->r2_lds, stream, (const PlanD*)pl->d, (const float*)pl->w,
                     (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, ra, ep, na);
     } else
     R2_DISPATCH(pl, R2_GO);

@@ -24,6 +24,7 @@ CCSD_R2_ONE(1, 0) CCSD_R2_ONE(1, 1) CCSD_R2_ONE(1, 2) CCSD_R2_ONE(1, 3)
 #endif
 #ifdef CCSD_INST_R2_D
 CCSD_R2_GEN(1) CCSD_R2_GEN(2) CCSD_R2_GEN(3) CCSD_R2_GEN(4)
+CCSD_INST __global__ void k_r2<3, 0, false, false, 1> CCSD_R2_SIG;     // non-affine ScoreNetworkF, the qm9 geometry compiled in (qm9_Base_CC)
 #endif
 #define CCSD_XA_SIG (const PlanD* __restrict__, const float* __restrict__, const unsigned char* __restrict__, XaArgs, NoiseArgs)
 #ifdef CCSD_INST_XA

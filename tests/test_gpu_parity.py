@@ -351,6 +351,8 @@ def test_geometry_instances_match_runtime_geometry_bitwise(lib):
                                        predictor="Euler", snr=0.05)
     pc.case_geometry_instances_bitwise(lib, DEV, B=512, steps=2, name="ccsd_community_small_CC", counts=(20, 12, 16, 18, 14, 20), expect=(5, 0),
                                        predictor="Euler", snr=0.06)
+    # qm9_Base_CC: k_xa stays the run-time-plan HodgeBaseline instance (1, 1); its non-affine k_r2 runs with the qm9 geometry compiled in
+    pc.case_geometry_instances_bitwise(lib, DEV, B=64, steps=2, name="ccsd_qm9_Base_CC", expect=(1, 1))
     # zinc250k (graph-only, N = 38, batch 256): k_xa<true, XA_BAKED38>;  ENZYMES_small_CC (S4 sampler, batch 64): k_xa<false, XA_BAKEDENZ>
     # (the general variant, baked) and the (66, 715) instances of the tiled rank-2 kernels
     wz, we = bench.WORKLOADS["zinc250k"], bench.WORKLOADS["enzymes_small_CC"]
