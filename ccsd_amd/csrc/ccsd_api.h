@@ -426,12 +426,15 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
         else { X(0, 0); } \
     } while (0)
 
+#define CCSD_P_SPLITS 8     /* most K slices k_gemm_p is split into when its row tiles cannot fill the chip */
+
 // ---------------- workspace ----------------
 struct Workspace {
     unsigned long long* offbits;
     unsigned char *mfr, *mfl;       // flag masks of every complex as byte tables (k_masktab): [B][Kp], [B][Ep]
     int Kp, Ep;
     float *H, *P0, *P1, *U1, *acoef, *net_x, *net_adj, *net_r, *norm2, *part, *sums, *chan, *zpart, *part2;
+    float* psplit;                  // K slices of the layer-1 projection (k_gemm_p with few row tiles)
     float *P0b, *P1b, *U1b;         // second set of hodge projections (merged k_r2 launch: the next norms pass's)
     int ntiles, nchunk;
     int p1_raw;     // who filled P1 last: k_r2 with the raw factors (1, see k_r2) or k_gemm_p with the finished projections (0)
@@ -451,6 +454,7 @@ static Workspace carve_ws(const ccsd_plan* pl, int B, void* base) {
     w.P0 = (float*)take(p.h_L > 0 ? (size_t)B * E * p.hl[0].wc * 4 : 0);
     w.P1 = (float*)take(p.h_L > 1 ? (size_t)B * E * p.h_pw * 4 : 0);
     w.U1 = (float*)take(p.h_L > 1 ? (size_t)B * p.h_pw * 4 : 0);
+    w.psplit = (float*)take(p.h_L > 1 && !pl->fused_r2 ? (size_t)CCSD_P_SPLITS * B * E * p.h_pw * 4 : 0);   // K slices of k_gemm_p (small batches)
     const bool two = pl->fused_r2 != 0;
     w.P0b = (float*)take(two && p.h_L > 0 ? (size_t)B * E * p.hl[0].wc * 4 : 0);
     w.P1b = (float*)take(two && p.h_L > 1 ? (size_t)B * E * p.h_pw * 4 : 0);
@@ -568,7 +572,7 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
 #endif
         CCSD_LAUNCH(k_gemm_p, g, dim3(CCSD_NTHREADS), 0, stream, rank2, (const float*)pl->w, w.P0, rows, p.E, p.K, h.wc,
                     h.wcat, 0, h.mval, h.cin, (const float*)nullptr, (const unsigned long long*)w.offbits,
-                    (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells);
+                    (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, p.K);
         prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_P, stream);
         LAUNCH_CHECK();
     }
@@ -579,10 +583,23 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
         const HodgeLayerD& h0 = p.hl[0];
         const HodgeLayerD& h = p.hl[1];
         dim3 g((h.wc + T_BN - 1) / T_BN, (rows + T_BM - 1) / T_BM, 1);
-        CCSD_LAUNCH(k_gemm_p, g, dim3(CCSD_NTHREADS), 0, stream, rank2, (const float*)pl->w, w.P1, rows, p.E, p.K, h.wc,
+        // few row tiles (small batches: ENZYMES_small_CC at B = 64 has 66): split K over up to CCSD_P_SPLITS slices, summed in a fixed order
+        const int tiles = (int)(g.x * g.y), nslab = (p.K + T_BK - 1) / T_BK;
+        int S = tiles >= 256 ? 1 : (512 + tiles - 1) / tiles;
+        if (S > CCSD_P_SPLITS) S = CCSD_P_SPLITS;
+        if (S > nslab) S = nslab;
+        const int kchunk = ((nslab + S - 1) / S) * T_BK;
+        S = (p.K + kchunk - 1) / kchunk;
+        g.z = S;
+        CCSD_LAUNCH(k_gemm_p, g, dim3(CCSD_NTHREADS), 0, stream, rank2, (const float*)pl->w, S > 1 ? w.psplit : w.P1, rows, p.E, p.K, h.wc,
                     h.wcat, 1, h0.mval, h0.cin, (const float*)w.acoef, (const unsigned long long*)w.offbits,
-                    (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells);
+                    (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, kchunk);
         LAUNCH_CHECK();
+        if (S > 1) {
+            const long long n = (long long)rows * h.wc;
+            CCSD_LAUNCH(k_sum_splits, dim3(grid_for(n, 256)), dim3(CCSD_NTHREADS), 0, stream, (const float*)w.psplit, w.P1, n, S);
+            LAUNCH_CHECK();
+        }
     }
     return CCSD_OK;
 }

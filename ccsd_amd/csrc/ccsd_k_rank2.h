@@ -166,20 +166,24 @@ __global__ __launch_bounds__(256) void k_gemm_p(const float* __restrict__ rank2,
                                                 int layer, MlpD mval, int cin, const float* __restrict__ acoef,
                                                 const unsigned long long* __restrict__ offbits,
                                                 const unsigned char* __restrict__ edges,
-                                                const unsigned long long* __restrict__ cells) {
+                                                const unsigned long long* __restrict__ cells, int kchunk) {
     __shared__ float As[T_BK * T_LD];
     __shared__ float Bs[T_BK * T_LD];
     __shared__ float s_mv[CCSD_MAXLIN * CCSD_HWBLK];   // mlp_value as zero-padded 8x8 blocks (LDS broadcast reads)
     const int m0 = blockIdx.y * T_BM, n0 = blockIdx.x * T_BN;
+    // split K (small batches: too few 64-row tiles to fill the chip): slice blockIdx.z sums k in [z kchunk, (z + 1) kchunk) into its own
+    // copy of P (P + z rows wc); k_sum_splits adds the slices in a fixed order.  kchunk >= K with gridDim.z == 1: the whole sum, in place.
+    const int kbeg = (int)blockIdx.z * kchunk, kend = kbeg + kchunk < K ? kbeg + kchunk : K;
+    P += (size_t)blockIdx.z * rows * wc;
     const float* Wc = W + wcat_off;
     TileAcc acc;
     tile_zero(acc);
     if (layer == 1) { stage_mlp_blocks(mval, W, s_mv, (int)threadIdx.x, (int)blockDim.x); __syncthreads(); }
-    for (int k0 = 0; k0 < K; k0 += T_BK) {
+    for (int k0 = kbeg; k0 < kend; k0 += T_BK) {
         for (int idx = threadIdx.x; idx < T_BM * T_BK; idx += blockDim.x) {
             const int r = idx / T_BK, kk = idx % T_BK, k = k0 + kk, row = m0 + r;
             float v = 0.f;
-            if (row < rows && k < K) {
+            if (row < rows && k < kend) {
                 v = rank2[(size_t)row * K + k];
                 if (layer == 1) {
                     const int b = row / E, e = row % E;
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256) void k_gemm_p(const float* __restrict__ rank2,
         }
         for (int idx = threadIdx.x; idx < T_BK * T_BN; idx += blockDim.x) {
             const int kk = idx / T_BN, c = idx % T_BN, k = k0 + kk, col = n0 + c;
-            Bs[kk * T_LD + c] = (k < K && col < wc) ? Wc[(size_t)k * wc + col] : 0.f;
+            Bs[kk * T_LD + c] = (k < kend && col < wc) ? Wc[(size_t)k * wc + col] : 0.f;
         }
         __syncthreads();
         tile_mma(acc, As, Bs);
@@ -210,6 +214,14 @@ __global__ __launch_bounds__(256) void k_gemm_p(const float* __restrict__ rank2,
             if (m < rows) P[(size_t)m * wc + n] = v[s];
         }
     });
+}
+// k_sum_splits: P[i] = parts[0][i] + parts[1][i] + ... (the K slices of k_gemm_p, always in this order: reproducible)
+__global__ void k_sum_splits(const float* __restrict__ parts, float* __restrict__ P, long long n, int S) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float acc = parts[i];
+        for (int z = 1; z < S; ++z) acc += parts[(size_t)z * n + i];
+        P[i] = acc;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
