@@ -434,7 +434,7 @@ struct Workspace {
     unsigned char *mfr, *mfl;       // flag masks of every complex as byte tables (k_masktab): [B][Kp], [B][Ep]
     int Kp, Ep;
     float *H, *P0, *P1, *U1, *acoef, *net_x, *net_adj, *net_r, *norm2, *part, *sums, *chan, *zpart, *part2;
-    float* psplit;                  // K slices of the layer-1 projection (k_gemm_p with few row tiles)
+    float* psplit; size_t psplit_floats;   // K slices of the layer-1 projection (k_gemm_p with few row tiles)
     float *P0b, *P1b, *U1b;         // second set of hodge projections (merged k_r2 launch: the next norms pass's)
     int ntiles, nchunk;
     int p1_raw;     // who filled P1 last: k_r2 with the raw factors (1, see k_r2) or k_gemm_p with the finished projections (0)
@@ -454,7 +454,9 @@ static Workspace carve_ws(const ccsd_plan* pl, int B, void* base) {
     w.P0 = (float*)take(p.h_L > 0 ? (size_t)B * E * p.hl[0].wc * 4 : 0);
     w.P1 = (float*)take(p.h_L > 1 ? (size_t)B * E * p.h_pw * 4 : 0);
     w.U1 = (float*)take(p.h_L > 1 ? (size_t)B * p.h_pw * 4 : 0);
-    w.psplit = (float*)take(p.h_L > 1 && !pl->fused_r2 ? (size_t)CCSD_P_SPLITS * B * E * p.h_pw * 4 : 0);   // K slices of k_gemm_p (small batches)
+    // K slices of k_gemm_p (few row tiles: small batches; the step-wise score / norms calls of fused-rank-2 plans use k_gemm_p too)
+    w.psplit_floats = p.h_L > 1 && (long long)B * E < 256 * T_BM ? (size_t)CCSD_P_SPLITS * B * E * p.h_pw : 0;
+    w.psplit = (float*)take(w.psplit_floats * 4);
     const bool two = pl->fused_r2 != 0;
     w.P0b = (float*)take(two && p.h_L > 0 ? (size_t)B * E * p.hl[0].wc * 4 : 0);
     w.P1b = (float*)take(two && p.h_L > 1 ? (size_t)B * E * p.h_pw * 4 : 0);
@@ -588,6 +590,7 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
         int S = tiles >= 256 ? 1 : (512 + tiles - 1) / tiles;
         if (S > CCSD_P_SPLITS) S = CCSD_P_SPLITS;
         if (S > nslab) S = nslab;
+        if ((size_t)S * rows * h.wc > w.psplit_floats) S = 1;     // (no room for slices: the whole sum in place)
         const int kchunk = ((nslab + S - 1) / S) * T_BK;
         S = (p.K + kchunk - 1) / kchunk;
         g.z = S;
