@@ -410,28 +410,32 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
     // permutation (row stride 68: 4 * 68 == 16 mod 32 keeps the four kq groups on disjoint banks).  Next slab's global
     // loads are issued before the MFMAs of the current one.
     constexpr int BLD = 68;
-    __shared__ __align__(16) float As[T_BM * H_LD];
-    __shared__ __align__(16) float Bs[H_BK * BLD];
+    // contraction slab: 32 wide; 64 in the instances with a compile-time E (half as many barriers and global round trips per tile --
+    // the contraction over E is short: 190 for community_small)
+    constexpr int HBK = EC ? 64 : H_BK, HLD = HBK + 8;       // (HLD == 8 mod 32: conflict-free ds_read_b128 fragments)
+    constexpr int RPP = 256 / HBK, NA = T_BM / RPP, NB = HBK / 16;
+    __shared__ __align__(16) float As[T_BM * HLD];
+    __shared__ __align__(16) float Bs[HBK * BLD];
     {
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         const int tid = threadIdx.x, wave = wave_index(), lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
         const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
         const bool vec = (K & 3) == 0;
-        // A slab 64 x 32: thread -> (row ar + 8u, column ak), u < 8 (scalar: E is not 16-byte friendly in general)
-        const int ar = tid >> 5, ak = tid & 31;
-        // B slab 32 x 64: thread -> (k row bk + 16u, 4-float column group bc4), u < 2
+        // A slab 64 x HBK: thread -> (row ar + RPP u, column ak), u < NA (scalar: E is not 16-byte friendly in general)
+        const int ar = tid / HBK, ak = tid % HBK;
+        // B slab HBK x 64: thread -> (k row bk + 16u, 4-float column group bc4), u < NB
         const int bk = tid >> 4, bc4 = (tid & 15) * 4;
-        float ra[8];
-        float4 rb[2];
+        float ra[NA];
+        float4 rb[NB];
         auto load_slab = [&](int k0) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int row = m0 + ar + 8 * u, k = k0 + ak;
+            for (int u = 0; u < NA; ++u) {
+                const int row = m0 + ar + RPP * u, k = k0 + ak;
                 const float v = Hb[(size_t)(row < E ? row : E - 1) * E + (k < E ? k : E - 1)];
                 ra[u] = (row < E && k < E) ? v : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < NB; ++u) {
                 const int k = k0 + bk + 16 * u, col = n0 + bc4;
                 const float* src = Fb + (size_t)(k < E ? k : E - 1) * K;
                 float4 v;
@@ -445,18 +449,18 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
             }
         };
         load_slab(0);
-        for (int k0 = 0; k0 < E; k0 += H_BK) {
+        for (int k0 = 0; k0 < E; k0 += HBK) {
             __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 8; ++u) As[(ar + 8 * u) * H_LD + ak] = ra[u];
+            for (int u = 0; u < NA; ++u) As[(ar + RPP * u) * HLD + ak] = ra[u];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) *reinterpret_cast<float4*>(Bs + (bk + 16 * u) * BLD + bc4) = rb[u];
+            for (int u = 0; u < NB; ++u) *reinterpret_cast<float4*>(Bs + (bk + 16 * u) * BLD + bc4) = rb[u];
             __syncthreads();
-            if (k0 + H_BK < E) load_slab(k0 + H_BK);
+            if (k0 + HBK < E) load_slab(k0 + HBK);
 #pragma unroll
-            for (int t = 0; t < H_BK / 16; ++t) {
-                const float4 a0 = *reinterpret_cast<const float4*>(As + (wm + l15) * H_LD + 16 * t + 4 * kq);
-                const float4 a1 = *reinterpret_cast<const float4*>(As + (wm + 16 + l15) * H_LD + 16 * t + 4 * kq);
+            for (int t = 0; t < HBK / 16; ++t) {
+                const float4 a0 = *reinterpret_cast<const float4*>(As + (wm + l15) * HLD + 16 * t + 4 * kq);
+                const float4 a1 = *reinterpret_cast<const float4*>(As + (wm + 16 + l15) * HLD + 16 * t + 4 * kq);
                 const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
                 float bv0[4], bv1[4];
 #pragma unroll
