@@ -156,7 +156,9 @@ int ccsd_noise_draws(ccsd_plan_t* plan, int32_t B, const float* flags_dev, uint6
 /* Which kernels a plan selected (host-side facts, no device work). */
 enum {
     CCSD_QUERY_FUSED_R2 = 0,      /* 1: the LDS-resident fused rank-2 kernel k_r2 serves the rank-2 side; 0: the tiled kernels */
-    CCSD_QUERY_XA_VARIANT = 1,    /* instantiation of the graph-network kernel k_xa: 0 plain, 1 HodgeBaseline, 2 X_GMH, 3 general */
+    CCSD_QUERY_XA_VARIANT = 1,    /* instantiation of the graph-network kernel k_xa: 0 plain, 1 HodgeBaseline, 2 X_GMH, 3 general; 4 / 5 / 6 plain with
+                                     the qm9 / community_small / zinc250k geometry compiled in; 7 .. 10 the whole plan of a shipped configuration
+                                     compiled in (qm9_CC, community_small_CC, zinc250k, ENZYMES_small_CC at their bench batch) */
     CCSD_QUERY_R2_LDS_BYTES = 2,
     CCSD_QUERY_XA_LDS_BYTES = 3,
     CCSD_QUERY_FUSED_LOOP = 4,    /* 1: ccsd_sampler_run fuses the Langevin apply into the predictor launches */
