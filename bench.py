@@ -35,7 +35,6 @@ QM9_HIST = {9: 10949, 8: 1757, 7: 294, 6: 60, 5: 15, 4: 5, 3: 1, 2: 1}   # data/
 COMMUNITY_HIST = {12: 29, 14: 14, 16: 23, 18: 25, 20: 9}                 # data/community_small.pkl
 PEAK_F32_MFMA_TFLOPS = 157.3                              # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_HBM_GBPS = 8000.0
-MFMA_FLOP = 2048                                          # one wave-level v_mfma_f32_16x16x4_f32
 # Workloads = BASELINE.json configs.  flop_* : dense-as-written GEMM FLOPs / complex / forward (FlopCounterMode on
 # the reference).  The default (the configuration the metric is quoted on) is qm9_CC, B = 1024 per GPU.
 WORKLOADS = {
@@ -82,7 +81,15 @@ N_SIMDS, MAX_CLOCK_HZ = 1024, 2.4e9                       # 256 CUs x 4 SIMDs; M
 # transcendentals 8.3; the plain-FMA figure is used for every instruction, so issue_frac is a lower bound
 VALU_ISSUE_CYCLES = 2.65
 KERNEL_NAMES = ["k_xa", "k_r2", "k_hf_score", "k_gemm_h", "k_gemm_p", "k_langevin_apply", "k_s4_apply", "k_ew1"]
-PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json")]   # newest first
+MFMA_F32_FLOP_PER_BUSY_CYCLE = 64                         # 2048 FLOP / 32 cycles (16x16x4) = 512 FLOP / 8 cycles (4x4x1 16B): both fp32 shapes
+WARMUP_MIN_SECONDS = 0.25                                 # the warm-up call is repeated until the device has been busy this long
+
+
+def pmc_files():
+    """Committed per-launch PMC summaries (tools/pmc_traffic.py), newest round first; each names its workload in `_meta`."""
+    import glob
+
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc*.json")), reverse=True)
 KERNEL_SOURCES = [os.path.join(ROOT, "ccsd_amd", "csrc", f) for f in ("ccsd_dev.h", "ccsd_rank2_common.h", "ccsd_k_rank2.h", "ccsd_k_r2.h", "ccsd_k_xa.h", "ccsd_k_update.h", "ccsd_attn_stack.inc", "ccsd_plan.h", "ccsd_api.h", "ccsd_baked_qm9.h", "ccsd_baked_cs.h", "ccsd_baked_z.h", "ccsd_baked_enz.h")]
 
 
@@ -99,7 +106,7 @@ def pmc_counters(workload: str, kernel: str):
     """Per-launch PMC means of `kernel` from the newest committed rocprofv3 --pmc passes (separate runs: FETCH_SIZE doubled
     -- gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md HBM section --, WRITE_SIZE as is).  They are NOT
     measured in this run: the object says which file they come from and whether the kernel source has changed since."""
-    for path in PMC_FILES:
+    for path in pmc_files():
         try:
             d = json.load(open(path))
         except Exception:
@@ -258,9 +265,10 @@ def kernel_work(wname: str, kname: str, E: int, K: int):
     return None, None, ""
 
 
-def roofline_obj(wname, kname, kt, B, dt, E, K):
-    """kt = (bracketed launches, their summed ms, all launches in the timed region)."""
-    sampled, kms, total = kt
+def roofline_obj(wname, kname, kt, B, ms_per_step, E, K):
+    """kt = (bracketed launches, their summed ms, all launches of the kernel-event pass, steps of that pass); ms_per_step = the timed
+    region's (un-instrumented) step time."""
+    sampled, kms, total, ksteps = kt
     if not sampled:
         return None
     avg_s = kms / sampled * 1e-3
@@ -271,8 +279,8 @@ def roofline_obj(wname, kname, kt, B, dt, E, K):
     mfma_frac = flops * B / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS if flops else None
     if hbm_frac is not None and mfma_frac is not None:     # both figures exist: the binding roofline is the larger fraction
         bound = "mfma" if mfma_frac >= hbm_frac else "hbm"
-    o = {"kernel": kname, "bound": bound, "launches": total, "launches_timed": sampled, "avg_launch_us": avg_s * 1e6,
-         "share_of_step": total * avg_s / dt, "traffic": None, "hbm_frac": hbm_frac, "mfma_frac_as_written": mfma_frac}
+    o = {"kernel": kname, "bound": bound, "launches_per_step": total / ksteps, "launches_timed": sampled, "event_pass_steps": ksteps,
+         "avg_launch_us": avg_s * 1e6, "share_of_step": (total / ksteps) * avg_s / (ms_per_step * 1e-3), "traffic": None, "hbm_frac": hbm_frac, "mfma_frac_as_written": mfma_frac}
     if kname in KERNEL_LIMITER:
         o["limiter"] = KERNEL_LIMITER[kname]
     if pmc:
@@ -281,16 +289,24 @@ def roofline_obj(wname, kname, kt, B, dt, E, K):
         o["traffic_source"] = f"{pmc['source']} (rocprofv3 --pmc passes collected at {pmc['collected_at_commit']}; replayed, not measured in this run)"
         o["traffic_stale"] = pmc["stale"]
         mf = c.get("SQ_INSTS_VALU_MFMA_F32")
+        busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES")
         if mf:
-            ex = mf * MFMA_FLOP / avg_s / 1e12
+            # executed matrix FLOPs from the pipe's BUSY CYCLES (PMC), not from the instruction count: the kernels mix
+            # v_mfma_f32_16x16x4_f32 (2048 FLOP, 32 cycles) with v_mfma_f32_4x4x1_16B_f32 (512 FLOP, 8 cycles) -- both 64 FLOP per busy
+            # cycle --, so pricing every MFMA at 2048 FLOP overstates k_r2.  Without the busy counter: 32 cycles each.
+            busy_cyc = busy if busy else mf * 32.0
+            ex = busy_cyc * MFMA_F32_FLOP_PER_BUSY_CYCLE / avg_s / 1e12
             o["executed_mfma_tflops"] = ex
             o["executed_frac"] = ex / PEAK_F32_MFMA_TFLOPS       # what the matrix pipe actually did (dead GEMMs skipped, padding included)
+            o["mfma_busy_frac"] = busy_cyc / (N_SIMDS * MAX_CLOCK_HZ * avg_s)   # == executed_frac: 157.3 TF = 1024 SIMDs x 64 FLOP x 2.4 GHz
+            o["mfma_cycles_per_instruction"] = busy_cyc / mf
             va = c.get("SQ_INSTS_VALU")
             if va:
                 # vector-issue cycles per launch: the matrix instructions' busy cycles (PMC; 32 per fp32 16x16x4 MFMA, 8.8 per 4x4x1)
                 # + VALU_ISSUE_CYCLES per other VALU wave-instruction (SQ_INSTS_VALU counts the MFMAs too), over what 1024 SIMDs offer
                 # at the 2.4 GHz maximum clock in the launch's time
-                cyc = (c.get("SQ_VALU_MFMA_BUSY_CYCLES") or mf * 32.0) + max(va - mf, 0.0) * VALU_ISSUE_CYCLES
+                cyc = busy_cyc + max(va - mf, 0.0) * VALU_ISSUE_CYCLES
+                o["valu_wave_instructions"] = va
                 o["issue_cycles_per_launch"] = cyc
                 o["issue_frac"] = cyc / (N_SIMDS * MAX_CLOCK_HZ * avg_s)
     if bound == "mfma" and flops and flops * B / avg_s / 1e12 > PEAK_F32_MFMA_TFLOPS and o.get("executed_mfma_tflops"):
@@ -298,14 +314,14 @@ def roofline_obj(wname, kname, kt, B, dt, E, K):
         # work (k_xa: unordered pairs instead of N x N, masked rows, MLP tiles of real width), so the executed MFMA rate is the honest figure
         o.update(achieved=o["executed_mfma_tflops"], peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=o["executed_frac"],
                  as_written_tflops=flops * B / avg_s / 1e12,
-                 note=f"achieved = MFMA instructions per launch (PMC) x 2048 FLOP / mean launch time; the as-written model-FLOPs convention ({what}) "
+                 note=f"achieved = MFMA busy cycles per launch (PMC) x 64 FLOP / mean launch time; the as-written model-FLOPs convention ({what}) "
                       "gives as_written_tflops, above the fp32 MFMA peak because the kernel legally skips most of that work")
     elif bound == "mfma" and flops:
         a = flops * B / avg_s / 1e12
         o.update(achieved=a, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=a / PEAK_F32_MFMA_TFLOPS,
                  note=f"achieved = {what} per launch / mean launch time (HIP events on the launch stream): the as-written model-FLOPs "
-                      "convention, which counts GEMMs the kernel legally skips; executed_frac = MFMA instructions (PMC) x 2048 FLOP / time "
-                      "is the pipe utilisation; fp32 MFMA peak")
+                      "convention, which counts GEMMs the kernel legally skips; executed_frac = MFMA busy cycles (PMC) x 64 FLOP / time "
+                      "is the pipe utilisation (= mfma_busy_frac); fp32 MFMA peak")
     elif bound == "hbm" and nbytes:
         a = nbytes * B / avg_s / 1e9
         o.update(achieved=a, peak=PEAK_HBM_GBPS, unit="GB/s", frac=a / PEAK_HBM_GBPS,
@@ -418,19 +434,32 @@ def _main(real_stdout):
             torch.cuda.synchronize()
 
     log(f"rank {rank}/{world}: {wname}, B={B} per GPU, warm-up {args.warmup} steps (builds the plan)")
-    run(max(1, args.warmup))
+    # Warm-up: W steps (the first call also builds the plan).  A W-step call of a few milliseconds leaves the device at idle
+    # clocks, so the same call is repeated until the device has been busy for WARMUP_MIN_SECONDS (untimed; reported as
+    # `warmup_steps_run`): the timed region then starts at the clocks a production run -- 1000 steps per call -- sees.
+    wsteps = max(1, args.warmup)
+    run(wsteps)
+    warm_run = wsteps
+    if dev != "cpu":
+        torch.cuda.synchronize()
+        tw0 = time.perf_counter()
+        run(wsteps)
+        torch.cuda.synchronize()
+        t1 = max(time.perf_counter() - tw0, 1e-4)
+        reps = torch.tensor([min(int(WARMUP_MIN_SECONDS / t1), 5000)], device=dev, dtype=torch.int64)
+        if world > 1:                               # every rank must make the same number of (collective) closure calls
+            dist.all_reduce(reps, op=dist.ReduceOp.MAX)
+        for _ in range(int(reps.item())):
+            run(wsteps)
+        torch.cuda.synchronize()
+        warm_run += wsteps * (1 + int(reps.item()))
     eng = inner.engine()
     E, K = eng.E, eng.K
     global MERGED_R2
     MERGED_R2 = bool(eng.query("merged_r2"))
-    if not args.no_kernel_events:
-        for kname in KERNEL_NAMES:                   # HIP events around those kernels' launches, on their stream
-            eng.profile_kernel(kname)
-        # every n-th launch: dense bracketing costs ~6 % of the step.  Short runs bracket more densely so that the roofline
-        # object always has samples.
-        eng.profile_stride(args.event_stride if args.steps >= 200 else 3 if args.steps >= 20 else 1)
     if world > 1:
         sampling_fn.timing, sampling_fn.gather_seconds = True, 0.0   # split [local loop | final all-gather] per rank (diagnostic)
+    # ---- the timed region: exactly K steps, un-instrumented (no HIP events between the dispatches)
     sync()
     t0 = time.perf_counter()
     outs = run(args.steps)
@@ -439,6 +468,20 @@ def _main(real_stdout):
     dt_local = time.perf_counter() - t0                              # this rank's own time, before it waits for the others
     sync()
     dt = time.perf_counter() - t0
+    # ---- kernel-event pass, AFTER the timed region (an event record between two dispatches breaks back-to-back issue: dense
+    # bracketing costs ~6 % of the step): the same steps again (at most 200) with every n-th launch of a kernel bracketed
+    ksteps = 0
+    if not args.no_kernel_events:
+        for kname in KERNEL_NAMES:                   # HIP events around those kernels' launches, on their stream
+            eng.profile_kernel(kname)
+        ksteps = min(args.steps, 200)
+        eng.profile_stride(args.event_stride if ksteps >= 200 else 3 if ksteps >= 20 else 1)
+        gs = getattr(sampling_fn, "gather_seconds", 0.0)
+        run(ksteps)
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        if world > 1:
+            sampling_fn.gather_seconds = gs          # (the per-rank split below belongs to the timed region)
     per_rank = None
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -460,7 +503,7 @@ def _main(real_stdout):
         for k in KERNEL_NAMES:
             tot = eng.profile_launches(k)
             n, ms = eng.profile_read(k)
-            ktimes[k] = (n, ms, tot)
+            ktimes[k] = (n, ms, tot, ksteps)
         eng.profile_kernel(None)
     nt = 3 if is_cc else 2
     ok = all(torch.isfinite(t).all().item() for t in outs[:nt]) and all(t.shape[0] == total for t in outs[:nt])
@@ -475,14 +518,14 @@ def _main(real_stdout):
         state_floats = N * F + N * N + E * K
         line = {
             "metric": "sampled complexes/sec at 1000 PC steps, QM9_CC batch=1024, 1/2/4/8 GPU",
-            "value": value, "unit": "complexes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "complexes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_steps_run": warm_run,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": f"synthetic (node-count histogram flags, Philox N(0,1) prior/noise; shipped {wl['ckpt']} weights)",
             "config": {"workload": wl["desc"].format(B=B), "global_batch": total,
                        "parallelism": f"batch-sharded x{world}, per-shard Langevin norms, all-gather at end",
                        "timed_region": "load_sampling_fn -> sampling_fn(models, init_flags): prior draw + PC steps (+ final all-gather)",
                        "finite": ok},
-            "roofline": roofline_obj(wname, dominant, ktimes[dominant], B, dt, E, K) if dominant else None,
+            "roofline": roofline_obj(wname, dominant, ktimes[dominant], B, ms_per_step, E, K) if dominant else None,
             "cpu_baseline": None,
         }
         if per_rank is not None:     # per-rank split of the timed region: PC-step time without the final all-gather, and the all-gather
@@ -490,7 +533,7 @@ def _main(real_stdout):
         if args.emulate:
             line["data"] = "EMULATION (host CPU, test of the launcher path only): " + line["data"]
         for k in live[1:]:
-            line[f"roofline_{k}"] = roofline_obj(wname, k, ktimes[k], B, dt, E, K)
+            line[f"roofline_{k}"] = roofline_obj(wname, k, ktimes[k], B, ms_per_step, E, K)
         if wl["flop_x"] is not None:
             line["achieved_model_tflops"] = evals * (wl["flop_x"] + wl["flop_a"] + wl["flop_f"]) * units_per_s / 1e12
         line["achieved_state_gbps"] = 2 * evals * state_floats * 4 * units_per_s / 1e9

@@ -3,13 +3,14 @@
 bench line's launch time belongs to; for k_xa the norms and predictor launches differ by a few percent either way)"""
 import csv, glob, sys, collections, json, os
 
+KNAMES = ("k_xa", "k_r2", "k_hf_score", "k_gemm_h", "k_gemm_p", "k_langevin_apply", "k_noise_norm", "k_s4_apply", "k_ew1")
 out = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[1:]:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         per = collections.defaultdict(float)
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
-            k = "k_xa" if "k_xa" in name else "k_r2" if "k_r2" in name else None
+            k = next((n for n in KNAMES if n in name), None)     # (k_gemm_p0 counts as k_gemm_p: the same GEMM, narrow instance)
             if k is None:
                 continue
             per[(k, r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
