@@ -100,6 +100,7 @@ struct ccsd_plan {
     int opt_xa_prio = 0;                                       // CCSD_XA_PRIO (diagnostic: k_xa issue-priority scheme)
     int opt_xa_stagger_mask = 0, opt_xa_stagger_sleep = 0;     // CCSD_XA_STAGGER="mask,sleep" (diagnostic)
     int opt_no_merge = 0;                                      // CCSD_NO_MERGE (diagnostic: separate norms / predictor k_r2 launches)
+    int opt_r2_masked = 1;                                     // CCSD_NO_R2_MASKED clears it (diagnostic: the loop's k_r2 launches re-mask rank2 in the Q_1 loader)
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     unsigned prof_mask = 0;
     size_t prof_used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -266,6 +267,7 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     pl->opt_old_gemm_p = getenv("CCSD_OLD_GEMM_P") != nullptr;
     pl->opt_no_fused_apply = getenv("CCSD_NO_FUSED_APPLY") != nullptr;
     pl->opt_no_merge = getenv("CCSD_NO_MERGE") != nullptr;
+    pl->opt_r2_masked = getenv("CCSD_NO_R2_MASKED") == nullptr;
     if (const char* pr = getenv("CCSD_XA_PRIO")) pl->opt_xa_prio = atoi(pr);
     if (const char* sg = getenv("CCSD_XA_STAGGER")) sscanf(sg, "%d,%d", &pl->opt_xa_stagger_mask, &pl->opt_xa_stagger_sleep);
     if (const char* sg = getenv("CCSD_R2_STAGGER")) sscanf(sg, "%d,%d", &pl->opt_r2_stagger_mask, &pl->opt_r2_stagger_sleep);
@@ -696,6 +698,8 @@ static int launch_r2(const ccsd_plan* pl, int B, const float* rank2, const float
                      RankEpi& ep, NoiseArgs& na, Workspace& w, void* stream, const CorrFuse* cf = nullptr, int merge_draw = -1) {
     R2Args ra{};
     if (cf) ra.cf = *cf;
+    // launches of the sampler loop that carry the fused corrector apply work on states this library produced: masked (R2Args::masked)
+    ra.masked = (cf && cf->on && pl->opt_r2_masked) ? 1 : 0;
     if (merge_draw >= 0) {
         ra.merge = 1; ra.draw_r2 = (unsigned)merge_draw;
         ra.P0b = w.P0b; ra.P1b = w.P1b; ra.U1b = w.U1b; ra.net2 = w.net_r; ra.part2 = w.part;
@@ -1112,6 +1116,10 @@ extern "C" int ccsd_sampler_run(ccsd_plan_t* pl, int32_t B, const float* flags, 
             const bool r2_done = merged && step > first_step;
             const bool merge_next = merged && !lastone;
             if ((st = corrector_norms(pl, B, step, 0, &a, &a, flags, nullptr, seed, sample_offset, w.sums, w, stream, /*keep_net=*/pl->fused_r2 != 0, r2_done))) return st;
+            // u_1 = fr . Wcat_1 depends on the flags alone: the run's first (general) k_r2 launch has just written it; the masked launches
+            // of the loop leave both copies alone (R2Args::masked), so the second buffer set gets its copy once
+            if (merged && !r2_done && pl->opt_r2_masked && p.h_L > 1 && p.hl[0].mval.n == 1)
+                RT_CHECK(rt_d2d_async(w.U1b, w.U1, (size_t)B * p.h_pw * 4, stream));
             if ((st = predictor(pl, B, step, &a, flags, nullptr, seed, sample_offset, &b, want_mean ? result : nullptr, w, stream, w.sums, merge_next))) return st;
             ccsd_state_t t = a; a = b; b = t;
         } else if (lang) {   // a -> (corrector) -> b -> (predictor) -> a

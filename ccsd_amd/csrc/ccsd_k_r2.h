@@ -13,6 +13,11 @@ struct R2Args {
     float* P0; float* P1;
     float* U1;             // [B][wc_1]: fr . Wcat_1 of the complex (linear mlp_value: P1 then holds the raw (F o fr) Wcat_1)
     int want_p;            // write the hodge projections (the A-network will run on the same state)
+    // The caller guarantees that the rank2 state is MASKED (fl F fr == F bit for bit: every state ccsd_init_state or an update epilogue
+    // of this library produced).  The sampler loop's launches (ccsd_sampler_run) set it: the layer-1 projection factor Q_1 = (F o fr) Wcat_1
+    // is then a plain F Wcat_1 tile (no cell-mask conversion / product per element in its loader), and u_1 = fr . Wcat_1 -- a function of
+    // the flags alone -- is not recomputed: U1 / U1b keep what the run's first (general) launch wrote.
+    int masked;
     int stagger_mask, stagger_sleep;   // workgroups with (blockIdx.x & mask) != 0 start `sleep` x 64 cycles late (see launch_r2)
     // Merged launch (ccsd_sampler_run, E = 36 geometry): the predictor half-step of PC step i, then -- on the new rank2 block, which
     // the epilogue also wrote back into LDS -- the norms pass of the corrector of step i + 1 (its ScoreNetworkF score to HBM, both
@@ -183,8 +188,18 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
                                     const float zz = z[j] * m[j];
-                                    if (ZN) s_z = fmaf(zz, zz, s_z);
+                                    if (ZN && !CF) s_z = fmaf(zz, zz, s_z);
                                     if (CF) vv[j] = fmaf(c2f, zz, fmaf(c1f, nn[j], vv[j]));
+                                }
+                                if (CF && ZN) {
+                                    // merged launch: the noise norm of the NEXT step's corrector draw (the norms pass that follows in this
+                                    // launch needs it) is taken here too -- same groups, same masks, the same per-thread order as the norms
+                                    // launch's own block load (bitwise the same sum) -- while this phase waits for its loads; it used to be a
+                                    // loop of its own ahead of the second pass, where nothing hid its ~100 vector instructions per group
+                                    float z2[4];
+                                    philox_normal4(na.seed, ra.draw_r2, na.b_off + b, (unsigned)i4, z2);
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) { const float zz = z2[j] * m[j]; s_z = fmaf(zz, zz, s_z); }
                                 }
                             }
                             *reinterpret_cast<float2*>(sF + e * ldk + k) = make_float2(vv[0], vv[1]);
@@ -210,7 +225,8 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
             };
             typedef std::integral_constant<bool, true> T_;
             typedef std::integral_constant<bool, false> F_;
-            if (ra.cf.on) phase0(std::integral_constant<int, 3>{}, T_{}, F_{});
+            if (ra.cf.on && ra.merge) phase0(std::integral_constant<int, 3>{}, T_{}, T_{});
+            else if (ra.cf.on) phase0(std::integral_constant<int, 3>{}, T_{}, F_{});
             else if (znorm) phase0(std::integral_constant<int, 3>{}, F_{}, T_{});
             else phase0(std::integral_constant<int, 3>{}, F_{}, F_{});
         } else {
@@ -262,25 +278,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
 #ifndef CCSD_EMU
         if (tid == 0) s_hdone = 0;
 #endif
-        // noise norm of the next corrector draw: the groups and the order of the norms launch's block load (bitwise the same sum)
-        {
-            const int EK = E * K, n4 = EK >> 2;
-            const FastDiv dK2(K >> 1);
-            for (int base = tid; base < n4; base += nth) {
-                float z[4];
-                philox_normal4(na.seed, na.draw_r, na.b_off + b, (unsigned)base, z);
-                int e, kp;
-                dK2.divmod(2 * base, e, kp);
-                const int k = 2 * kp;
-                const bool wrap = k + 2 == K;
-                const int e1 = wrap ? e + 1 : e, k1 = wrap ? 0 : k + 2;
-                const unsigned f0 = *reinterpret_cast<const unsigned short*>(sFrb + k), f1 = *reinterpret_cast<const unsigned short*>(sFrb + k1);
-                const float fl0 = sFl[e], fl1 = sFl[e1];
-                const float m[4] = {fl0 * (float)(f0 & 0xffu), fl0 * (float)(f0 >> 8), fl1 * (float)(f1 & 0xffu), fl1 * (float)(f1 >> 8)};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { const float zz = z[j] * m[j]; s_z = fmaf(zz, zz, s_z); }
-            }
-        }
+        // (the noise norm of the next corrector draw was taken in phase 0, beside the fused apply)
         __syncthreads();
     }
     stamp(ra.dbg, 1);
@@ -295,6 +293,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     const HodgeLayerD& h1 = p.hl[1];
     const bool doP0 = ra.want_p && p.h_L > 0, doP1 = hodge2;
     const bool lin1 = doP1 && h0.mval.n == 1;      // rank2' affine in rank2: fold it around the GEMM
+    const bool pm = !GEN1 && lin1 && ra.masked;    // masked state: Q_1 as a plain projection tile, U1 untouched
     const int wc0 = doP0 ? h0.wc : 0, wc1 = doP1 ? p.h_pw : 0;   // (layers >= 1: one concatenated projection, PlanD::h_pw)
 
     // ---- phase 1: H = F F^T (upper-triangle tiles, mirrored), P_0 = F Wcat_0, P_1 = rank2' Wcat_1.
@@ -343,7 +342,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
                 un = fmaf(frk, wv, un);
             }
             ra.P1[((size_t)b * E + m) * wc1 + n] = acc;
-            if (lin1 && m == 0) ra.U1[(size_t)b * wc1 + n] = un;
+            if (lin1 && m == 0 && !pm) ra.U1[(size_t)b * wc1 + n] = un;
         }
     }
 #endif
@@ -471,11 +470,11 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
         else if ((diag & 2) && type == 0) { (void)0; }
         else
         if (ST && strip) {
-            if (type == 2) kloop(BoolTag<false>{}, BoolTag<true>{}, BoolTag<true>{});
+            if (type == 2 && !pm) kloop(BoolTag<false>{}, BoolTag<true>{}, BoolTag<true>{});
             else if (type == 0) kloop(BoolTag<true>{}, BoolTag<false>{}, BoolTag<true>{});
             else kloop(BoolTag<false>{}, BoolTag<false>{}, BoolTag<true>{});
         } else {
-            if (type == 2) kloop(BoolTag<false>{}, BoolTag<true>{}, BoolTag<false>{});
+            if (type == 2 && !pm) kloop(BoolTag<false>{}, BoolTag<true>{}, BoolTag<false>{});
             else if (type == 0) kloop(BoolTag<true>{}, BoolTag<false>{}, BoolTag<false>{});
             else kloop(BoolTag<false>{}, BoolTag<false>{}, BoolTag<false>{});
         }
@@ -538,7 +537,7 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (mb + r < E) dst[(size_t)r * wc1] = acc[r];
-                if (!GEN1 && i == 0 && kq == 0) ra.U1[(size_t)b * wc1 + n] = un;
+                if (!GEN1 && i == 0 && kq == 0 && !pm) ra.U1[(size_t)b * wc1 + n] = un;
             }
         }
     };

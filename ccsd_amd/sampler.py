@@ -89,9 +89,24 @@ class Sampler:
         self.is_cc = bool(_get(self.config, "is_cc", False))
         self.is_mol = self.IS_MOL if self.IS_MOL is not None else _get(_get(self.config, "data"), "data") in ("QM9", "ZINC250k")
         self.applies_ema = self.APPLIES_EMA if self.APPLIES_EMA is not None else not self.is_mol
-        self.device = loader.load_device()
-        self.device0 = loader._device_id(self.device)
+        # Several GPUs (reference: load_device() returns every GPU and each network is wrapped in DataParallel, loader.py:58-68,
+        # 134-135, 649-650).  Here: one process per GPU, each sampling a shard of every chunk (ccsd_amd/distributed.py).  A process
+        # that belongs to a torch.distributed group -- started by torch.distributed.run, or by CCSD.run(gpus=N) -- takes the
+        # sharded seam in load(); a lone process is the single-GPU harness.
+        self.rank, self.world = 0, 1
+        if (torch.distributed.is_available() and torch.distributed.is_initialized()) or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            from . import distributed
+
+            self.rank, self.world, dev = distributed.init()
+            self.device = dev if dev == "cpu" else [dev]
+            self.device0 = dev
+        else:
+            self.device = loader.load_device()
+            self.device0 = loader._device_id(self.device)
         sample = _get(self.config, "sample")
+        # sharded runs: True (default) = the Langevin norm sums are all-reduced and Philox is keyed by the global sample index, i.e. the
+        # statistics of the reference's DataParallel run (norms over the whole chunk); False = per-shard norms, no per-step traffic
+        self.shard_exact = bool(_get(sample, "shard_exact", True))
         # every class: sample.n_samples, else the SAMPLING config's data.batch_size, else None (sampler.py:116-118, 393-395, 705-707)
         self.n_samples = _get(sample, "n_samples", _get(_get(self.config, "data"), "batch_size", None))
         self.divide_batch = _get(sample, "divide_batch", 1) or 1
@@ -121,9 +136,18 @@ class Sampler:
                 sd.update(ema)                                            # ema.copy_to(model.parameters()), sampler.py:469-471
             self.models.append(loader.load_model_from_ckpt(self.ckpt_dict[f"params_{p}"], sd, self.device))
         data = _get(cfg, "data")
-        self.sampling_fn = loader.load_sampling_fn(self.configt, _get(cfg, "sampler"), _get(cfg, "sample"), self.device,
-                                                   is_cc=self.is_cc, d_min=_get(data, "d_min"), d_max=_get(data, "d_max"),
-                                                   divide_batch=self.divide_batch, **dict({"keep_traj": self.keep_traj}, **self.extra))
+        extra = dict({"keep_traj": self.keep_traj}, **self.extra)
+        if self.world > 1:
+            # full-chunk flags in, all-gathered full chunk out on every rank: the contract of the reference's DataParallel call
+            from . import distributed
+
+            self.sampling_fn = distributed.load_sampling_fn_sharded(self.configt, _get(cfg, "sampler"), _get(cfg, "sample"), self.device,
+                                                                    is_cc=self.is_cc, d_min=_get(data, "d_min"), d_max=_get(data, "d_max"),
+                                                                    divide_batch=self.divide_batch, exact=self.shard_exact, **extra)
+        else:
+            self.sampling_fn = loader.load_sampling_fn(self.configt, _get(cfg, "sampler"), _get(cfg, "sample"), self.device,
+                                                       is_cc=self.is_cc, d_min=_get(data, "d_min"), d_max=_get(data, "d_max"),
+                                                       divide_batch=self.divide_batch, **extra)
         counts, self.n_test = train_node_counts(self.configt, with_test_size=True)
         if counts is None:
             with open(_COUNTS) as f:
@@ -156,6 +180,7 @@ class Sampler:
         for _ in range(n_rounds):
             parts = None
             for _d in range(self.divide_batch):
+                # (sharded runs: every rank draws the same full-chunk flags from its identically seeded numpy stream)
                 fl = init_flags(self.node_counts, self.configt, qty, is_cc=self.is_cc).to(self.device0)
                 res = self.sampling_fn(*self.models, fl)
                 nt = 3 if self.is_cc else 2
@@ -190,12 +215,13 @@ class Sampler:
             out["rank2_cell_bits"], out["rank2_cell_count"] = quant.rank2_cells(rank2, 0.5)
         out["sampling_time"] = torch.tensor(sampling_time)
         self.result = out
-        if save:
+        if save and self.rank == 0:          # every rank holds the gathered samples; rank 0 writes them
             folder = os.path.join(_get(cfg, "folder", "./"), "samples")
             os.makedirs(folder, exist_ok=True)
             name = f"{_get(cfg, 'config_name', 'sample')}_{_get(cfg, 'ckpt')}-sample_{_get(cfg, 'current_time', 'now')}"
             np.savez_compressed(os.path.join(folder, name + ".npz"), **{k: v.detach().cpu().numpy() for k, v in out.items()})
-        print("Sampling done.")
+        if self.rank == 0:
+            print("Sampling done.")
         return out
 
 

@@ -204,7 +204,11 @@ int ccsd_s4_apply(ccsd_plan_t* plan, int32_t B, int32_t step, const ccsd_state_t
 /* The whole loop with in-kernel Philox noise and per-shard Langevin norms (the reference's own
  * divide_batch semantics, sampler.py:1199-1211).  `state` holds the prior on entry (see
  * ccsd_init_state) and the last state on exit; `result` receives the means (denoise) or the state;
- * `scratch` is a second state used for ping-pong.  traj_dev (nullable): [diff_steps][N*F+N*N+E*K]
+ * `scratch` is a second state used for ping-pong.  PRECONDITION: `state` is MASKED by `flags_dev` -- x rows, adj rows / columns
+ * and rank2 rows / columns of switched-off nodes hold zeros, as in every state the reference's loop ever sees (its prior is masked,
+ * solver.py:1111-1118, and every update preserves the masks) and in everything ccsd_init_state or an earlier ccsd_sampler_run
+ * wrote.  The loop's rank-2 kernels rely on it (they skip re-masking rank2 in the hodge-projection loader); the step calls above
+ * (ccsd_score, ccsd_corrector_norms, ccsd_predictor, ...) accept arbitrary states.  traj_dev (nullable): [diff_steps][N*F+N*N+E*K]
  * receives sample 0 of every step (diff_traj, solver.py:1150-1165).  first_step/last_step allow
  * running a sub-range [first_step, last_step) of the diff_steps steps. */
 int ccsd_sampler_run(ccsd_plan_t* plan, int32_t B, const float* flags_dev, uint64_t seed, int64_t sample_offset,
