@@ -128,11 +128,15 @@ static inline HodgeLayerD& ccsd_hl_mut(PlanD& p, int l) { return l < CCSD_MAXHL 
 #include <string>
 #include <vector>
 
-// The plan without its weight-derived fields (the affine fold of ScoreNetworkF): what the configuration alone determines.  A
-// kernel instance with a BAKED plan (ccsd_baked_qm9.h) serves exactly the plans whose architecture bytes equal the baked ones.
+// The plan without its weight-derived fields (the affine fold of ScoreNetworkF) and without the sampler's run-time scalars (snr,
+// scale_eps: the kernels receive them as launch arguments -- LangArgs / CorrFuse -- and never read them from the plan): what the
+// ARCHITECTURE alone determines (network hyper-parameters, geometry, the LDS layout the batch bucket selects).  A kernel instance
+// with a BAKED plan (ccsd_baked_*.h) serves exactly the plans whose architecture bytes equal the baked ones -- whatever snr /
+// scale_eps / predictor the sampling configuration names.
 static inline void ccsd_plan_arch_bytes(const PlanD& p, unsigned char* out) {
     PlanD q;
     memcpy(&q, &p, sizeof(PlanD));
+    q.snr = q.seps = 0.f;
     q.f_alpha = q.f_beta = q.f_gamma = 0.f;
     for (int j = 0; j < CCSD_MAXCN; ++j) q.f_betas[j] = 0.f;
     memcpy(out, &q, sizeof(PlanD));

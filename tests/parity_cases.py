@@ -801,11 +801,13 @@ def case_kat_hodge_layers(lib, device):
 
 
 def case_geometry_instances_bitwise(lib, device, B=64, steps=3, name="ccsd_qm9_CC", counts=(9, 9, 8, 7, 9, 5, 9, 3, 6, 9, 2, 9), expect=(4, 0),
-                                    predictor="Reverse", snr=0.2, corrector="Langevin", scale_eps=0.7):
+                                    predictor="Reverse", snr=0.2, corrector="Langevin", scale_eps=0.7, no_bake=False):
     """The kernel instances with compile-time geometry or a compile-time plan (k_xa XA_PLAIN9 / XA_BAKED*, k_r2 QM9, the (E, K)
     instances of the general-path kernels) against the run-time instances of the same source (a plan created with CCSD_NO_GEO set):
     the same arithmetic in the same order -- only index computations, loop bounds and branches fold -- so the production loop must
-    agree BIT FOR BIT, and so must the scores.  Also checks which k_xa instance the plan selects (`expect`: specialised, plain)."""
+    agree BIT FOR BIT, and so must the scores.  Also checks which k_xa instance the plan selects (`expect`: specialised, plain).
+    no_bake: the first plan is created with CCSD_NO_BAKE set -- the geometry-only instance of a configuration that would select a
+    baked one (baked instances are keyed on the ARCHITECTURE: no sampler setting steers a shipped network away from them)."""
     meta, parts = load_ckpt_np(name)
     cfg, is_cc = meta["config"], meta["is_cc"]
     N, Fd = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
@@ -824,10 +826,13 @@ def case_geometry_instances_bitwise(lib, device, B=64, steps=3, name="ccsd_qm9_C
     make = solver.S4_solver if predictor == "S4" else solver.get_pc_sampler
     outs, variants = [], []
     old = os.environ.pop("CCSD_NO_GEO", None)
+    old_nb = os.environ.pop("CCSD_NO_BAKE", None)
     try:
         for off in (False, True):
             if off:
                 os.environ["CCSD_NO_GEO"] = "1"
+            elif no_bake:
+                os.environ["CCSD_NO_BAKE"] = "1"
             fn = make(device=device, rng="philox", seed=11, max_steps=steps, lib=lib, **skw, **kw)
             res = fn(*ms, flags)
             eng = fn.engine()
@@ -837,11 +842,15 @@ def case_geometry_instances_bitwise(lib, device, B=64, steps=3, name="ccsd_qm9_C
             scores = [eng.score(t, st[0], st[1], st[2] if is_cc else None, flags).clone() for t in range(len(names))]
             outs.append([r.clone() for r in res[:len(names)]] + scores)
             os.environ.pop("CCSD_NO_GEO", None)
+            os.environ.pop("CCSD_NO_BAKE", None)
     finally:
         os.environ.pop("CCSD_NO_GEO", None)
+        os.environ.pop("CCSD_NO_BAKE", None)
         if old is not None:
             os.environ["CCSD_NO_GEO"] = old
+        if old_nb is not None:
+            os.environ["CCSD_NO_BAKE"] = old_nb
     if device != "cpu":
-        assert variants == list(expect), f"k_xa variants selected: {variants} (expected the specialised instance, then the plain one)"
+        assert variants == list(expect), f"k_xa variants selected: {variants}, expected {list(expect)} (the specialised instance, then the plain one)"
     for k, (a, b) in enumerate(zip(*outs)):
         assert torch.equal(a, b), f"{name} tensor {k}: specialised instance != run-time instance (max diff {(a - b).abs().max().item():.3e})"

@@ -339,18 +339,24 @@ def test_zinc5b_production_loop_vs_oracle(lib):
 
 def test_geometry_instances_match_runtime_geometry_bitwise(lib):
     """k_xa<false, XA_PLAIN9> / k_r2<3, 1, true, false, QM9> == the run-time-geometry instances, bit for bit (production loop + scores)."""
-    # another snr than the baked plan's: the geometry-only instances k_xa<false, XA_PLAIN9> / k_r2<3, 1, true, false, 1>
-    pc.case_geometry_instances_bitwise(lib, DEV, snr=0.25, expect=(4, 0))
-    # the bench line's configuration: the plan equals the baked one -- k_xa<false, XA_BAKED9> / k_r2<3, 1, true, false, 2>, every plan
-    # field a compile-time constant
+    # the geometry-only instances k_xa<false, XA_PLAIN9> / k_r2<3, 1, true, false, 1> (CCSD_NO_BAKE keeps the plan off the baked ones)
+    pc.case_geometry_instances_bitwise(lib, DEV, snr=0.25, expect=(4, 0), no_bake=True)
+    # the bench line's configuration: the plan's architecture bytes equal the baked ones -- k_xa<false, XA_BAKED9> /
+    # k_r2<3, 1, true, false, 2>, every plan field a compile-time constant
     pc.case_geometry_instances_bitwise(lib, DEV, B=1024, steps=3, expect=(7, 0))
-    # k_xa<true, XA_PLAIN20> (community_small geometry, channel stack in HBM) against k_xa<true, XA_PLAIN>
-    # (B = 512: the batch at which the plan keeps the channel stack in HBM.)  The bench configuration selects the baked instance
-    # k_xa<true, XA_BAKED20> (ccsd_baked_cs.h, five AttentionLayers unrolled), another snr the geometry-only k_xa<true, XA_PLAIN20>
+    # baked instances are keyed on the ARCHITECTURE only: other sampler settings of the shipped network (snr, scale_eps, the shipped
+    # YAML's chunk of 2500 falls into the same batch bucket) select the same instance ...
+    pc.case_geometry_instances_bitwise(lib, DEV, B=1024, steps=2, snr=0.25, scale_eps=0.9, expect=(7, 0))
+    # ... and CCSD_NO_BAKE holds it to the geometry-only instance of the same source
+    pc.case_geometry_instances_bitwise(lib, DEV, B=1024, steps=2, expect=(4, 0), no_bake=True)
+    # k_xa<true, XA_BAKED20> (community_small_CC, B = 512: channel stack in HBM, five AttentionLayers unrolled) at the shipped and at
+    # another snr; k_xa<true, XA_PLAIN20> (geometry only) against k_xa<true, XA_PLAIN>
     pc.case_geometry_instances_bitwise(lib, DEV, B=512, steps=2, name="ccsd_community_small_CC", counts=(20, 12, 16, 18, 14, 20), expect=(8, 0),
                                        predictor="Euler", snr=0.05)
-    pc.case_geometry_instances_bitwise(lib, DEV, B=512, steps=2, name="ccsd_community_small_CC", counts=(20, 12, 16, 18, 14, 20), expect=(5, 0),
+    pc.case_geometry_instances_bitwise(lib, DEV, B=512, steps=2, name="ccsd_community_small_CC", counts=(20, 12, 16, 18, 14, 20), expect=(8, 0),
                                        predictor="Euler", snr=0.06)
+    pc.case_geometry_instances_bitwise(lib, DEV, B=512, steps=2, name="ccsd_community_small_CC", counts=(20, 12, 16, 18, 14, 20), expect=(5, 0),
+                                       predictor="Euler", snr=0.05, no_bake=True)
     # qm9_Base_CC: k_xa stays the run-time-plan HodgeBaseline instance (1, 1); its non-affine k_r2 runs with the qm9 geometry compiled in
     pc.case_geometry_instances_bitwise(lib, DEV, B=64, steps=2, name="ccsd_qm9_Base_CC", expect=(1, 1))
     # zinc250k (graph-only, N = 38, batch 256): k_xa<true, XA_BAKED38>;  ENZYMES_small_CC (S4 sampler, batch 64): k_xa<false, XA_BAKEDENZ>
