@@ -40,3 +40,14 @@ def make_flags(B, N, counts):
     for b in range(B):
         f[b, : counts[b % len(counts)]] = 1.0
     return f
+
+
+def parse_case(case):
+    """Name of a g5 sampler case -> (num_scales override or None, number of steps run or None = all): "k10" = a 10-scale SDE run to
+    the end, "n1000_first3" = the checkpoint's 1000 scales, first 3 steps, "n1000" = the checkpoint's 1000 scales from the prior to
+    the last step."""
+    if case.startswith("k"):
+        return int(case[1:]), None
+    if "first" in case:
+        return None, int(case.split("first")[1])
+    return None, None

@@ -13,7 +13,7 @@ from ccsd_amd import loader, solver
 from ccsd_amd.engine import PCEngine
 from ccsd_amd.plan import rank2_dim
 from oracle import ccsd_oracle as O
-from tests.helpers import load_ckpt_np, load_golden, make_flags, rng_matches
+from tests.helpers import load_ckpt_np, load_golden, make_flags, parse_case, rng_matches
 
 # float tolerance of the path (BASELINE.json north_star: scores within 1e-4 relative).  Two checks per tensor:
 #  (1) max |got - ref| <= RTOL * max|ref|            -- relative to the tensor's scale, since entries pass through zero;
@@ -141,8 +141,7 @@ def sampler_from_golden(g, ckpt, case, lib, device, rng="torch_cpu", shape_overr
     N, Fd = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
     flags = torch.from_numpy(g["flags"])
     B = flags.shape[0] if shape_override is None else shape_override
-    num_scales = int(case[1:]) if case.startswith("k") else None
-    max_steps = None if case.startswith("k") else int(case.split("first")[1])
+    num_scales, max_steps = parse_case(case)
     names = ["x", "adj"] + (["rank2"] if is_cc else [])
     sdes = []
     for p in names:
@@ -197,7 +196,7 @@ def f64_arithmetic():
         torch.set_default_dtype(dd)
 
 
-def case_fp64_arbiter(gname, ckpt, case, lib, device, factor=2.0):
+def case_fp64_arbiter(gname, ckpt, case, lib, device, factor=1.5):
     """Who is right when the product and the fp32 reference golden differ by more than RTOL?  The same trajectory is
     computed by the oracle in float64 (f64_arithmetic) and both are measured against it.  Required: the product is within
     max(RTOL, factor * the reference's own error) of the exact result -- it may not be (much) further from the truth than the
@@ -211,8 +210,7 @@ def case_fp64_arbiter(gname, ckpt, case, lib, device, factor=2.0):
     flags = torch.from_numpy(g["flags"])
     B = flags.shape[0]
     names = ["x", "adj"] + (["rank2"] if is_cc else [])
-    num_scales = int(case[1:]) if case.startswith("k") else None
-    max_steps = None if case.startswith("k") else int(case.split("first")[1])
+    num_scales, max_steps = parse_case(case)
     with f64_arithmetic():
         sdes = []
         for p in names:

@@ -63,6 +63,8 @@ def test_kat_small_general_paths(lib):
     ("ccsd_qm9_CC_pflow", "ccsd_qm9_CC", "k6"),
     ("gdss_community_small_pflow", "gdss_community_small", "k5"),
     ("ccsd_qm9_CC_subvp_mixed", "ccsd_qm9_CC", "k4"),
+    # the metric's own length: the shipped 1000-scale qm9_CC set-up from the prior to the last step, every draw from the CPU generator
+    ("ccsd_qm9_CC_full1000", "ccsd_qm9_CC", "n1000"),
 ])
 def test_pc_sampler_identical_seed(lib, gname, ckpt, case):
     pc.case_pc_sampler_identical_seed(gname, ckpt, case, lib, DEV)

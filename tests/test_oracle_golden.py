@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import ccsd_oracle as O
-from tests.helpers import load_ckpt_np, load_golden, rng_matches
+from tests.helpers import load_ckpt_np, load_golden, parse_case, rng_matches
 
 torch.set_num_threads(8)
 
@@ -177,6 +177,8 @@ G5 = [
     ("ccsd_qm9_CC_pflow", "ccsd_qm9_CC", ["k6"]),
     ("gdss_community_small_pflow", "gdss_community_small", ["k5"]),
     ("ccsd_qm9_CC_subvp_mixed", "ccsd_qm9_CC", ["k4"]),
+    # the shipped qm9_CC sampling set-up at FULL length: 1000 scales from the prior to the last step (B = 2)
+    ("ccsd_qm9_CC_full1000", "ccsd_qm9_CC", ["n1000"]),
 ]
 
 
@@ -187,11 +189,7 @@ def oracle_sampler_from_golden(g, ckpt, case, noise=None):
     N, Fd = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
     flags = torch.from_numpy(g["flags"])
     B = flags.shape[0]
-    num_scales, max_steps = None, None
-    if case.startswith("k"):
-        num_scales = int(case[1:])
-    else:
-        max_steps = int(case.split("first")[1])
+    num_scales, max_steps = parse_case(case)
     parts = ["x", "adj"] + (["rank2"] if is_cc else [])
     sdes = []
     for p in parts:

@@ -617,6 +617,102 @@ def reference_variant_status():
         print("variant", k, v["result"], v.get("type", ""), v.get("message", v.get("shape")))
 
 
+def kat_reference_held():
+    """The known-answer vectors the REFERENCE'S OWN TESTS hold for the path (tests/models/test_ScoreNetwork_A_CC.py:119-162,
+    test_ScoreNetwork_A_Base_CC.py:115-158, test_ScoreNetwork_F.py:69-106, test_hodge_attention.py:96-209, test_hodge_layers.py:143-375)
+    as a fixture: tests/golden/kat_reference_held.npz.  Each reference test function is RUN here, unmodified, with the classes it
+    constructs wrapped by a recorder: the fixture holds, per test, the constructor arguments, the weights the reference constructor
+    drew (torch.manual_seed(42), in the test's own construction order), the tensors the module was called with, what it returned, and
+    the EXPECTED values exactly as the reference test writes them (literal `expected_* = torch.tensor([...])` assignments, read from
+    the test's syntax tree together with the slice of the output they are compared with and the atol).  The reference test's own
+    assertions run too, so a wrong capture fails here.  A second, container-independent pin of the oracle (and, for the three whole
+    networks, of the HIP path) next to the generated goldens."""
+    import ast
+    import importlib.util
+
+    tests = [
+        ("tests/models/test_ScoreNetwork_A_CC.py", "test_ScoreNetworkA_CC", ["ScoreNetworkA_CC"]),
+        ("tests/models/test_ScoreNetwork_A_Base_CC.py", "test_ScoreNetworkA_Base_CC", ["ScoreNetworkA_Base_CC"]),
+        ("tests/models/test_ScoreNetwork_F.py", "test_ScoreNetworkF", ["ScoreNetworkF"]),
+        ("tests/models/test_hodge_attention.py", "test_HodgeAttention", ["HodgeAttention"]),
+        ("tests/models/test_hodge_attention.py", "test_HodgeAdjAttentionLayer", ["HodgeAdjAttentionLayer"]),
+        ("tests/models/test_hodge_layers.py", "test_DenseHCNConv", ["DenseHCNConv"]),
+        ("tests/models/test_hodge_layers.py", "test_HodgeNetworkLayer", ["HodgeNetworkLayer"]),
+        ("tests/models/test_hodge_layers.py", "test_BaselineBlock", ["BaselineBlock"]),
+        ("tests/models/test_hodge_layers.py", "test_HodgeBaselineLayer", ["HodgeBaselineLayer"]),
+    ]
+    out, index = {}, {}
+    for rel, tname, classes in tests:
+        path = os.path.join(refshim.REFERENCE_ROOT, rel)
+        spec = importlib.util.spec_from_file_location("ref_" + tname, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)                      # (seeds torch / numpy at import, like a pytest run of the file)
+        records = []
+
+        def wrap(cls):
+            class Rec(cls):
+                def __init__(self, *a, **k):
+                    super().__init__(*a, **k)
+                    self._rec = {"cls": cls.__name__, "args": plain(k if k else list(a)), "calls": []}
+                    records.append(self)
+
+                def forward(self, *a, **k):
+                    res = super().forward(*a, **k)
+                    keep = lambda t: t.detach().clone() if isinstance(t, torch.Tensor) else t       # (ints such as N, d_min pass through)
+                    self._rec["calls"].append(([keep(t) for t in a], {n: keep(t) for n, t in k.items()},
+                                               [r.detach().clone() for r in (res if isinstance(res, tuple) else (res,))]))
+                    return res
+            Rec.__name__ = cls.__name__
+            return Rec
+
+        for c in classes:
+            setattr(mod, c, wrap(getattr(mod, c)))
+        fn = getattr(mod, tname)
+        # fixture values from the module's own fixture functions (pytest's wrappers hold the plain function), resolved recursively
+        import inspect
+
+        def fixture_value(name, cache={}):
+            key = (tname, name)
+            if key not in cache:
+                raw = getattr(mod, name)._get_wrapped_function()
+                cache[key] = raw(**{a: fixture_value(a) for a in inspect.signature(raw).parameters})
+            return cache[key]
+
+        fn(**{a: fixture_value(a) for a in inspect.signature(fn).parameters})       # the reference's assertions run here
+        # literal expected values + the compared slice, from the test's syntax tree
+        tree = ast.parse(open(path).read())
+        fdef = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == tname)
+        lits, checks = {}, []
+        for n in ast.walk(fdef):
+            if isinstance(n, ast.Assign) and isinstance(n.targets[0], ast.Name) and n.targets[0].id.startswith("expected"):
+                lits[n.targets[0].id] = np.asarray(ast.literal_eval(n.value.args[0]), dtype=np.float32)
+            if isinstance(n, ast.Call) and getattr(n.func, "attr", "") == "allclose":
+                atol = next(ast.literal_eval(k.value) for k in n.keywords if k.arg == "atol")
+                checks.append((ast.unparse(n.args[0]), n.args[1].id, float(atol)))
+        rec = records[-1]._rec                               # the instance the value assertions are made on (the last one built)
+        mdl = records[-1]
+        key = tname[len("test_"):]
+        for k2, v in mdl.state_dict().items():
+            out[f"{key}/w/{k2}"] = v.detach().numpy().copy()
+        args, kwargs, res = rec["calls"][-1]
+        for i, t in enumerate(args):
+            if isinstance(t, torch.Tensor):
+                out[f"{key}/in/{i}"] = t.numpy()
+        for nme, t in kwargs.items():
+            if isinstance(t, torch.Tensor):
+                out[f"{key}/kw/{nme}"] = t.numpy()
+        for i, t in enumerate(res):
+            out[f"{key}/out/{i}"] = t.numpy()
+        for nme, v in lits.items():
+            out[f"{key}/{nme}"] = v
+        index[key] = {"cls": rec["cls"], "args": rec["args"], "n_in": len(args), "plain_in": {str(i): t for i, t in enumerate(args) if not isinstance(t, torch.Tensor)},
+                      "plain_kw": {n: t for n, t in kwargs.items() if not isinstance(t, torch.Tensor)}, "tensor_kw": sorted(n for n, t in kwargs.items() if isinstance(t, torch.Tensor)), "n_out": len(res), "checks": checks, "source": f"{rel}::{tname}",
+                      "models_built_before": len(records) - 1}
+        print("kat_reference_held", key, "ok:", [c[0] for c in checks])
+    out["index"] = np.array(json.dumps(index))
+    np.savez_compressed(os.path.join(GOLD, "kat_reference_held.npz"), **out)
+
+
 def reference_kat_status():
     """Run the reference's own known-answer tests for the path in this container and record the result."""
     files = ["tests/models", "tests/utils/test_graph_utils.py", "tests/utils/test_cc_utils.py",
@@ -672,6 +768,13 @@ def main():
         g5_pc_runs("ccsd_qm9_CC_langevin2", cks["ccsd_qm9_CC"], True, 2, [9, 6],
                    dict(predictor="Reverse", corrector="Langevin", snr=0.2, scale_eps=0.7, n_steps=2),
                    {"k4": (4, None)}, seed=6)
+    if "full" in only:
+        # One FULL-LENGTH run: the shipped sampling set-up of qm9_CC (1000 scales, Reverse + Langevin) from the prior to the last
+        # step, every draw from torch's CPU generator.  ~2.5 minutes of reference CPU time: made on request only
+        # (python tools/make_golden.py full), the other fixtures are unaffected.
+        g5_pc_runs("ccsd_qm9_CC_full1000", cks["ccsd_qm9_CC"], True, 2, [9, 7],
+                   dict(predictor="Reverse", corrector="Langevin", snr=0.2, scale_eps=0.7, n_steps=1),
+                   {"n1000": (None, None)}, seed=77, min_dist=5e-3)
     if not only or "s4" in only:
         # S4_solver (solver.py:1179-1563): the sampler the shipped ENZYMES_small_CC config selects
         s4 = dict(predictor="S4", corrector="None", snr=0.15, scale_eps=0.7, n_steps=1)
@@ -718,6 +821,8 @@ def main():
                    {"k10": (10, None), "n1000_first3": (None, 3)}, seed=42)
     if not only or "refkat" in only:
         reference_kat_status()
+    if not only or "refheld" in only:
+        kat_reference_held()
     if not only or "variants" in only:
         reference_variant_status()
 
