@@ -14,8 +14,12 @@ plots, wandb -- is out of scope; `sample()` returns the te
 init_flags (cc_utils.py:883-914): the reference draws `np.random.randint(0, len(train_list), batch)` and takes the node
 flags of those training objects.  Only the node COUNT of each training object matters, so this build ships the counts
 (ccsd_amd/data/node_counts.json: per-graph node counts of the pickled datasets in file order -> the same indices pick
-the same flags for the same numpy seed).  QM9 / ZINC250k need the csv blobs the reference repository does not ship:
-there the flags are drawn from the test-set node-count histogram instead (documented deviation).
+the same flags for the same numpy seed).  QM9 / ZINC250k: the reference draws from its training molecules (sampler.py:1162-1194),
+whose files the reference repository does not ship (.MISSING_LARGE_BLOBS).  When the user's dataset copy is present under
+<folder>/data (<dataset>_kekulized.npz or <dataset>.csv, with valid_idx_<dataset>.json) the node counts of the training molecules
+are read from it in the reference's order (mol_train_node_counts: same indices, same flags for the same numpy seed); otherwise
+the flags come from a shipped histogram -- QM9: the node counts of the shipped test graphs (data/qm9_test_nx.pkl), ZINC250k: a
+discretised normal fit of the dataset's published heavy-atom statistics (node_counts.json notes) -- and the run says so.
 """
 from __future__ import annotations
 
@@ -72,6 +76,70 @@ def init_flags(obj_counts, config, batch_size: Optional[int] = None, is_cc: bool
     for b, c in enumerate(counts):
         flags[b, : int(min(c, N))] = 1.0
     return flags
+
+
+_TWO_LETTER = ("Cl", "Br", "Si", "Se", "Na", "Li", "Mg", "Ca", "Al", "Sn", "Zn", "Cu", "Fe", "As", "Te")
+
+
+def smiles_heavy_atoms(smiles: str) -> int:
+    """Number of non-hydrogen atoms of a SMILES string, without rdkit: one per bracket atom (other than [H] / isotopes of H), per
+    two-letter element, per organic-subset letter (B C N O P S F I) and per aromatic letter (b c n o p s).  That is the node count
+    of the molecule's graph in the reference (mol.GetNumAtoms() of the kekulised molecule, data_loader_mol.py / mol_utils.py)."""
+    n, i, L = 0, 0, len(smiles)
+    while i < L:
+        ch = smiles[i]
+        if ch == "[":
+            j = smiles.index("]", i)
+            body = smiles[i + 1:j].lstrip("0123456789")
+            sym = body[:2] if body[:2] in _TWO_LETTER else body[:1]
+            if sym not in ("H",):
+                n += 1
+            i = j + 1
+        elif smiles[i:i + 2] in _TWO_LETTER:
+            n += 1
+            i += 2
+        elif ch in "BCNOPSFI" or ch in "bcnops":
+            n += 1
+            i += 1
+        else:
+            i += 1
+    return n
+
+
+def mol_train_node_counts(config, configt):
+    """Node counts of the TRAINING molecules of QM9 / ZINC250k in the reference's order (data_loader_mol.py:352-379: the molecules of
+    <dataset>_kekulized.npz in file order minus the indices of valid_idx_<dataset>.json), from the user's own copy of the dataset --
+    the reference repository does not ship these blobs (.MISSING_LARGE_BLOBS).  Looked up under <folder>/<data.dir>/:
+      <dataset>_kekulized.npz   arr_0 = atomic numbers per molecule, zero padded -> count of non-zeros (what the reference itself loads), else
+      <dataset>.csv             column SMILES1 (QM9) / smiles (ZINC250k) -> heavy atoms per SMILES (smiles_heavy_atoms)
+    with valid_idx_<dataset>.json beside it.  Returns None when neither file (or the index file) is there."""
+    data = _get(configt, "data")
+    name = str(_get(data, "data")).lower()
+    folder = _get(config, "folder", "./")
+    ddir = _get(_get(config, "data"), "dir", None) or _get(data, "dir", "./data")
+    for base in dict.fromkeys([os.path.join(folder, ddir), os.path.join(folder, "data")]):
+        idx_path = os.path.join(base, f"valid_idx_{name}.json")
+        npz, csv_path = os.path.join(base, f"{name}_kekulized.npz"), os.path.join(base, f"{name}.csv")
+        if not os.path.exists(idx_path) or not (os.path.exists(npz) or os.path.exists(csv_path)):
+            continue
+        with open(idx_path) as f:
+            test_idx = json.load(f)
+        if isinstance(test_idx, dict):                       # QM9: {"valid_idxs": ["123", ...]}
+            test_idx = test_idx["valid_idxs"]
+        test_idx = {int(i) for i in test_idx}
+        if os.path.exists(npz):
+            with np.load(npz, allow_pickle=True) as z:
+                counts = np.array([int(np.count_nonzero(np.asarray(x))) for x in z["arr_0"]], dtype=np.int64)
+        else:
+            import csv
+
+            col = "SMILES1" if name == "qm9" else "smiles"
+            with open(csv_path, newline="") as f:
+                counts = np.array([smiles_heavy_atoms(row[col]) for row in csv.DictReader(f)], dtype=np.int64)
+        keep = np.ones(len(counts), dtype=bool)
+        keep[[i for i in test_idx if i < len(counts)]] = False
+        return counts[keep]
+    return None
 
 
 class Sampler:
@@ -149,13 +217,22 @@ class Sampler:
                                                        is_cc=self.is_cc, d_min=_get(data, "d_min"), d_max=_get(data, "d_max"),
                                                        divide_batch=self.divide_batch, **extra)
         counts, self.n_test = train_node_counts(self.configt, with_test_size=True)
+        self.node_counts_source = "shipped per-graph node counts of the training split (ccsd_amd/data/node_counts.json)"
+        if counts is None and self.is_mol:
+            # molecule datasets: the training molecules of the user's own dataset copy, as the reference draws them (sampler.py:1162-1194)
+            counts = mol_train_node_counts(cfg, self.configt)
+            self.node_counts_source = "training molecules of the dataset under <folder>/data (reference order)"
         if counts is None:
             with open(_COUNTS) as f:
                 entry = json.load(f).get(_dataset_key(_get(_get(self.configt, "data"), "data")), {})
-            counts = entry.get("test_histogram")
+            counts = entry.get("test_histogram") or entry.get("fallback_histogram")
             if counts is None:
                 raise FileNotFoundError(f"no node counts for dataset {_get(_get(self.configt, 'data'), 'data')}: pass "
                                         "`node_counts=` to sample()")
+            self.node_counts_source = entry.get("note", "shipped node-count histogram")
+            if self.rank == 0:
+                print(f"init_flags: dataset files not found under {_get(cfg, 'folder', './')}/data -- node counts are drawn from the shipped "
+                      f"histogram ({self.node_counts_source})")
         self.node_counts = counts
 
     def sample(self, save: bool = False, node_counts=None, rounds: Optional[int] = None) -> Dict[str, torch.Tensor]:

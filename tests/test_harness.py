@@ -190,3 +190,68 @@ def test_plotly_fig_switches_diff_traj(tmp_path):
     assert len(traj) == 2 and [tuple(t.shape) for t in traj[0]] == [(9, 4), (9, 9), (36, 466)]
     # the last entry holds sample 0 of the first chunk's returned (denoised) tensors
     assert torch.equal(traj[-1][1].cpu(), out["adj"][0].cpu()) and torch.equal(traj[-1][2].cpu(), out["rank2"][0].cpu())
+
+
+def _mol_dataset(tmp_path, name, col, smiles, test_idx, as_dict):
+    os.makedirs(tmp_path / "data", exist_ok=True)
+    with open(tmp_path / "data" / f"{name}.csv", "w") as f:
+        f.write(f"idx,{col},extra\n" + "".join(f"{i},{s},0\n" for i, s in enumerate(smiles)))
+    with open(tmp_path / "data" / f"valid_idx_{name}.json", "w") as f:
+        json.dump({"valid_idxs": [str(i) for i in test_idx]} if as_dict else test_idx, f)
+
+
+def test_molecule_node_counts_come_from_the_users_dataset(tmp_path):
+    """QM9 / ZINC250k: the reference draws init_flags from its TRAINING molecules (sampler.py:1162-1194, cc_utils.py:883-914;
+    data_loader_mol.py:352-379: file order minus valid_idx).  With the user's dataset copy under <folder>/data the product does the
+    same -- heavy atoms per SMILES of <dataset>.csv, or the atomic-number rows of <dataset>_kekulized.npz -- and the harness draws
+    the same indices from the numpy stream."""
+    smiles = ["C", "CCO", "c1ccccc1", "CC(=O)Nc1ccc(Cl)cc1", "[nH]1cccc1", "C[N+](C)(C)C", "O=C1C=CC(=O)N1", "CC(C)CO", "N#CC1CC1", "OCC(O)CO"]
+    want = [1, 3, 6, 11, 5, 5, 7, 5, 5, 6]
+    assert [S.smiles_heavy_atoms(s) for s in smiles] == want
+    _mol_dataset(tmp_path, "qm9", "SMILES1", smiles, [1, 4, 7], as_dict=True)
+    cfg = AttrDict({"folder": str(tmp_path), "data": {"data": "QM9", "dir": "./data"}})
+    cfgt = AttrDict({"data": {"data": "QM9", "max_node_num": 9}})
+    counts = S.mol_train_node_counts(cfg, cfgt)
+    assert counts.tolist() == [want[i] for i in (0, 2, 3, 5, 6, 8, 9)]
+    # the kekulised arrays take precedence (what the reference itself loads): arr_0 = zero-padded atomic numbers
+    x = np.zeros((10, 9), np.int64)
+    for i, n in enumerate([2, 3, 4, 5, 6, 7, 8, 9, 1, 2]):
+        x[i, :n] = 6
+    np.savez(tmp_path / "data" / "qm9_kekulized.npz", x, np.zeros((10, 4, 9, 9), np.int8))
+    assert S.mol_train_node_counts(cfg, cfgt).tolist() == [2, 4, 5, 7, 8, 1, 2]
+    # ZINC250k: a plain list of indices, column "smiles"; nothing under <folder>/data -> None
+    _mol_dataset(tmp_path, "zinc250k", "smiles", smiles, [0, 9], as_dict=False)
+    cz = AttrDict({"folder": str(tmp_path), "data": {"data": "ZINC250k", "dir": "./data"}})
+    assert S.mol_train_node_counts(cz, AttrDict({"data": {"data": "ZINC250k", "max_node_num": 38}})).tolist() == want[1:9]
+    assert S.mol_train_node_counts(AttrDict({"folder": str(tmp_path / "nowhere"), "data": {"data": "QM9"}}), cfgt) is None
+
+
+def test_harness_draws_flags_from_the_users_training_molecules(tmp_path):
+    from tests.emu_util import emu_library
+
+    smiles = ["CCO", "c1ccccc1", "CC(=O)NC", "CCCCCCCCC", "C", "CC", "OCC(O)CO", "CC(C)CO"]
+    _mol_dataset(tmp_path, "qm9", "SMILES1", smiles, [4, 5], as_dict=True)
+    out, c = run_harness(tmp_path, emu_library(), None, "sample_qm9_CC", QM9_CC_YAML, max_steps=1)
+    train = np.array([3, 6, 5, 9, 6, 5])
+    assert "training molecules" in c.sampler.node_counts_source and np.array_equal(np.asarray(c.sampler.node_counts), train)
+    np.random.seed(QM9_CC_YAML["sample"]["seed"])
+    want = np.concatenate([train[np.random.randint(0, len(train), 4)] for _ in range(2)])       # two chunks of 4 (divide_batch 2)
+    assert np.array_equal(out["flags"].sum(1).cpu().numpy().astype(np.int64), want)
+
+
+def test_zinc250k_has_a_documented_fallback_histogram(tmp_path, capsys):
+    """No dataset files: QM9 falls back to the node counts of the shipped test graphs, ZINC250k to a documented approximation --
+    neither raises (the shipped sample_zinc250k.yaml runs without `node_counts=`), and the run says which source it used."""
+    table = json.load(open(S._COUNTS))
+    h = table["ZINC250k"]["fallback_histogram"]
+    assert "APPROXIMATION" in table["ZINC250k"]["note"] and min(map(int, h)) == 6 and max(map(int, h)) == 38
+    cfgt = AttrDict({"data": {"data": "ZINC250k", "max_node_num": 38, "batch_size": 8}})
+    np.random.seed(3)
+    fl = S.init_flags(h, cfgt, 64)
+    n = fl.sum(1)
+    assert fl.shape == (64, 38) and 6 <= n.min() and n.max() <= 38 and 18 < n.mean() < 28
+    cfg = AttrDict(dict(QM9_CC_YAML, folder=str(tmp_path)))
+    smp = S.get_sampler_from_config(cfg)
+    smp.load()
+    assert isinstance(smp.node_counts, dict)
+    assert "shipped" in capsys.readouterr().out
