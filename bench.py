@@ -375,6 +375,19 @@ def _main(real_stdout):
 
     if args.emulate:
         os.environ.setdefault("CUDA_VISIBLE_DEVICES", "")
+    else:
+        # the library is in place BEFORE the process group exists (no collective -- and no RCCL call -- ever waits on a compiler):
+        # rank 0 (re)builds when a source is newer, the other ranks wait for the finished file
+        import __graft_entry__ as ge
+
+        if int(os.environ.get("RANK", "0")) == 0:
+            ge.build()
+        else:
+            t_wait = time.time()
+            while not os.path.exists(ge.LIB) or any(os.path.getmtime(f) > os.path.getmtime(ge.LIB) for f in ge.SOURCES):
+                if time.time() - t_wait > 1200:
+                    raise SystemExit("bench.py: timed out waiting for rank 0 to build libccsd_hip.so")
+                time.sleep(1.0)
     rank, world, dev = distributed.init("gloo" if args.emulate else None)
     if args.emulate and os.environ.get("CCSD_BENCH_FAIL_RANK") == str(rank):     # tests/test_bench_launcher.py: a dying worker
         os._exit(7)
@@ -389,13 +402,6 @@ def _main(real_stdout):
         if world > 1:
             dist.barrier()
         lib = lib or emu_library()
-    else:
-        import __graft_entry__ as ge
-
-        if rank == 0:
-            ge.build()
-        if world > 1:
-            dist.barrier()
     from ccsd_amd import loader
 
     wname = args.workload

@@ -141,13 +141,17 @@ _hip: Optional[Library] = None
 
 
 def get_library() -> Library:
-    """The HIP library.  Fails loudly when it has not been built (python __graft_entry__.py)."""
+    """The HIP library.  Fails loudly when it has not been built (python __graft_entry__.py).
+    CCSD_LIB_PATH (developer A/B runs only, tools/dev/*.sh) names another build of the SAME HIP library -- e.g. a diagnostic build with
+    cycle stamps -- instead of overwriting the product file; it is still a HIP library (is_hip: a GPU is required) and a missing
+    file is an error, never a fallback."""
     global _hip
     if _hip is None:
-        if not os.path.exists(HIP_LIB_PATH):
+        path = os.environ.get("CCSD_LIB_PATH") or HIP_LIB_PATH
+        if not os.path.exists(path):
             raise CcsdError(
-                f"{HIP_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  ccsd_amd has no CPU fallback."
             )
-        _hip = Library(HIP_LIB_PATH, is_hip=True)
+        _hip = Library(path, is_hip=True)
     return _hip

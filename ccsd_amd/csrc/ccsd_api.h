@@ -388,10 +388,11 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
         return set_err(CCSD_ERR_UNSUPPORTED, "more than two HodgeAdjAttentionLayers need the fused rank-2 kernel (E <= 64, cnum <= 2, hidden widths <= 16)");
     }
 #ifndef CCSD_EMU
-    if ((size_t)pl->h.xa_lds_floats * 4 > 64 * 1024)
+    if ((size_t)pl->h.xa_lds_floats * 4 > 64 * 1024) {
         PC(rt_set_max_dyn_smem(xa_kernel(pl->h), (size_t)pl->h.xa_lds_floats * 4));
         if (xa_variant(pl->h) == XA_PLAIN9 || xa_variant(pl->h) == XA_BAKED9)     // (its run-time-geometry twin serves launches with a diagnostic thread count)
             PC(rt_set_max_dyn_smem((const void*)k_xa<false, XA_PLAIN>, (size_t)pl->h.xa_lds_floats * 4));
+    }
     if (pl->fused_r2 && pl->r2_lds > 64 * 1024) {
         PC(rt_set_max_dyn_smem(r2_kernel(pl), pl->r2_lds));
     }
@@ -456,8 +457,8 @@ static Workspace carve_ws(const ccsd_plan* pl, int B, void* base) {
     w.P0 = (float*)take(p.h_L > 0 ? (size_t)B * E * p.hl[0].wc * 4 : 0);
     w.P1 = (float*)take(p.h_L > 1 ? (size_t)B * E * p.h_pw * 4 : 0);
     w.U1 = (float*)take(p.h_L > 1 ? (size_t)B * p.h_pw * 4 : 0);
-    // K slices of k_gemm_p (few row tiles: small batches; the step-wise score / norms calls of fused-rank-2 plans use k_gemm_p too)
-    w.psplit_floats = p.h_L > 1 && (long long)B * E < 256 * T_BM ? (size_t)CCSD_P_SPLITS * B * E * p.h_pw : 0;
+    // K slices of k_gemm_p (always split: batch-invariant summation order; the step-wise score / norms calls of fused-rank-2 plans use k_gemm_p too)
+    w.psplit_floats = p.h_L > 1 ? (size_t)CCSD_P_SPLITS * B * E * p.h_pw : 0;
     w.psplit = (float*)take(w.psplit_floats * 4);
     const bool two = pl->fused_r2 != 0;
     w.P0b = (float*)take(two && p.h_L > 0 ? (size_t)B * E * p.hl[0].wc * 4 : 0);
@@ -587,12 +588,13 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
         const HodgeLayerD& h0 = p.hl[0];
         const HodgeLayerD& h = p.hl[1];
         dim3 g((h.wc + T_BN - 1) / T_BN, (rows + T_BM - 1) / T_BM, 1);
-        // few row tiles (small batches: ENZYMES_small_CC at B = 64 has 66): split K over up to CCSD_P_SPLITS slices, summed in a fixed order
-        const int tiles = (int)(g.x * g.y), nslab = (p.K + T_BK - 1) / T_BK;
-        int S = tiles >= 256 ? 1 : (512 + tiles - 1) / tiles;
-        if (S > CCSD_P_SPLITS) S = CCSD_P_SPLITS;
-        if (S > nslab) S = nslab;
-        if ((size_t)S * rows * h.wc > w.psplit_floats) S = 1;     // (no room for slices: the whole sum in place)
+        // K is ALWAYS split into the same slices (up to CCSD_P_SPLITS, one workgroup grid layer each, summed in a fixed order by
+        // k_sum_splits): the slicing is a function of (K, T_BK) alone, so the summation order of a row of P_1 -- hence every score
+        // downstream -- does not depend on the batch or shard size (a sharded run, a divide_batch chunk and the whole batch agree
+        // per sample).  Small batches need the slices anyway to fill the chip (ENZYMES_small_CC at B = 64 has 66 row tiles).
+        const int nslab = (p.K + T_BK - 1) / T_BK;
+        int S = CCSD_P_SPLITS < nslab ? CCSD_P_SPLITS : nslab;
+        if ((size_t)S * rows * h.wc > w.psplit_floats) S = 1;     // (cannot happen: carve_ws sizes the slices for every batch)
         const int kchunk = ((nslab + S - 1) / S) * T_BK;
         S = (p.K + kchunk - 1) / kchunk;
         g.z = S;

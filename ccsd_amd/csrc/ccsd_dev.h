@@ -50,6 +50,9 @@ CCSD_DEV void stamp(long long* dbg, int slot) {
 #ifdef CCSD_STOP_DIAG
     // Diagnostic build only (tools/dev/phase_mix.sh): the whole grid ends at the stamp whose slot + 1 the host wrote behind the stamp rows, so
     // that per-dispatch PMC counters of launches stopped at successive stamps difference into a per-phase instruction mix.
+    // VALID STOP SLOTS are the stamps EVERY thread of the workgroup executes (the lists XA_STOPS / R2_STOPS in tools/dev/phase_mix.py):
+    // a stamp inside a `t == 0` / single-wave branch (k_r2 slot 6) would end that wave alone -- its siblings run on, the differenced
+    // counters are wrong, and a wave stopped ahead of k_r2's s_hdone hand-over leaves the others spinning into the trap.  Never list one.
     if (dbg && dbg[((size_t)gridDim.x + 254) * 64 + 63] == slot + 1) __builtin_amdgcn_endpgm();
 #endif
     if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 64 + slot] = (long long)__builtin_readcyclecounter();

@@ -17,7 +17,7 @@ if [ "$1" = build ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $O/ccsd_hip.o tools/dev/_prof/ccsd_r2_stop.o $O/ccsd_r2b.o $O/ccsd_r2c.o $O/ccsd_r2d.o tools/dev/_prof/ccsd_xa_stop.o -o tools/dev/_prof/libccsd_stop.so
     rm tools/dev/_prof/*_stop.o
 else
-    cp tools/dev/_prof/libccsd_stop.so ccsd_amd/libccsd_hip.so
+    export CCSD_LIB_PATH=$R/tools/dev/_prof/libccsd_stop.so      # (the product library stays in place: ccsd_amd/_lib.py honours the override)
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT -d $R/gpurun_out/pm1 -o run -- python3 $R/tools/dev/phase_mix.py launch > $R/gpurun_out/pm1.log 2>&1
     rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_F32 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM -d $R/gpurun_out/pm2 -o run -- python3 $R/tools/dev/phase_mix.py launch > $R/gpurun_out/pm2.log 2>&1
