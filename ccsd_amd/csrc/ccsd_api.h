@@ -100,6 +100,7 @@ struct ccsd_plan {
     int opt_xa_prio = 0;                                       // CCSD_XA_PRIO (diagnostic: k_xa issue-priority scheme)
     int opt_xa_stagger_mask = 0, opt_xa_stagger_sleep = 0;     // CCSD_XA_STAGGER="mask,sleep" (diagnostic)
     int opt_no_merge = 0;                                      // CCSD_NO_MERGE (diagnostic: separate norms / predictor k_r2 launches)
+    int opt_no_tiled_fuse = 0;                                 // CCSD_NO_TILED_FUSE (diagnostic: k_noise_norm / k_langevin_apply as launches of their own on the tiled path)
     int opt_r2_masked = 1;                                     // CCSD_NO_R2_MASKED clears it (diagnostic: the loop's k_r2 launches re-mask rank2 in the Q_1 loader)
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     unsigned prof_mask = 0;
@@ -268,6 +269,7 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     pl->opt_no_fused_apply = getenv("CCSD_NO_FUSED_APPLY") != nullptr;
     pl->opt_no_merge = getenv("CCSD_NO_MERGE") != nullptr;
     pl->opt_r2_masked = getenv("CCSD_NO_R2_MASKED") == nullptr;
+    pl->opt_no_tiled_fuse = getenv("CCSD_NO_TILED_FUSE") != nullptr;
     if (const char* pr = getenv("CCSD_XA_PRIO")) pl->opt_xa_prio = atoi(pr);
     if (const char* sg = getenv("CCSD_XA_STAGGER")) sscanf(sg, "%d,%d", &pl->opt_xa_stagger_mask, &pl->opt_xa_stagger_sleep);
     if (const char* sg = getenv("CCSD_R2_STAGGER")) sscanf(sg, "%d,%d", &pl->opt_r2_stagger_mask, &pl->opt_r2_stagger_sleep);
@@ -472,7 +474,7 @@ static Workspace carve_ws(const ccsd_plan* pl, int B, void* base) {
     w.ntiles = p.is_cc ? ((p.K + T_BN - 1) / T_BN) * ((p.E + T_BM - 1) / T_BM) : 0;
     w.nchunk = p.is_cc ? (int)((((size_t)p.E * p.K + 3) / 4 + CCSD_NN_CH - 1) / CCSD_NN_CH) : 0;   // k_noise_norm / k_ew1: chunks of flat groups per sample
     { const int np = w.ntiles > w.nchunk ? w.ntiles : w.nchunk; w.part = (float*)take((size_t)B * (np ? np : 1) * 2 * 4); }
-    w.zpart = (float*)take((size_t)B * (w.nchunk ? w.nchunk : 1) * 4);
+    w.zpart = (float*)take((size_t)B * ((size_t)w.nchunk > E ? (size_t)w.nchunk : E ? E : 1) * 4);   // chunk partials of k_noise_norm, or the row partials of P0Fuse mode 1
     w.part2 = (float*)take((size_t)B * 2 * 4);
     w.sums = (float*)take(64);
     w.chan = (float*)take(p.chan_global ? (size_t)B * p.chan_rows * p.N * p.N * 4 : 0);
@@ -540,7 +542,10 @@ struct RankEpi;
 static int launch_r2(const ccsd_plan* pl, int B, const float* rank2, const float* adj, const float* flags, int want_p,
                      RankEpi& ep, NoiseArgs& na, Workspace& w, void* stream, const CorrFuse* cf, int merge_draw);
 // hodge projections for ScoreNetworkA_CC from (adj, rank2)
-static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* rank2, Workspace& w, void* stream) {
+// fuse (tiled path, h_L == 1; tiled_fuse_ok): the Langevin corrector's element-wise work on rank2 rides on the layer-0 projection
+// pass -- mode 1: the noise norm of the corrector's draw per row (-> fuse->zrow), mode 2: the corrector apply (corrected rank2 -> fuse->f1,
+// which the projection is then taken of).  See P0Fuse (ccsd_k_rank2.h).
+static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* rank2, Workspace& w, void* stream, const P0Fuse* fuse = nullptr) {
     const PlanD& p = pl->h;
     if (p.h_L < 1) return CCSD_OK;
     if (p.h_L > 2) {
@@ -558,26 +563,40 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
         const HodgeLayerD& h = p.hl[0];
         dim3 g((h.wc + T_BN - 1) / T_BN, (rows + T_BM - 1) / T_BM, 1);
         prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_P, stream);
+        P0Fuse pf{};
+        if (fuse) pf = *fuse;
 #ifndef CCSD_EMU
         const int nt = (h.wc + 15) / 16, Kp = (p.K + 31) & ~31;
         if (nt <= 4 && !pl->opt_old_gemm_p) {     // narrow projections: no 64-column padding
             const dim3 g0((rows + T_BM - 1) / T_BM);
             const float* WT = (const float*)pl->wp + h.wcatT;
+#define P0_GO(NT_, KC_, M_) hipLaunchKernelGGL((k_gemm_p0<NT_, KC_, M_>), g0, dim3(256), 0, (hipStream_t)stream, rank2, WT, w.P0, rows, p.K, Kp, h.wc, pf)
+#define P0_MODES(NT_, KC_) do { if (pf.mode == 1) P0_GO(NT_, KC_, 1); else if (pf.mode == 2) P0_GO(NT_, KC_, 2); else P0_GO(NT_, KC_, 0); } while (0)
             switch (nt) {
                 case 1:
-                    if (p.K == 1140 && p.geo_off != 1) hipLaunchKernelGGL((k_gemm_p0<1, 1140>), g0, dim3(256), 0, (hipStream_t)stream, rank2, WT, w.P0, rows, p.K, Kp, h.wc);
-                    else if (p.K == 8436 && p.geo_off != 1) hipLaunchKernelGGL((k_gemm_p0<1, 8436>), g0, dim3(256), 0, (hipStream_t)stream, rank2, WT, w.P0, rows, p.K, Kp, h.wc);
-                    else hipLaunchKernelGGL(k_gemm_p0<1>, g0, dim3(256), 0, (hipStream_t)stream, rank2, WT, w.P0, rows, p.K, Kp, h.wc);
+                    if (p.K == 1140 && p.geo_off != 1) P0_MODES(1, 1140);
+                    else if (p.K == 8436 && p.geo_off != 1) P0_GO(1, 8436, 0);      // (k_ew1 plans: their corrector work rides on k_ew1)
+                    else P0_MODES(1, 0);
                     break;
-                case 2: hipLaunchKernelGGL(k_gemm_p0<2>, g0, dim3(256), 0, (hipStream_t)stream, rank2, WT, w.P0, rows, p.K, Kp, h.wc); break;
-                case 3: hipLaunchKernelGGL(k_gemm_p0<3>, g0, dim3(256), 0, (hipStream_t)stream, rank2, WT, w.P0, rows, p.K, Kp, h.wc); break;
-                default: hipLaunchKernelGGL(k_gemm_p0<4>, g0, dim3(256), 0, (hipStream_t)stream, rank2, WT, w.P0, rows, p.K, Kp, h.wc); break;
+                case 2: P0_MODES(2, 0); break;
+                case 3: P0_MODES(3, 0); break;
+                default: P0_MODES(4, 0); break;
             }
+#undef P0_MODES
+#undef P0_GO
         } else
 #endif
-        CCSD_LAUNCH(k_gemm_p, g, dim3(CCSD_NTHREADS), 0, stream, rank2, (const float*)pl->w, w.P0, rows, p.E, p.K, h.wc,
-                    h.wcat, 0, h.mval, h.cin, (const float*)nullptr, (const unsigned long long*)w.offbits,
-                    (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, p.K);
+        {
+            const float* src = rank2;
+            if (pf.mode) {      // (host emulation / wide projections: the corrector work as an element-wise pass of its own)
+                CCSD_LAUNCH(k_p0_fuse_ew, dim3(grid_for(rows, 256)), dim3(CCSD_NTHREADS), 0, stream, rank2, pf, rows, p.K);
+                LAUNCH_CHECK();
+                if (pf.mode == 2) src = pf.f1;
+            }
+            CCSD_LAUNCH(k_gemm_p, g, dim3(CCSD_NTHREADS), 0, stream, src, (const float*)pl->w, w.P0, rows, p.E, p.K, h.wc,
+                        h.wcat, 0, h.mval, h.cin, (const float*)nullptr, (const unsigned long long*)w.offbits,
+                        (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, p.K);
+        }
         prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_P, stream);
         LAUNCH_CHECK();
     }
@@ -759,8 +778,16 @@ static inline bool merge_ok(const ccsd_plan* pl) {
     r2_shape(pl, &mt, &rs, &aff, &gen1);
     return mt == 3 && rs == 1 && aff && !gen1 && (pl->h.K & 1) == 0 && ((pl->h.E * pl->h.K) & 3) == 0;
 }
-// (k_r2 plans; k_ew1 plans whose hodge projections do not depend on the adjacency: one hodge layer)
-static inline bool fused_apply_ok(const ccsd_plan* pl) { return (pl->fused_r2 || (pl->ew1 && pl->h.h_L <= 1)) && !pl->opt_no_fused_apply; }
+// tiled rank-2 path (k_gemm_h / k_gemm_p0 / k_hf_score: community_small_CC) with ONE hodge layer: the corrector's rank2 work rides on
+// the layer-0 projection pass (P0Fuse) -- flat-keyed corrector draws, K a multiple of 4 (a Philox group = one 16-byte piece of a row)
+static inline bool tiled_fuse_ok(const ccsd_plan* pl) {
+    return pl->cfg.is_cc && !pl->fused_r2 && !pl->ew1 && pl->h.h_L == 1 && (pl->h.K & 3) == 0 && pl->cfg.predictor != CCSD_PRED_S4 &&
+           pl->cfg.corrector == CCSD_CORR_LANGEVIN && !pl->opt_no_tiled_fuse;
+}
+// (k_r2 plans; k_ew1 plans whose hodge projections do not depend on the adjacency: one hodge layer; tiled plans with one hodge layer)
+static inline bool fused_apply_ok(const ccsd_plan* pl) {
+    return (pl->fused_r2 || (pl->ew1 && pl->h.h_L <= 1) || tiled_fuse_ok(pl)) && !pl->opt_no_fused_apply;
+}
 // every rank2 draw of a k_ew1 plan is keyed by flat groups (the kernel streams 16-byte pieces); otherwise only the corrector's
 static inline int predictor_flat(const ccsd_plan* pl) { return pl->ew1 ? 1 : 0; }
 
@@ -876,13 +903,22 @@ static int corrector_norms(ccsd_plan* pl, int B, int step, int it, const ccsd_st
     // When the rank2 iterate is still the base state the fused kernel serves both the A-net's projections
     // and ScoreNetworkF in one pass over rank2.
     const bool fused = pl->fused_r2 && p.is_cc && cur->rank2 == base->rank2;
+    // tiled path, one hodge layer: the noise norm of the corrector's (flat-keyed, in-kernel) rank2 draw rides on the projection pass
+    const bool zfuse = !fused && tiled_fuse_ok(pl) && na.flat_r && !na.zr;
     int ntiles = w.ntiles;
     if (fused) {
         RankEpi ep{};
         ep.mode = MODE_NORMS; ep.out = w.net_r; ep.part = w.part;
         if (!r2_done && (st = launch_r2(pl, B, cur->rank2, cur->adj, flags, 1, ep, na, w, stream))) return st;
         ntiles = 1;
-    } else if ((st = launch_p(pl, B, cur->adj, base->rank2, w, stream))) return st;
+    } else {
+        P0Fuse pf{};
+        if (zfuse) {
+            pf.mode = 1; pf.zrow = w.zpart; pf.seed = na.seed; pf.b_off = na.b_off; pf.draw = na.draw_r;
+            pf.mt = MaskTab{w.mfr, w.mfl, w.Kp, w.Ep}; pf.E = p.E;
+        }
+        if ((st = launch_p(pl, B, cur->adj, base->rank2, w, stream, zfuse ? &pf : nullptr))) return st;
+    }
     XaArgs xa{};
     xa.xX = cur->x; xa.adjX = base->adj;      // score_x(x_cur, adj_0)      solver.py:761
     xa.xA = base->x; xa.adjA = cur->adj;      // score_adj(x_0, adj_cur)    solver.py:775
@@ -907,15 +943,16 @@ static int corrector_norms(ccsd_plan* pl, int B, int step, int it, const ccsd_st
         // tiled path: the noise norm of a flat-keyed Philox draw comes from its own (traffic-free) kernel; the per-tile partials of
         // k_hf_score and its chunk partials are reduced per sample first (one workgroup per sample), then over the batch
         const bool zk = na.flat_r && !na.zr && !pl->ew1;
-        if (zk) {
+        if (zk && !zfuse) {
 #define NN_GO(EC_, KC_) CCSD_LAUNCH((k_noise_norm<EC_, KC_>), dim3(w.nchunk, B), dim3(CCSD_NTHREADS), 0, stream, na, (MaskTab{w.mfr, w.mfl, w.Kp, w.Ep}), p.E, p.K, w.zpart)
             GEO_EK(p, NN_GO);
 #undef NN_GO
             LAUNCH_CHECK();
         }
         if (zk || ntiles > 8) {
+            // (zpart: the chunk partials of k_noise_norm, or the E row partials of the fused projection pass)
             CCSD_LAUNCH(k_normpart, dim3(B), dim3(CCSD_NTHREADS), 0, stream, (const float*)w.part, ntiles, zk ? (const float*)w.zpart : (const float*)nullptr,
-                        w.nchunk, w.part2);
+                        zfuse ? p.E : w.nchunk, w.part2);
             LAUNCH_CHECK();
             part = w.part2; ntiles = 1;
         }
@@ -959,6 +996,7 @@ static int predictor(ccsd_plan* pl, int B, int step, const ccsd_state_t* in, con
     const ccsd_step_coef_t* c = &pl->coef[(size_t)step * 3];
     const bool fused = pl->fused_r2 && p.is_cc;
     const bool ew1 = pl->ew1 && p.is_cc && !fused;
+    const float* r2_in = in->rank2;           // what the rank-2 kernels of the tiled path read (the corrected state when the apply is fused)
     CorrFuse cf{};
     if (fuse_sums) {   // the Langevin corrector's apply pass runs in the prologues of this half-step's kernels
         cf.on = 1; cf.net_x = w.net_x; cf.net_adj = w.net_adj; cf.net_r = w.net_r; cf.sums = fuse_sums;
@@ -983,6 +1021,14 @@ static int predictor(ccsd_plan* pl, int B, int step, const ccsd_state_t* in, con
         ep.out = out->rank2; ep.mean = mean ? mean->rank2 : nullptr;
         if ((st = launch_ew1(pl, B, in->rank2, ep, na, w, stream, nullptr, &cf, w.net_r))) return st;
         if ((st = launch_p(pl, B, in->adj, cf.on ? (const float*)w.net_r : in->rank2, w, stream))) return st;
+    } else if (cf.on && tiled_fuse_ok(pl)) {
+        // tiled path: the corrector apply rides on the projection pass -- corrected rank2 written in place over the raw scores it
+        // consumes (w.net_r), P_0 taken of it; k_gemm_h / k_hf_score below read the corrected state from there
+        P0Fuse pf{};
+        pf.mode = 2; pf.net = w.net_r; pf.f1 = w.net_r; pf.seed = na.seed; pf.b_off = na.b_off; pf.draw = cf.draw_r;
+        pf.mt = MaskTab{w.mfr, w.mfl, w.Kp, w.Ep}; pf.E = p.E; pf.cf = cf;
+        if ((st = launch_p(pl, B, in->adj, in->rank2, w, stream, &pf))) return st;
+        r2_in = w.net_r;
     } else if ((st = launch_p(pl, B, in->adj, in->rank2, w, stream))) return st;
     XaArgs xa{};
     xa.xX = xa.xA = in->x; xa.adjX = xa.adjA = in->adj; xa.flags = flags;
@@ -994,11 +1040,11 @@ static int predictor(ccsd_plan* pl, int B, int step, const ccsd_state_t* in, con
     xa.cf = cf;
     if ((st = launch_xa(pl, B, xa, na, w, stream))) return st;
     if (p.is_cc && !fused && !ew1) {
-        if ((st = launch_h(pl, B, in->rank2, w, stream))) return st;
+        if ((st = launch_h(pl, B, r2_in, w, stream))) return st;
         RankEpi ep{};
         ep.mode = MODE_PRED; ep.pa = c[2].pa; ep.pb = c[2].pb; ep.pc = c[2].pc;
         ep.out = out->rank2; ep.mean = mean ? mean->rank2 : nullptr;
-        if ((st = launch_hf(pl, B, in->rank2, ep, na, w, stream))) return st;
+        if ((st = launch_hf(pl, B, r2_in, ep, na, w, stream))) return st;
     }
     return CCSD_OK;
 }

@@ -231,10 +231,48 @@ __global__ void k_sum_splits(const float* __restrict__ parts, float* __restrict_
 // transposed packed weights Wcat^T[col][Kp]) read back as ds_read_b128 permuted-k fragments; wave w owns rows
 // 16w..16w+15 and every 16-column tile, so no MFMA is spent on the 64-column padding of the general tile engine.
 // ---------------------------------------------------------------------------------------------
+// Fused Langevin-corrector work of the tiled path (h_L == 1, K a multiple of 4; ccsd_api.h: tiled_fuse_ok).  The projection kernel is
+// the one pass of a half-step that streams rank2 once, row by row, in 16-byte pieces = the flat Philox groups of the corrector's
+// draw (NoiseArgs::flat_r), so the corrector's element-wise work rides on it:
+//   mode 1 (norms pass):      zrow[row] = sum_k (z fl fr)^2 of the row  -- the noise norm (gen_noise_rank2 + torch.norm,
+//                              cc_utils.py:613-615, solver.py:793-797); replaces k_noise_norm;
+//   mode 2 (predictor pass):  F1 = fma(c2, z fl fr, fma(c1, net, F)) -- the corrector apply, same expression as k_langevin_apply
+//                              (solver.py:797-801) -- is what goes into LDS (P_0 = F1 Wcat_0) AND out to `f1` for k_gemm_h / k_hf_score;
+//                              replaces k_langevin_apply's pass over rank2 and the projection's own read of the corrected state.
+// `f1` may alias `net` (every element is read, then written, by the same thread).
+struct P0Fuse {
+    int mode;
+    const float* net; float* f1; float* zrow;
+    unsigned long long seed; long long b_off; unsigned int draw;
+    MaskTab mt; int E;
+    CorrFuse cf;
+};
+// element-wise form of the two modes (host emulation, whose projections run through the general k_gemm_p): one thread per flat group
+__global__ void k_p0_fuse_ew(const float* __restrict__ rank2, P0Fuse pf, int rows, int K) {
+    float c1 = 0.f, c2 = 0.f;
+    if (pf.mode == 2) corr_coef(pf.cf, 2, &c1, &c2);
+    const int E = pf.E;
+    for (long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(row / E), e = (int)(row - (long long)b * E);
+        float zs = 0.f;
+        for (int k = 0; k < K; k += 4) {
+            float z[4], m[4];
+            philox_normal4(pf.seed, pf.draw, pf.b_off + b, (unsigned)(((long long)e * K + k) >> 2), z);
+            group_masks(pf.mt, b, E, K, e, k, m);
+            for (int j = 0; j < 4; ++j) {
+                const float zz = z[j] * m[j];
+                const size_t gi = (size_t)row * K + k + j;
+                if (pf.mode == 1) zs = fmaf(zz, zz, zs);
+                else pf.f1[gi] = fmaf(c2, zz, fmaf(c1, pf.net[gi], rank2[gi]));
+            }
+        }
+        if (pf.mode == 1) pf.zrow[row] = zs;
+    }
+}
 #ifndef CCSD_EMU
-template <int NT, int KC = 0>          // KC: K as a compile-time constant (0: the argument); Kp follows
+template <int NT, int KC = 0, int MODE = 0>          // KC: K as a compile-time constant (0: the argument); Kp follows; MODE: P0Fuse::mode
 __global__ __launch_bounds__(256) void k_gemm_p0(const float* __restrict__ rank2, const float* __restrict__ WT, float* __restrict__ P,
-                                                 int rows, int K_, int Kp_, int wc) {
+                                                 int rows, int K_, int Kp_, int wc, P0Fuse pf) {
     const int K = KC ? KC : K_, Kp = KC ? ((KC + 31) & ~31) : Kp_;
     __shared__ __align__(16) float As[T_BM * H_LD];
     __shared__ __align__(16) float Bs[16 * NT * H_LD];
@@ -253,30 +291,66 @@ __global__ __launch_bounds__(256) void k_gemm_p0(const float* __restrict__ rank2
         }
         return v;
     };
+    // fused corrector work (MODE != 0; K % 4 == 0): the thread's two rows of every slab are fixed -> (sample, edge) once
+    float c1 = 0.f, c2 = 0.f, zacc[2] = {0.f, 0.f};
+    int fb[2] = {0, 0}, fe[2] = {0, 0};
+    if (MODE == 2) corr_coef(pf.cf, 2, &c1, &c2);
+    if (MODE) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = m0 + r0 + 32 * u, rc = row < rows ? row : rows - 1;
+            fb[u] = rc / pf.E; fe[u] = rc - fb[u] * pf.E;
+        }
+    }
+    auto ldn = [&](int row, int k) -> float4 {         // raw score beside the state (MODE 2)
+        const int rc = row < rows ? row : rows - 1, kc = k + 3 < K ? k : K - 4;
+        return *reinterpret_cast<const float4*>(pf.net + (size_t)rc * K + kc);
+    };
+    auto fuse = [&](float4& v, const float4& n, int u, int k) {
+        const int row = m0 + r0 + 32 * u;
+        if (row >= rows || k >= K) return;               // (clamped rows of the last workgroup, zero padding of the last slab)
+        float z[4], m[4];
+        philox_normal4(pf.seed, pf.draw, pf.b_off + fb[u], (unsigned)((fe[u] * K + k) >> 2), z);
+        group_masks(pf.mt, fb[u], pf.E, K, fe[u], k, m);
+        if (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float zz = z[j] * m[j]; zacc[u] = fmaf(zz, zz, zacc[u]); }
+        } else {
+            v.x = fmaf(c2, z[0] * m[0], fmaf(c1, n.x, v.x)); v.y = fmaf(c2, z[1] * m[1], fmaf(c1, n.y, v.y));
+            v.z = fmaf(c2, z[2] * m[2], fmaf(c1, n.z, v.z)); v.w = fmaf(c2, z[3] * m[3], fmaf(c1, n.w, v.w));
+            *reinterpret_cast<float4*>(pf.f1 + (size_t)row * K + k) = v;
+        }
+    };
     f32x4 acc[NT];
 #pragma unroll
     for (int c = 0; c < NT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 ra[2], rb[(NT + 1) / 2];
-    auto load_slab = [&](int k0) {
-        ra[0] = lda(m0 + r0, k0 + c4); ra[1] = lda(m0 + r0 + 32, k0 + c4);
+    // Register double buffering, two slabs ahead in the apply mode (its element-wise work -- Philox, masks, the f1 store -- sits
+    // between a slab's arrival and its use: with one slab in flight the memory pipe idles meanwhile), one slab ahead otherwise.
+    constexpr int NS = MODE == 2 ? 2 : 1;
+    float4 ra[NS][2], rn[NS][2], rb[NS][(NT + 1) / 2];
+    auto load_slab = [&](auto S_, int k0) {
+        constexpr int S = decltype(S_)::value;
+        ra[S][0] = lda(m0 + r0, k0 + c4); ra[S][1] = lda(m0 + r0 + 32, k0 + c4);
+        if (MODE == 2) { rn[S][0] = ldn(m0 + r0, k0 + c4); rn[S][1] = ldn(m0 + r0 + 32, k0 + c4); }
 #pragma unroll
         for (int u = 0; u < (NT + 1) / 2; ++u) {           // 16*NT weight rows x 8 float4: tid + 256u < 128*NT
             const int idx = tid + 256 * u, wr = idx >> 3;
-            rb[u] = wr < 16 * NT ? *reinterpret_cast<const float4*>(WT + (size_t)wr * Kp + k0 + (idx & 7) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[S][u] = wr < 16 * NT ? *reinterpret_cast<const float4*>(WT + (size_t)wr * Kp + k0 + (idx & 7) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    load_slab(0);
-    for (int k0 = 0; k0 < Kp; k0 += H_BK) {
+    auto slab = [&](auto S_, int k0) {                     // consume stage S (slab k0), refill it with slab k0 + NS * H_BK
+        constexpr int S = decltype(S_)::value;
+        if (MODE) { fuse(ra[S][0], rn[S][0], 0, k0 + c4); fuse(ra[S][1], rn[S][1], 1, k0 + c4); }   // (before the barrier: registers only)
         __syncthreads();
-        *reinterpret_cast<float4*>(As + r0 * H_LD + c4) = ra[0];
-        *reinterpret_cast<float4*>(As + (r0 + 32) * H_LD + c4) = ra[1];
+        *reinterpret_cast<float4*>(As + r0 * H_LD + c4) = ra[S][0];
+        *reinterpret_cast<float4*>(As + (r0 + 32) * H_LD + c4) = ra[S][1];
 #pragma unroll
         for (int u = 0; u < (NT + 1) / 2; ++u) {
             const int idx = tid + 256 * u, wr = idx >> 3;
-            if (wr < 16 * NT) *reinterpret_cast<float4*>(Bs + wr * H_LD + (idx & 7) * 4) = rb[u];
+            if (wr < 16 * NT) *reinterpret_cast<float4*>(Bs + wr * H_LD + (idx & 7) * 4) = rb[S][u];
         }
         __syncthreads();
-        if (k0 + H_BK < Kp) load_slab(k0 + H_BK);
+        if (k0 + NS * H_BK < Kp) load_slab(S_, k0 + NS * H_BK);
 #pragma unroll
         for (int t = 0; t < H_BK / 16; ++t) {
             const float4 a = *reinterpret_cast<const float4*>(As + (16 * wave + l15) * H_LD + 16 * t + 4 * kq);
@@ -288,6 +362,24 @@ __global__ __launch_bounds__(256) void k_gemm_p0(const float* __restrict__ rank2
                 acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc[c], 0, 0, 0);
                 acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc[c], 0, 0, 0);
             }
+        }
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, NS - 1> S1;
+    load_slab(S0{}, 0);
+    if (NS == 2 && H_BK < Kp) load_slab(S1{}, H_BK);
+    for (int k0 = 0; k0 < Kp; k0 += NS * H_BK) {
+        slab(S0{}, k0);
+        if (NS == 2 && k0 + H_BK < Kp) slab(S1{}, k0 + H_BK);
+    }
+    if (MODE == 1) {
+        // the row's eight column groups sit in eight consecutive lanes: fixed butterfly, lane 0 of the group stores
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float v = zacc[u];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+            const int row = m0 + r0 + 32 * u;
+            if ((tid & 7) == 0 && row < rows) pf.zrow[row] = v;
         }
     }
 #pragma unroll
