@@ -250,9 +250,13 @@ def kernel_work(wname: str, kname: str, E: int, K: int):
     if kname == "k_xa":
         f = None if wl["flop_x"] is None else wl["flop_x"] + wl["flop_a"]
         return f, None, "dense-as-written GEMM FLOPs of ScoreNetworkX + ScoreNetworkA(_CC) (SURVEY 8a)"
-    if kname in ("k_r2", "k_hf_score"):
+    if kname == "k_r2":
         return wl["flop_f"], 2 * E * K * 4, ("FLOPs: dense-as-written GEMM FLOPs of ScoreNetworkF (SURVEY 8a); bytes: read + write of rank2 "
                                              "(E*K fp32 each)")
+    if kname == "k_hf_score":
+        # tiled path: ScoreNetworkF's two contractions are two kernels -- H = F F^T in k_gemm_h, (H F) + the per-element network here
+        return 2 * E * E * K, 2 * E * K * 4, ("FLOPs: the (H F) contraction as written, 2 E^2 K (H = F F^T is k_gemm_h's; together = ScoreNetworkF's "
+                                              "dense-as-written GEMM FLOPs, SURVEY 8a); bytes: read + write of rank2 (E*K fp32 each)")
     if kname in ("k_langevin_apply", "k_s4_apply"):
         return None, 3 * E * K * 4, "read state + raw score, write state (rank2 dominates)"
     if kname == "k_ew1":
