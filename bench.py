@@ -340,6 +340,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup-seconds", type=float, default=WARMUP_MIN_SECONDS,
+                    help="repeat the W-step warm-up call until the device has been busy this long (0: exactly W steps -- profiler passes, "
+                         "whose per-launch medians should see the timed region's launch mix)")
     ap.add_argument("--workload", default="qm9_CC", choices=sorted(WORKLOADS), help="BASELINE.json config (default: the metric's)")
     ap.add_argument("--batch", type=int, default=0, help="complexes per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -450,13 +453,13 @@ def _main(real_stdout):
     wsteps = max(1, args.warmup)
     run(wsteps)
     warm_run = wsteps
-    if dev != "cpu":
+    if dev != "cpu" and args.warmup_seconds > 0:
         torch.cuda.synchronize()
         tw0 = time.perf_counter()
         run(wsteps)
         torch.cuda.synchronize()
         t1 = max(time.perf_counter() - tw0, 1e-4)
-        reps = torch.tensor([min(int(WARMUP_MIN_SECONDS / t1), 5000)], device=dev, dtype=torch.int64)
+        reps = torch.tensor([min(int(args.warmup_seconds / t1), 5000)], device=dev, dtype=torch.int64)
         if world > 1:                               # every rank must make the same number of (collective) closure calls
             dist.all_reduce(reps, op=dist.ReduceOp.MAX)
         for _ in range(int(reps.item())):

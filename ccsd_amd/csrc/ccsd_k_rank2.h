@@ -576,6 +576,75 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
     const unsigned char* const flb = mt.mfl + (size_t)b * mt.Ep;
     float s_net = 0.f, s_z = 0.f;
     const bool znorm = !na.flat_r || na.zr != nullptr;   // host-supplied draws are read per element, whatever the group layout
+#ifndef CCSD_EMU
+    bool epi_done = false;
+    if constexpr (AFFINE && NP == 1) {
+        // Affine ScoreNetworkF, one Hodge power (every shipped tiled configuration): the epilogue specialised per mode and noise source
+        // OUTSIDE the element loops -- no per-element mode branches, uniform base pointers + one 32-bit element offset per lane,
+        // whole 4-row groups without row tests.  Same arithmetic, in the same order, as the general form below (fnet_element<true>):
+        // the two agree bit for bit.  (PMC, community_small_CC: the general form issued 67 vector instructions per element.)
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const int wave = wave_index(), lane = threadIdx.x & 63;
+        const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32, l15 = lane & 15, kq = lane >> 4;
+        const float fa = p.f_alpha, fgam = p.f_gamma, fbe = p.f_betas[1];
+        const bool cn2 = p.f_cnum > 1;
+        const float* const Fbb = Fb;
+        float* const outb = ep.out + (size_t)b * E * K;
+        float* const meanb = ep.mean ? ep.mean + (size_t)b * E * K : nullptr;
+        const float* const zrb = na.zr ? na.zr + (size_t)b * E * K : nullptr;
+        auto run = [&](auto MODE_, auto ZS_) {
+            constexpr int MODE = decltype(MODE_)::value;     // 0 score, 1 norms, 2 predictor, 3 predictor + mean output
+            constexpr int ZS = decltype(ZS_)::value;         // 0: no draw, 1: in-kernel Philox (4-row groups), 2: host-supplied draws
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int e0 = m0 + wm + 16 * i + 4 * kq, k = n0 + wn + 16 * j + l15;
+                    if (k >= K || e0 >= E) continue;
+                    const f32x4 hf = accs[0].a[i][j];
+                    const float fr = (float)frb[k];
+                    const unsigned fl4 = *reinterpret_cast<const unsigned*>(flb + e0);     // e0 is a multiple of 4, rows are padded to Ep
+                    const unsigned off = (unsigned)(e0 * K + k);
+                    float z[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (ZS == 1) philox_normal4(na.seed, na.draw_r, na.b_off + b, (unsigned)((e0 >> 2) * K + k), z);
+                    const int nr = E - e0 < 4 ? E - e0 : 4;          // rows of the group inside the block (4 except in the last one)
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) {
+                        if (s2 >= nr) break;
+                        const unsigned g = off + (unsigned)(s2 * K);
+                        const float f = Fbb[g];
+                        if (ZS == 2) z[s2] = zrb[g];
+                        const float m = (float)((fl4 >> (8 * s2)) & 0xffu) * fr;          // flags_left * flags_right, cc_utils.py:590
+                        float t = fmaf(fa, f, fgam);
+                        if (cn2) t = fmaf(fbe, hf[s2], t);
+                        const float net = m * t;
+                        if (MODE == 0) {
+                            outb[g] = ep.sscale * net;
+                        } else if (MODE == 1) {
+                            outb[g] = net;
+                            s_net = fmaf(net, net, s_net);
+                            const float zz = z[s2] * m;
+                            s_z = fmaf(zz, zz, s_z);
+                        } else {
+                            const float zz = z[s2] * m;                               // gen_noise_rank2, cc_utils.py:613-615
+                            const float mean = fmaf(ep.pa, f, ep.pb * net);           // v_mean = pa*v + pb*net
+                            if (MODE == 3) meanb[g] = mean;
+                            outb[g] = fmaf(ep.pc, zz, mean);
+                        }
+                    }
+                }
+        };
+#define HF_RUN(M_, Z_) run(std::integral_constant<int, M_>{}, std::integral_constant<int, Z_>{})
+        const bool inj = na.zr != nullptr;
+        if (ep.mode == MODE_SCORE) HF_RUN(0, 0);
+        else if (ep.mode == MODE_NORMS) { if (!znorm) HF_RUN(1, 0); else if (inj) HF_RUN(1, 2); else HF_RUN(1, 1); }
+        else if (ep.mean) { if (inj) HF_RUN(3, 2); else HF_RUN(3, 1); }
+        else { if (inj) HF_RUN(2, 2); else HF_RUN(2, 1); }
+#undef HF_RUN
+        epi_done = true;
+    }
+    if (!epi_done)
+#endif
     tile_foreach4n<NP>(accs, [&](int ml, int nl, const float (*hfp)[4]) {
         const int k = n0 + nl, e0 = m0 + ml;
         if (k >= K || e0 >= E) return;

@@ -13,7 +13,7 @@ if [ "$2" = pmc ]; then
     pre=""; steps=200
     if [ "$wl" != qm9_CC ]; then pre="${wl}_"; steps=30; fi
     export PMC_WORKLOAD=$wl
-    rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_$wl -o run -- python3 $R/bench.py --workload $wl --steps $steps --warmup 10 --no-cpu-baseline --no-kernel-events > $R/gpurun_out/prof_${tag}_$wl.log 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_$wl -o run -- python3 $R/bench.py --workload $wl --steps $steps --warmup 10 --no-cpu-baseline --no-kernel-events --warmup-seconds 0 > $R/gpurun_out/prof_${tag}_$wl.log 2>&1
     echo "stats done"
     cd $R
     bash tools/pmc_run.sh ${pre}fetch FETCH_SIZE > /dev/null && echo "fetch done"
@@ -28,7 +28,7 @@ else
     python3 bench.py --workload community_small_CC --steps 60 --warmup 5 2> /dev/null > gpurun_out/${tag}_community_small_CC_full_bench.json && echo "community_small_CC (roofline + cpu baseline) done"
     for wl in community_small_CC zinc250k_CC_5b enzymes_small_CC qm9_Base_CC zinc250k community_small; do
         cd /tmp
-        rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_$wl -o run -- python3 $R/bench.py --workload $wl --steps 30 --warmup 3 --no-cpu-baseline --no-kernel-events > $R/gpurun_out/${tag}_${wl}_bench.json 2> $R/gpurun_out/${tag}_${wl}.err || echo "$wl failed"
+        rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_$wl -o run -- python3 $R/bench.py --workload $wl --steps 30 --warmup 3 --no-cpu-baseline --no-kernel-events --warmup-seconds 0 > $R/gpurun_out/${tag}_${wl}_bench.json 2> $R/gpurun_out/${tag}_${wl}.err || echo "$wl failed"
         echo "$wl done"
     done
 fi
