@@ -102,7 +102,7 @@ def kernel_source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def pmc_counters(workload: str, kernel: str):
+def pmc_counters(workload: str, kernel: str, B: int):
     """Per-launch PMC means of `kernel` from the newest committed rocprofv3 --pmc passes (separate runs: FETCH_SIZE doubled
     -- gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md HBM section --, WRITE_SIZE as is).  They are NOT
     measured in this run: the object says which file they come from and whether the kernel source has changed since."""
@@ -113,6 +113,8 @@ def pmc_counters(workload: str, kernel: str):
             continue
         meta = d.get("_meta", {})
         if meta.get("workload", "qm9_CC") != workload or kernel not in d:
+            continue
+        if meta.get("batch", WORKLOADS[workload]["batch"]) != B:       # per-launch counters belong to the batch they were collected at
             continue
         src = meta.get("kernel_src_sha16")
         return {"counters": d[kernel], "source": os.path.relpath(path, ROOT), "collected_at_commit": meta.get("commit", "round 1 (5cbf17b)"),
@@ -277,7 +279,7 @@ def roofline_obj(wname, kname, kt, B, ms_per_step, E, K):
         return None
     avg_s = kms / sampled * 1e-3
     flops, nbytes, what = kernel_work(wname, kname, E, K)
-    pmc = pmc_counters(wname, kname)
+    pmc = pmc_counters(wname, kname, B)
     bound = KERNEL_BOUND[kname]
     hbm_frac = nbytes * B / avg_s / 1e9 / PEAK_HBM_GBPS if nbytes else None
     mfma_frac = flops * B / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS if flops else None

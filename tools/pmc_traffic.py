@@ -30,7 +30,7 @@ try:
     commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=root, text=True).strip()
 except Exception:
     commit = os.environ.get("CCSD_COMMIT", "unknown")
-out["_meta"] = {"workload": workload, "commit": commit, "kernel_src_sha16": bench.kernel_source_hash(),
+out["_meta"] = {"workload": workload, "batch": bench.WORKLOADS[workload]["batch"], "commit": commit, "kernel_src_sha16": bench.kernel_source_hash(),
                 "note": f"medians over the launches of a 10-step bench run (bench.py --workload {workload} --steps 10 --warmup 2); hbm_bytes = 2*FETCH_SIZE*1024 + "
                         "WRITE_SIZE*1024 (gfx950 FETCH_SIZE half-count correction, MI355X_MICROARCH.md); separate --pmc passes"}
 json.dump(out, open(os.path.join(root, "profiles", f"{rnd}_pmc.json" if workload == "qm9_CC" else f"{rnd}_pmc_{workload}.json"), "w"), indent=1)
