@@ -10,7 +10,7 @@ tag=$1
 cd /tmp && export TMPDIR=/tmp
 if [ "$2" = pmc ]; then
     wl=${3:-qm9_CC}
-    pre=""; steps=200
+    pre=""; steps=1000
     if [ "$wl" != qm9_CC ]; then pre="${wl}_"; steps=30; fi
     export PMC_WORKLOAD=$wl
     rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_$wl -o run -- python3 $R/bench.py --workload $wl --steps $steps --warmup 10 --no-cpu-baseline --no-kernel-events --warmup-seconds 0 > $R/gpurun_out/prof_${tag}_$wl.log 2>&1
