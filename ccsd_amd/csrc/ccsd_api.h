@@ -95,7 +95,7 @@ struct ccsd_plan {
     int ew1 = 0;
     // diagnostic knobs, read from the environment ONCE at plan creation (never on the launch path):
     // CCSD_OLD_GEMM_P, CCSD_XA_THREADS, CCSD_NO_FUSED_APPLY (CCSD_NO_FUSED_R2 / CCSD_XA_PASS / CCSD_XA_GCH / CCSD_NO_CHAIN shape the plan itself)
-    int opt_old_gemm_p = 0, opt_xa_threads = 256, opt_no_fused_apply = 0;
+    int opt_old_gemm_p = 0, opt_xa_threads = 0, opt_no_fused_apply = 0;   // opt_xa_threads: 0 = by batch (launch_xa)
     int opt_r2_stagger_mask = 0, opt_r2_stagger_sleep = 0;     // CCSD_R2_STAGGER="mask,sleep" (diagnostic)
     int opt_xa_prio = 0;                                       // CCSD_XA_PRIO (diagnostic: k_xa issue-priority scheme)
     int opt_xa_stagger_mask = 0, opt_xa_stagger_sleep = 0;     // CCSD_XA_STAGGER="mask,sleep" (diagnostic)
@@ -273,7 +273,7 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     if (const char* pr = getenv("CCSD_XA_PRIO")) pl->opt_xa_prio = atoi(pr);
     if (const char* sg = getenv("CCSD_XA_STAGGER")) sscanf(sg, "%d,%d", &pl->opt_xa_stagger_mask, &pl->opt_xa_stagger_sleep);
     if (const char* sg = getenv("CCSD_R2_STAGGER")) sscanf(sg, "%d,%d", &pl->opt_r2_stagger_mask, &pl->opt_r2_stagger_sleep);
-    if (const char* xt = getenv("CCSD_XA_THREADS")) { const int v = atoi(xt); if (v >= 64 && v <= 512 && v % 64 == 0) pl->opt_xa_threads = v; }
+    if (const char* xt = getenv("CCSD_XA_THREADS")) { const int v = atoi(xt); if (v >= 64 && v <= 1024 && v % 64 == 0) pl->opt_xa_threads = v; }
     PlanBuilder pb;
     pl->nweights = ccsd_build_plan(cfg, &pl->h, pb);
     if (pb.status != CCSD_OK) { delete pl; return set_err(pb.status, pb.err); }
@@ -633,7 +633,18 @@ static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Work
     xa.P0 = set_b ? w.P0b : w.P0; xa.P1 = set_b ? w.P1b : w.P1; xa.U1 = set_b ? w.U1b : w.U1; xa.chan_ws = w.chan;
     xa.p1_raw = w.p1_raw; xa.dbg = pl->dbg ? pl->dbg + 32 : nullptr;
     xa.stagger_mask = pl->opt_xa_stagger_mask; xa.stagger_sleep = pl->opt_xa_stagger_sleep; xa.prio_mode = pl->opt_xa_prio;
-    const int xa_threads = pl->opt_xa_threads;   // 256 unless CCSD_XA_THREADS was set when the plan was created (diagnostic: 64..512)
+    // Threads per graph.  256 (four waves) is right when the batch fills the chip -- 1024 graphs = four co-resident workgroups per CU --
+    // and k_xa is bound by the latency of one graph's critical path either way; when the batch leaves a CU with one or two workgroups
+    // (B <= 256 / <= 512) the same graph runs on sixteen / eight waves: every per-pair, per-tile and per-element loop of the kernel strides
+    // by the workgroup's thread count (zinc250k B = 256: 419 -> 293 us per launch; community_small_CC B = 512: 418 -> 349 us; ENZYMES_small_CC
+    // B = 64: 236 -> 180 us).  Only the instances compiled for 4 waves per SIMD without a fixed thread count take more than 256 (XA_4WAVES in
+    // ccsd_k_xa.h); CCSD_XA_THREADS (read at plan creation) overrides the choice (diagnostic: 64 .. 1024).
+    int xa_threads = pl->opt_xa_threads;
+    if (xa_threads == 0) {
+        const int v0 = xa_variant(pl->h);
+        const bool big_ok = v0 != XA_PLAIN9 && v0 != XA_BAKED9 && (!pl->h.chan_global || v0 == XA_BAKED20 || v0 == XA_BAKED38);
+        xa_threads = !big_ok ? 256 : B <= 256 ? 1024 : B <= 512 ? 512 : 256;
+    }
     prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
     xa.wp = pl->wp; xa.hpairs = pl->hpairs;
     const dim3 xblk(CCSD_NTHREADS == 1 ? 1 : xa_threads);

@@ -87,8 +87,16 @@ __global__ __launch_bounds__(256) void k_gemm_h(const float* __restrict__ rank2,
     __shared__ __align__(16) float Bs[T_BN * H_LD];
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, wave = wave_index(), lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const bool diag = tx == ty, vec = (K & 3) == 0;
+    // Wave -> 16 x 16 sub-tiles.  Off-diagonal tiles: a 32 x 32 block (2 x 2 sub-tiles) per wave.  DIAGONAL tiles (half of a
+    // community_small complex's six): H is symmetric, only the ten sub-tiles on or above the diagonal of the 4 x 4 grid are computed and
+    // mirrored on store (the same products in the same order: bit-identical to computing both halves) -- waves 0 / 3 take the diagonal
+    // blocks without their lower sub-tile (3 each), waves 1 / 2 one sub-tile row of the off-diagonal block each (2 each): 3 sub-tiles per
+    // wave at most instead of 4, i.e. 3/4 of the matrix time of such a tile.
+    const int wm = diag ? (wave == 0 || wave == 1 ? 0 : wave == 2 ? 16 : 32) : (wave >> 1) * 32;
+    const int wn = diag ? (wave == 0 ? 0 : 32) : (wave & 1) * 32;
+    const bool row1 = !diag || wave == 0 || wave == 3;     // sub-tile row 1 of the wave's block is live
+    const bool r1c0 = !diag;                               // ... its column 0 too (never in a diagonal tile)
     // thread -> (row, 4-float column group) of the 64 x 32 slab: two groups per thread and matrix
     const int r0 = tid >> 3, c4 = (tid & 7) * 4;
     auto ldg = [&](int row, int k) -> float4 {
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(256) void k_gemm_h(const float* __restrict__ rank2,
 #pragma unroll
         for (int t = 0; t < H_BK / 16; ++t) {
             const float4 a0 = *reinterpret_cast<const float4*>(As + (wm + l15) * H_LD + 16 * t + 4 * kq);
-            const float4 a1 = *reinterpret_cast<const float4*>(As + (wm + 16 + l15) * H_LD + 16 * t + 4 * kq);
+            const float4 a1 = *reinterpret_cast<const float4*>(As + ((row1 ? wm + 16 : wm) + l15) * H_LD + 16 * t + 4 * kq);
             const float4 b0 = *reinterpret_cast<const float4*>(Bp + (wn + l15) * H_LD + 16 * t + 4 * kq);
             const float4 b1 = *reinterpret_cast<const float4*>(Bp + (wn + 16 + l15) * H_LD + 16 * t + 4 * kq);
             const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
@@ -132,11 +140,38 @@ __global__ __launch_bounds__(256) void k_gemm_h(const float* __restrict__ rank2,
             for (int j = 0; j < 4; ++j) {
                 acc.a[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[j], bv0[j], acc.a[0][0], 0, 0, 0);
                 acc.a[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[j], bv1[j], acc.a[0][1], 0, 0, 0);
-                acc.a[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[j], bv0[j], acc.a[1][0], 0, 0, 0);
-                acc.a[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[j], bv1[j], acc.a[1][1], 0, 0, 0);
+            }
+            if (r1c0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc.a[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[j], bv0[j], acc.a[1][0], 0, 0, 0);
+            }
+            if (row1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc.a[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[j], bv1[j], acc.a[1][1], 0, 0, 0);
             }
         }
     }
+    {
+        float* Hb = H + (size_t)b * E * E;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (i == 1 && !(j == 0 ? r1c0 : row1)) continue;          // (dead sub-tiles of a diagonal tile)
+                const int n = n0 + wn + 16 * j + l15;
+                if (n >= E) continue;
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    const int m = m0 + wm + 16 * i + 4 * kq + s2;
+                    if (m < E) {
+                        const float hv = (zero_diag && m == n) ? 0.f : acc.a[i][j][s2];
+                        Hb[(size_t)m * E + n] = hv;
+                        Hb[(size_t)n * E + m] = hv;                          // mirror (diagonal tiles: their lower sub-tiles)
+                    }
+                }
+            }
+    }
+    return;
 #endif
     float* Hb = H + (size_t)b * E * E;
     tile_foreach4(acc, [&](int ml, int nl, const float* v) {

@@ -188,7 +188,11 @@ CCSD_DEV XLateOut xnet_late_stage(int stage, const PlanD& p, const float* __rest
 // VAR: XA_PLAIN; XA_HB: the plan holds HodgeBaselineLayers (ScoreNetworkA_Base_CC); XA_GMH: the X-network is
 // ScoreNetworkX_GMH; XA_GEN: both, and conv = "MLP" attention.  Separate instantiations keep those branches out of the register allocation of the headline variant.
 template <bool GCH, int VAR>
-__global__ __launch_bounds__(256, GCH ? 2 : 4) void k_xa(const PlanD* __restrict__ plan, const float* __restrict__ w,
+// Launch bounds: 4 waves per SIMD (128 VGPRs) everywhere but in the run-time-plan large-graph variants (2: they need ~155 VGPRs).  The
+// instances whose thread count is not compiled in may be launched with up to 1024 threads (launch_xa: more threads per graph when the
+// batch leaves CUs with one or two workgroups -- every per-pair / per-tile loop of the kernel strides by the workgroup's thread count).
+#define XA_4WAVES(G_, V_) (!(G_) || (V_) == XA_BAKED20 || (V_) == XA_BAKED38)
+__global__ __launch_bounds__((VAR == XA_PLAIN9 || VAR == XA_BAKED9 || !XA_4WAVES(GCH, VAR)) ? 256 : 1024, XA_4WAVES(GCH, VAR) ? 4 : 2) void k_xa(const PlanD* __restrict__ plan, const float* __restrict__ w,
                                             const unsigned char* __restrict__ edges, XaArgs xa, NoiseArgs na) {
     CCSD_DYN_SMEM(sm);
     // XA_BAKED9: every plan field is a constant of the instance (the host selects it only for plans whose architecture bytes equal
