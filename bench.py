@@ -322,6 +322,11 @@ def roofline_obj(wname, kname, kt, B, ms_per_step, E, K):
                  as_written_tflops=flops * B / avg_s / 1e12,
                  note=f"achieved = MFMA busy cycles per launch (PMC) x 64 FLOP / mean launch time; the as-written model-FLOPs convention ({what}) "
                       "gives as_written_tflops, above the fp32 MFMA peak because the kernel legally skips most of that work")
+    elif bound == "mfma" and flops and flops * B / avg_s / 1e12 > PEAK_F32_MFMA_TFLOPS:
+        # as above, but no PMC pass exists for this workload / batch: the as-written rate alone is not a utilisation figure
+        o.update(achieved=None, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=None, as_written_tflops=flops * B / avg_s / 1e12,
+                 note=f"the as-written model-FLOPs convention ({what}) exceeds the fp32 MFMA peak -- the kernel legally skips most of that work --, "
+                      "and no PMC pass was collected at this workload / batch to give the executed rate")
     elif bound == "mfma" and flops:
         a = flops * B / avg_s / 1e12
         o.update(achieved=a, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=a / PEAK_F32_MFMA_TFLOPS,
