@@ -640,11 +640,13 @@ static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Work
     // B = 64: 236 -> 180 us).  Only the instances compiled for 4 waves per SIMD without a fixed thread count take more than 256 (XA_4WAVES in
     // ccsd_k_xa.h); CCSD_XA_THREADS (read at plan creation) overrides the choice (diagnostic: 64 .. 1024).
     int xa_threads = pl->opt_xa_threads;
-    if (xa_threads == 0) {
-        const int v0 = xa_variant(pl->h);
-        const bool big_ok = v0 != XA_PLAIN9 && v0 != XA_BAKED9 && (!pl->h.chan_global || v0 == XA_BAKED20 || v0 == XA_BAKED38);
-        xa_threads = !big_ok ? 256 : B <= 256 ? 1024 : B <= 512 ? 512 : 256;
-    }
+    const int v0 = xa_variant(pl->h);
+    // most threads the variant's instance may be launched with (its __launch_bounds__, XA_4WAVES in ccsd_k_xa.h; the qm9 instances have
+    // their 256 compiled in -- an override moves those plans to the run-time-geometry twin below)
+    const bool fixed256 = v0 == XA_PLAIN9 || v0 == XA_BAKED9;
+    const int max_threads = (pl->h.chan_global && v0 != XA_BAKED20 && v0 != XA_BAKED38) ? 256 : 1024;
+    if (xa_threads == 0) xa_threads = (fixed256 || max_threads == 256) ? 256 : B <= 256 ? 1024 : B <= 512 ? 512 : 256;
+    if (xa_threads > max_threads) xa_threads = max_threads;
     prof_mark(const_cast<ccsd_plan*>(pl), KID_XA, stream);
     xa.wp = pl->wp; xa.hpairs = pl->hpairs;
     const dim3 xblk(CCSD_NTHREADS == 1 ? 1 : xa_threads);

@@ -198,6 +198,18 @@ def test_alternative_kernel_paths_qm9(lib, env, monkeypatch):
     pc.case_philox_properties(lib, DEV)
 
 
+@pytest.mark.parametrize("threads", ["256", "512"])
+def test_k_xa_thread_count_is_a_speed_matter_only(lib, threads, monkeypatch):
+    """launch_xa gives a graph 1024 / 512 / 256 threads by batch (small test batches: 1024).  Any other count must reproduce the
+    reference goldens the same way (per-sample norm sums re-associate, nothing else changes): the large-graph baked instance (zinc250k),
+    the general instance behind the ENZYMES S4 sampler and a tiled-path CC checkpoint, with CCSD_XA_THREADS forcing the count."""
+    monkeypatch.setenv("CCSD_XA_THREADS", threads)
+    pc.case_pc_sampler_identical_seed("gdss_zinc250k", "gdss_zinc250k", "k5", lib, DEV)
+    pc.case_pc_sampler_identical_seed("s4_ccsd_enzymes_small_CC", "ccsd_enzymes_small_CC", "n1000_first2", lib, DEV)
+    pc.case_pc_sampler_identical_seed("ccsd_community_small_CC", "ccsd_community_small_CC", "k5", lib, DEV)
+    pc.case_forward_vs_reference_golden("gdss_community_small", lib, DEV)
+
+
 def test_full_size_community_small_cc_philox_properties(lib):
     """BASELINE configs[1] size (community_small_CC, B=512, E=190, K=1140: the tiled rank-2 kernels) for a few steps:
     size-independent properties of the state."""
