@@ -281,10 +281,18 @@ def test_kat_hodge_layers_three_and_four(lib):
 
 def test_production_loop_vs_oracle_qm9_full_batch(lib):
     """What bench.py times, at the BASELINE batch (B = 1024, realistic node-count mix): ccsd_sampler_run with in-kernel Philox
-    and the Langevin apply fused into the predictor launches, three PC steps, against the oracle replaying the exported
-    draws -- plus bit equality with the step-wise loop at the same batch."""
+    and the Langevin apply fused into the predictor launches, eight PC steps (seven merged k_r2 launches), against the oracle
+    replaying the exported draws -- plus bit equality with the step-wise loop at the same batch."""
     pc.case_production_loop_vs_oracle("ccsd_qm9_CC", lib, DEV, 1024, [9, 9, 8, 9, 7, 9, 9, 6, 9, 5, 9, 9, 4, 9, 8, 9, 3, 9, 7, 2, 9, 1],
-                                      3, "Reverse", "Langevin", 0.2, 0.7, seed=17, expect_fused=True)
+                                      8, "Reverse", "Langevin", 0.2, 0.7, seed=17, expect_fused=True)
+
+
+def test_production_loop_vs_oracle_community_small_cc_full_batch(lib):
+    """BASELINE configs[1] at its own batch (community_small_CC, B = 512, the dataset's node-count mix): the tiled rank-2 kernels with
+    the corrector riding on the projection passes, k_xa on 512 threads per graph -- two PC steps of ccsd_sampler_run against the oracle
+    on the exported draws, and bit equality with the step-wise loop."""
+    pc.case_production_loop_vs_oracle("ccsd_community_small_CC", lib, DEV, 512, [12] * 29 + [14] * 14 + [16] * 23 + [18] * 25 + [20] * 9,
+                                      2, "Euler", "Langevin", 0.05, 0.7, seed=29, expect_fused=True)
 
 
 def test_production_loop_vs_oracle_tiled_path(lib):
