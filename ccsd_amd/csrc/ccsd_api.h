@@ -473,7 +473,8 @@ static Workspace carve_ws(const ccsd_plan* pl, int B, void* base) {
     w.norm2 = (float*)take((size_t)B * 4 * 4);
     w.ntiles = p.is_cc ? ((p.K + T_BN - 1) / T_BN) * ((p.E + T_BM - 1) / T_BM) : 0;
     w.nchunk = p.is_cc ? (int)((((size_t)p.E * p.K + 3) / 4 + CCSD_NN_CH - 1) / CCSD_NN_CH) : 0;   // k_noise_norm / k_ew1: chunks of flat groups per sample
-    { const int np = w.ntiles > w.nchunk ? w.ntiles : w.nchunk; w.part = (float*)take((size_t)B * (np ? np : 1) * 2 * 4); }
+    { int np = w.ntiles > w.nchunk ? w.ntiles : w.nchunk; if ((int)E > np) np = (int)E;      // (per-row partials of P0Fuse mode 3)
+      w.part = (float*)take((size_t)B * (np ? np : 1) * 2 * 4); }
     w.zpart = (float*)take((size_t)B * ((size_t)w.nchunk > E ? (size_t)w.nchunk : E ? E : 1) * 4);   // chunk partials of k_noise_norm, or the row partials of P0Fuse mode 1
     w.part2 = (float*)take((size_t)B * 2 * 4);
     w.sums = (float*)take(64);
@@ -571,11 +572,12 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
             const dim3 g0((rows + T_BM - 1) / T_BM);
             const float* WT = (const float*)pl->wp + h.wcatT;
 #define P0_GO(NT_, KC_, M_) hipLaunchKernelGGL((k_gemm_p0<NT_, KC_, M_>), g0, dim3(256), 0, (hipStream_t)stream, rank2, WT, w.P0, rows, p.K, Kp, h.wc, pf)
-#define P0_MODES(NT_, KC_) do { if (pf.mode == 1) P0_GO(NT_, KC_, 1); else if (pf.mode == 2) P0_GO(NT_, KC_, 2); else P0_GO(NT_, KC_, 0); } while (0)
+#define P0_MODES(NT_, KC_) do { if (pf.mode == 1) P0_GO(NT_, KC_, 1); else if (pf.mode == 2) P0_GO(NT_, KC_, 2); \
+                                else if (pf.mode == 3) P0_GO(NT_, KC_, 3); else if (pf.mode == 4) P0_GO(NT_, KC_, 4); else P0_GO(NT_, KC_, 0); } while (0)
             switch (nt) {
                 case 1:
                     if (p.K == 1140 && p.geo_off != 1) P0_MODES(1, 1140);
-                    else if (p.K == 8436 && p.geo_off != 1) P0_GO(1, 8436, 0);      // (k_ew1 plans: their corrector work rides on k_ew1)
+                    else if (p.K == 8436 && p.geo_off != 1) P0_MODES(1, 8436);
                     else P0_MODES(1, 0);
                     break;
                 case 2: P0_MODES(2, 0); break;
@@ -591,7 +593,7 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
             if (pf.mode) {      // (host emulation / wide projections: the corrector work as an element-wise pass of its own)
                 CCSD_LAUNCH(k_p0_fuse_ew, dim3(grid_for(rows, 256)), dim3(CCSD_NTHREADS), 0, stream, rank2, pf, rows, p.K);
                 LAUNCH_CHECK();
-                if (pf.mode == 2) src = pf.f1;
+                if (pf.mode == 2 || pf.mode == 4) src = pf.f1;
             }
             CCSD_LAUNCH(k_gemm_p, g, dim3(CCSD_NTHREADS), 0, stream, src, (const float*)pl->w, w.P0, rows, p.E, p.K, h.wc,
                         h.wcat, 0, h.mval, h.cin, (const float*)nullptr, (const unsigned long long*)w.offbits,
@@ -797,6 +799,11 @@ static inline bool tiled_fuse_ok(const ccsd_plan* pl) {
     return pl->cfg.is_cc && !pl->fused_r2 && !pl->ew1 && pl->h.h_L == 1 && (pl->h.K & 3) == 0 && pl->cfg.predictor != CCSD_PRED_S4 &&
            pl->cfg.corrector == CCSD_CORR_LANGEVIN && !pl->opt_no_tiled_fuse;
 }
+// element-wise ScoreNetworkF plans (k_ew1's: affine, cnum = 1) with ONE hodge layer: the whole rank-2 side of a half-step rides on the
+// layer-0 projection pass (P0Fuse modes 3 / 4) -- one read of rank2 per norms pass, one read + one write per predictor pass
+static inline bool ew1_fuse_ok(const ccsd_plan* pl) {
+    return pl->ew1 && pl->h.h_L == 1 && (pl->h.K & 3) == 0 && pl->cfg.corrector == CCSD_CORR_LANGEVIN && !pl->opt_no_tiled_fuse;
+}
 // (k_r2 plans; k_ew1 plans whose hodge projections do not depend on the adjacency: one hodge layer; tiled plans with one hodge layer)
 static inline bool fused_apply_ok(const ccsd_plan* pl) {
     return (pl->fused_r2 || (pl->ew1 && pl->h.h_L <= 1) || tiled_fuse_ok(pl)) && !pl->opt_no_fused_apply;
@@ -918,6 +925,8 @@ static int corrector_norms(ccsd_plan* pl, int B, int step, int it, const ccsd_st
     const bool fused = pl->fused_r2 && p.is_cc && cur->rank2 == base->rank2;
     // tiled path, one hodge layer: the noise norm of the corrector's (flat-keyed, in-kernel) rank2 draw rides on the projection pass
     const bool zfuse = !fused && tiled_fuse_ok(pl) && na.flat_r && !na.zr;
+    // element-wise ScoreNetworkF plans: raw score + both norms per row ride on it too (no k_ew1 launch in this pass)
+    const bool e1fuse = !fused && ew1_fuse_ok(pl) && na.flat_r && !na.zr;
     int ntiles = w.ntiles;
     if (fused) {
         RankEpi ep{};
@@ -930,7 +939,12 @@ static int corrector_norms(ccsd_plan* pl, int B, int step, int it, const ccsd_st
             pf.mode = 1; pf.zrow = w.zpart; pf.seed = na.seed; pf.b_off = na.b_off; pf.draw = na.draw_r;
             pf.mt = MaskTab{w.mfr, w.mfl, w.Kp, w.Ep}; pf.E = p.E;
         }
-        if ((st = launch_p(pl, B, cur->adj, base->rank2, w, stream, zfuse ? &pf : nullptr))) return st;
+        if (e1fuse && cur->rank2 == base->rank2) {
+            pf.mode = 3; pf.zrow = w.part; pf.seed = na.seed; pf.b_off = na.b_off; pf.draw = na.draw_r;
+            pf.mt = MaskTab{w.mfr, w.mfl, w.Kp, w.Ep}; pf.E = p.E; pf.alpha = p.f_alpha; pf.gamma = p.f_gamma;
+            pf.net_out = keep_net ? w.net_r : nullptr;
+        }
+        if ((st = launch_p(pl, B, cur->adj, base->rank2, w, stream, pf.mode ? &pf : nullptr))) return st;
     }
     XaArgs xa{};
     xa.xX = cur->x; xa.adjX = base->adj;      // score_x(x_cur, adj_0)      solver.py:761
@@ -938,7 +952,9 @@ static int corrector_norms(ccsd_plan* pl, int B, int step, int it, const ccsd_st
     xa.flags = flags; xa.do_x = xa.do_a = 1; xa.mode = MODE_NORMS;
     xa.out_x = w.net_x; xa.out_a = w.net_adj; xa.norm2 = w.norm2;
     if ((st = launch_xa(pl, B, xa, na, w, stream, fused && r2_done))) return st;
-    if (p.is_cc && !fused && pl->ew1) {
+    if (p.is_cc && !fused && pl->ew1 && e1fuse && cur->rank2 == base->rank2) {
+        ntiles = p.E;                            // (per-row partials written by the projection pass above)
+    } else if (p.is_cc && !fused && pl->ew1) {
         // element-wise ScoreNetworkF: one streaming pass gives both norm partials per (sample, chunk); the raw score is kept only
         // for a separate ccsd_corrector_apply (the fused loop recomputes it)
         RankEpi ep{};
@@ -1026,6 +1042,15 @@ static int predictor(ccsd_plan* pl, int B, int step, const ccsd_state_t* in, con
         // draw_base(step + 1, 0))
         const int md = merge_next ? (int)draw_base(pl, step + 1, 0) + 2 : -1;
         if ((st = launch_r2(pl, B, in->rank2, in->adj, flags, 1, ep, na, w, stream, &cf, md))) return st;
+    } else if (ew1 && cf.on && ew1_fuse_ok(pl) && !na.zr) {
+        // element-wise ScoreNetworkF, one hodge layer: corrector apply + projection + predictor update in ONE pass over rank2
+        P0Fuse pf{};
+        pf.mode = 4; pf.seed = na.seed; pf.b_off = na.b_off; pf.draw = cf.draw_r; pf.draw_pred = na.draw_r;
+        pf.mt = MaskTab{w.mfr, w.mfl, w.Kp, w.Ep}; pf.E = p.E; pf.cf = cf;
+        pf.alpha = p.f_alpha; pf.gamma = p.f_gamma; pf.pa = c[2].pa; pf.pb = c[2].pb; pf.pc = c[2].pc;
+        pf.out = out->rank2; pf.mean = mean ? mean->rank2 : nullptr;
+        pf.f1 = w.net_r;                         // (host emulation only: its projection runs as a pass of its own over the corrected state)
+        if ((st = launch_p(pl, B, in->adj, in->rank2, w, stream, &pf))) return st;
     } else if (ew1) {
         // element-wise ScoreNetworkF first: with the fused apply it produces the corrected rank2 (in the raw-score scratch, which
         // the fused loop does not fill) that the hodge projections of the A-network must see

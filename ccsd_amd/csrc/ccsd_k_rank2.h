@@ -275,33 +275,63 @@ __global__ void k_sum_splits(const float* __restrict__ parts, float* __restrict_
 //                              (solver.py:797-801) -- is what goes into LDS (P_0 = F1 Wcat_0) AND out to `f1` for k_gemm_h / k_hf_score;
 //                              replaces k_langevin_apply's pass over rank2 and the projection's own read of the corrected state.
 // `f1` may alias `net` (every element is read, then written, by the same thread).
+// Plans whose ScoreNetworkF is affine with cnum = 1 (k_ew1's: net = fl fr (alpha F + gamma), no Hodge Laplacian term -- the N = 38
+// substitute for zinc250k_CC) have NO other rank-2 kernel in a half-step, so there the whole rank-2 side rides on the projection pass:
+//   mode 3 (norms pass):      per row { sum net^2, sum (z fl fr)^2 } -> zrow[row][2]  (+ the raw score to `net_out` when a separate
+//                              ccsd_corrector_apply will want it); the projection is of the state as given;
+//   mode 4 (predictor pass):  F1 = corrector apply with the raw score recomputed in place (as k_ew1 does), P_0 = F1 Wcat_0,
+//                              new state = fma(pc, z' fl fr, fma(pa, F1, pb net(F1))) -> `out` (+ the mean -> `mean`), z' = the
+//                              predictor's flat-keyed draw.  Same expressions, in the same order, as k_ew1 / k_langevin_apply.
+// One read of rank2 per norms pass (k_ew1 + k_gemm_p0 read it twice) and one read + one write per predictor pass (k_ew1: one read, two
+// writes; k_gemm_p0: one more read): 18 GB instead of 36 GB per PC step at E = 703, K = 8436, B = 256.
 struct P0Fuse {
     int mode;
     const float* net; float* f1; float* zrow;
     unsigned long long seed; long long b_off; unsigned int draw;
     MaskTab mt; int E;
     CorrFuse cf;
+    // modes 3 / 4
+    float alpha, gamma, pa, pb, pc;
+    unsigned int draw_pred;
+    float* out; float* mean; float* net_out;
 };
 // element-wise form of the two modes (host emulation, whose projections run through the general k_gemm_p): one thread per flat group
 __global__ void k_p0_fuse_ew(const float* __restrict__ rank2, P0Fuse pf, int rows, int K) {
     float c1 = 0.f, c2 = 0.f;
-    if (pf.mode == 2) corr_coef(pf.cf, 2, &c1, &c2);
+    if (pf.mode == 2 || pf.mode == 4) corr_coef(pf.cf, 2, &c1, &c2);
     const int E = pf.E;
     for (long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += (long long)gridDim.x * blockDim.x) {
         const int b = (int)(row / E), e = (int)(row - (long long)b * E);
-        float zs = 0.f;
+        float zs = 0.f, ns = 0.f;
         for (int k = 0; k < K; k += 4) {
-            float z[4], m[4];
-            philox_normal4(pf.seed, pf.draw, pf.b_off + b, (unsigned)(((long long)e * K + k) >> 2), z);
+            float z[4], zp[4] = {0.f, 0.f, 0.f, 0.f}, m[4];
+            const unsigned g = (unsigned)(((long long)e * K + k) >> 2);
+            philox_normal4(pf.seed, pf.draw, pf.b_off + b, g, z);
+            if (pf.mode == 4) philox_normal4(pf.seed, pf.draw_pred, pf.b_off + b, g, zp);
             group_masks(pf.mt, b, E, K, e, k, m);
             for (int j = 0; j < 4; ++j) {
                 const float zz = z[j] * m[j];
                 const size_t gi = (size_t)row * K + k + j;
                 if (pf.mode == 1) zs = fmaf(zz, zz, zs);
-                else pf.f1[gi] = fmaf(c2, zz, fmaf(c1, pf.net[gi], rank2[gi]));
+                else if (pf.mode == 2) pf.f1[gi] = fmaf(c2, zz, fmaf(c1, pf.net[gi], rank2[gi]));
+                else if (pf.mode == 3) {
+                    const float net = m[j] * fmaf(pf.alpha, rank2[gi], pf.gamma);
+                    ns = fmaf(net, net, ns); zs = fmaf(zz, zz, zs);
+                    if (pf.net_out) pf.net_out[gi] = net;
+                } else {
+                    float f = rank2[gi];
+                    float net = m[j] * fmaf(pf.alpha, f, pf.gamma);
+                    f = fmaf(c2, zz, fmaf(c1, net, f));
+                    pf.f1[gi] = f;
+                    net = m[j] * fmaf(pf.alpha, f, pf.gamma);
+                    const float mean = fmaf(pf.pa, f, pf.pb * net);
+                    if (pf.mean) pf.mean[gi] = mean;
+                    pf.out[gi] = fmaf(pf.pc, zp[j] * m[j], mean);
+                }
             }
         }
         if (pf.mode == 1) pf.zrow[row] = zs;
+        if (pf.mode == 3) { pf.zrow[2 * row] = ns; pf.zrow[2 * row + 1] = zs; }
     }
 }
 #ifndef CCSD_EMU
@@ -327,9 +357,9 @@ __global__ __launch_bounds__(256) void k_gemm_p0(const float* __restrict__ rank2
         return v;
     };
     // fused corrector work (MODE != 0; K % 4 == 0): the thread's two rows of every slab are fixed -> (sample, edge) once
-    float c1 = 0.f, c2 = 0.f, zacc[2] = {0.f, 0.f};
+    float c1 = 0.f, c2 = 0.f, zacc[2] = {0.f, 0.f}, nacc[2] = {0.f, 0.f};
     int fb[2] = {0, 0}, fe[2] = {0, 0};
-    if (MODE == 2) corr_coef(pf.cf, 2, &c1, &c2);
+    if (MODE == 2 || MODE == 4) corr_coef(pf.cf, 2, &c1, &c2);
     if (MODE) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -350,10 +380,36 @@ __global__ __launch_bounds__(256) void k_gemm_p0(const float* __restrict__ rank2
         if (MODE == 1) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { const float zz = z[j] * m[j]; zacc[u] = fmaf(zz, zz, zacc[u]); }
-        } else {
+        } else if (MODE == 2) {
             v.x = fmaf(c2, z[0] * m[0], fmaf(c1, n.x, v.x)); v.y = fmaf(c2, z[1] * m[1], fmaf(c1, n.y, v.y));
             v.z = fmaf(c2, z[2] * m[2], fmaf(c1, n.z, v.z)); v.w = fmaf(c2, z[3] * m[3], fmaf(c1, n.w, v.w));
             *reinterpret_cast<float4*>(pf.f1 + (size_t)row * K + k) = v;
+        } else if (MODE == 3) {
+            const float f[4] = {v.x, v.y, v.z, v.w};
+            float net[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                net[j] = m[j] * fmaf(pf.alpha, f[j], pf.gamma);                // fnet_element<AFFINE>, cnum = 1 (k_ew1)
+                const float zz = z[j] * m[j];
+                nacc[u] = fmaf(net[j], net[j], nacc[u]);
+                zacc[u] = fmaf(zz, zz, zacc[u]);
+            }
+            if (pf.net_out) *reinterpret_cast<float4*>(pf.net_out + (size_t)row * K + k) = make_float4(net[0], net[1], net[2], net[3]);
+        } else {
+            float zp[4];
+            philox_normal4(pf.seed, pf.draw_pred, pf.b_off + fb[u], (unsigned)((fe[u] * K + k) >> 2), zp);
+            float f[4] = {v.x, v.y, v.z, v.w}, o[4], mu[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float net = m[j] * fmaf(pf.alpha, f[j], pf.gamma);
+                f[j] = fmaf(c2, z[j] * m[j], fmaf(c1, net, f[j]));             // k_langevin_apply
+                net = m[j] * fmaf(pf.alpha, f[j], pf.gamma);
+                mu[j] = fmaf(pf.pa, f[j], pf.pb * net);                        // v_mean = pa*v + pb*net
+                o[j] = fmaf(pf.pc, zp[j] * m[j], mu[j]);
+            }
+            v = make_float4(f[0], f[1], f[2], f[3]);                            // the corrected state: what the projection is taken of
+            *reinterpret_cast<float4*>(pf.out + (size_t)row * K + k) = make_float4(o[0], o[1], o[2], o[3]);
+            if (pf.mean) *reinterpret_cast<float4*>(pf.mean + (size_t)row * K + k) = make_float4(mu[0], mu[1], mu[2], mu[3]);
         }
     };
     f32x4 acc[NT];
@@ -361,7 +417,7 @@ __global__ __launch_bounds__(256) void k_gemm_p0(const float* __restrict__ rank2
     for (int c = 0; c < NT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // Register double buffering, two slabs ahead in the apply mode (its element-wise work -- Philox, masks, the f1 store -- sits
     // between a slab's arrival and its use: with one slab in flight the memory pipe idles meanwhile), one slab ahead otherwise.
-    constexpr int NS = MODE == 2 ? 2 : 1;
+    constexpr int NS = (MODE == 2 || MODE == 4) ? 2 : 1;
     float4 ra[NS][2], rn[NS][2], rb[NS][(NT + 1) / 2];
     auto load_slab = [&](auto S_, int k0) {
         constexpr int S = decltype(S_)::value;
@@ -375,7 +431,10 @@ __global__ __launch_bounds__(256) void k_gemm_p0(const float* __restrict__ rank2
     };
     auto slab = [&](auto S_, int k0) {                     // consume stage S (slab k0), refill it with slab k0 + NS * H_BK
         constexpr int S = decltype(S_)::value;
-        if (MODE) { fuse(ra[S][0], rn[S][0], 0, k0 + c4); fuse(ra[S][1], rn[S][1], 1, k0 + c4); }   // (before the barrier: registers only)
+        if (MODE) {                                                                  // (before the barrier: registers only)
+            fuse(ra[S][0], MODE == 2 ? rn[S][0] : ra[S][0], 0, k0 + c4);
+            fuse(ra[S][1], MODE == 2 ? rn[S][1] : ra[S][1], 1, k0 + c4);
+        }
         __syncthreads();
         *reinterpret_cast<float4*>(As + r0 * H_LD + c4) = ra[S][0];
         *reinterpret_cast<float4*>(As + (r0 + 32) * H_LD + c4) = ra[S][1];
@@ -407,14 +466,18 @@ __global__ __launch_bounds__(256) void k_gemm_p0(const float* __restrict__ rank2
         slab(S0{}, k0);
         if (NS == 2 && k0 + H_BK < Kp) slab(S1{}, k0 + H_BK);
     }
-    if (MODE == 1) {
+    if (MODE == 1 || MODE == 3) {
         // the row's eight column groups sit in eight consecutive lanes: fixed butterfly, lane 0 of the group stores
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            float v = zacc[u];
+            float v = zacc[u], w2 = nacc[u];
             v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+            if (MODE == 3) { w2 += __shfl_xor(w2, 1, 64); w2 += __shfl_xor(w2, 2, 64); w2 += __shfl_xor(w2, 4, 64); }
             const int row = m0 + r0 + 32 * u;
-            if ((tid & 7) == 0 && row < rows) pf.zrow[row] = v;
+            if ((tid & 7) == 0 && row < rows) {
+                if (MODE == 1) pf.zrow[row] = v;
+                else { pf.zrow[2 * (size_t)row] = w2; pf.zrow[2 * (size_t)row + 1] = v; }
+            }
         }
     }
 #pragma unroll
