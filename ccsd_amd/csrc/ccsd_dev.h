@@ -276,6 +276,35 @@ CCSD_DEV float block_sum(float v, float* red) {
 #endif
 }
 
+// NV block-wide sums at once (one pair of barriers instead of NV triples); each value in block_sum's order, so bit-identical to NV
+// block_sum calls.  Results valid in every thread.  `red` = 16 * NV floats of LDS.
+template <int NV>
+CCSD_DEV void block_sums(float (&v)[NV], float* red) {
+#ifdef CCSD_EMU
+    (void)v; (void)red;
+#else
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o, 64);
+    }
+    const int wave = wave_index(), lane = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) red[wave * NV + i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float t = 0.f;
+        for (int w = 0; w < nw; ++w) t += red[w * NV + i];
+        v[i] = t;
+    }
+    __syncthreads();
+#endif
+}
+
 // per-thread MLP over at most W features (fully unrolled, predicated: stays in registers).
 // Restates layers.py:260-275 for the tiny channel-mixing MLPs (hodge branch, ScoreNetworkF).
 template <int W>

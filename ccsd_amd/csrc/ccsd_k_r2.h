@@ -1077,8 +1077,9 @@ __global__ __launch_bounds__(512, 4) void k_r2(const PlanD* __restrict__ plan, c
     // (no phase 3: the epilogue wrote the results to HBM)
     stamp(ra.dbg, 4);
     if (ep.mode == MODE_NORMS) {
-        const float tn_ = block_sum(s_net, sRed);
-        const float tz_ = block_sum(s_z, sRed);
+        float t2_[2] = {s_net, s_z};
+        block_sums<2>(t2_, sRed);
+        const float tn_ = t2_[0], tz_ = t2_[1];
         if (tid == 0) { ep.part[(size_t)b * 2 + 0] = tn_; ep.part[(size_t)b * 2 + 1] = tz_; }
     }
     stamp(ra.dbg, 5);

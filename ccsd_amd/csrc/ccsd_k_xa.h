@@ -1219,8 +1219,9 @@ __global__ __launch_bounds__((VAR == XA_PLAIN9 || VAR == XA_BAKED9 || !XA_4WAVES
 #endif
     if (xa.mode == MODE_NORMS) {
         __syncthreads();
-        const float t0 = block_sum(nx_net, s_red), t1 = block_sum(na_net, s_red);
-        const float t2 = block_sum(nx_z, s_red), t3 = block_sum(na_z, s_red);
+        float t4[4] = {nx_net, na_net, nx_z, na_z};
+        block_sums<4>(t4, s_red);
+        const float t0 = t4[0], t1 = t4[1], t2 = t4[2], t3 = t4[3];
         if (tid == 0) {
             float* o = xa.norm2 + (size_t)b * 4;
             if (xa.do_x) { o[0] = t0; o[2] = t2; }
