@@ -93,6 +93,10 @@ struct ccsd_plan {
     size_t r2_lds = 0;
     // element-wise rank-2 side (k_ew1): affine ScoreNetworkF without a Hodge Laplacian term (cnum = 1), tiled path, PC samplers
     int ew1 = 0;
+    // general hodge stack: more than two HodgeAdjAttentionLayers whose later projections cannot be folded into rank2's (a non-affine
+    // mlp_value, or no fused rank-2 kernel for the geometry): R_l is materialised layer by layer (k_hodge_value) from the dense hodge
+    // adjacencies k_xa<., XA_GEN> dumps (launch_xa); CCSD_HODGE_GENERAL forces it for any plan with more than two layers (diagnostic)
+    int h_general = 0;
     // diagnostic knobs, read from the environment ONCE at plan creation (never on the launch path):
     // CCSD_OLD_GEMM_P, CCSD_XA_THREADS, CCSD_NO_FUSED_APPLY (CCSD_NO_FUSED_R2 / CCSD_XA_PASS / CCSD_XA_GCH / CCSD_NO_CHAIN shape the plan itself)
     int opt_old_gemm_p = 0, opt_xa_threads = 0, opt_no_fused_apply = 0;   // opt_xa_threads: 0 = by batch (launch_xa)
@@ -383,12 +387,14 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
             pl->fused_r2 = 1; pl->r2_ldk = ldk; pl->r2_ldh = ldh; pl->r2_lds = fl * 4;
         }
     }
+    if (pl->h.h_L > 2) {
+        bool affine_values = true;
+        for (int l = 0; l + 1 < pl->h.h_L; ++l) affine_values = affine_values && ccsd_hl(pl->h, l).mval.n == 1;
+        // (the folded route -- k_r2 hands over one consolidated projection, k_xa chains the M_j -- is built and tested for up to four layers)
+        if (!affine_values || !pl->fused_r2 || pl->h.h_L > 4 || getenv("CCSD_HODGE_GENERAL") != nullptr) { pl->h_general = 1; pl->fused_r2 = 0; }
+    }
     pl->ew1 = cfg->is_cc && !pl->fused_r2 && pl->h.f_affine && pl->h.f_cnum == 1 && cfg->predictor != CCSD_PRED_S4 &&
               getenv("CCSD_NO_EW1") == nullptr;
-    if (pl->h.h_L > 2 && !pl->fused_r2) {
-        ccsd_plan_destroy(pl);
-        return set_err(CCSD_ERR_UNSUPPORTED, "more than two HodgeAdjAttentionLayers need the fused rank-2 kernel (E <= 64, cnum <= 2, hidden widths <= 16)");
-    }
 #ifndef CCSD_EMU
     if ((size_t)pl->h.xa_lds_floats * 4 > 64 * 1024) {
         PC(rt_set_max_dyn_smem(xa_kernel(pl->h), (size_t)pl->h.xa_lds_floats * 4));
@@ -442,6 +448,9 @@ struct Workspace {
     float* psplit; size_t psplit_floats;   // K slices of the layer-1 projection (k_gemm_p with few row tiles)
     float *P0b, *P1b, *U1b;         // second set of hodge projections (merged k_r2 launch: the next norms pass's)
     int ntiles, nchunk;
+    float *hgH, *hgR[2], *hgP[CCSD_MAXHL + CCSD_MAXHLX - 1];   // general hodge stack: dumped H^l, R_l (two alternating), P_l of the layers >= 1
+    size_t hg_hstride;
+    const float* hg_rank2;          // (the rank2 launch_p saw: launch_xa continues from it)
     int p1_raw;     // who filled P1 last: k_r2 with the raw factors (1, see k_r2) or k_gemm_p with the finished projections (0)
     size_t bytes;
 };
@@ -467,6 +476,15 @@ static Workspace carve_ws(const ccsd_plan* pl, int B, void* base) {
     w.P1b = (float*)take(two && p.h_L > 1 ? (size_t)B * E * p.h_pw * 4 : 0);
     w.U1b = (float*)take(two && p.h_L > 1 ? (size_t)B * p.h_pw * 4 : 0);
     w.acoef = (float*)take(p.h_L > 1 ? (size_t)B * p.a_cinit * E * 4 : 0);
+    if (pl->h_general) {
+        int cmax = 1;
+        for (int l = 0; l + 1 < p.h_L; ++l) cmax = ccsd_hl(p, l).cout > cmax ? ccsd_hl(p, l).cout : cmax;
+        w.hg_hstride = (size_t)cmax * E * E;
+        w.hgH = (float*)take((size_t)B * w.hg_hstride * 4);
+        w.hgR[0] = (float*)take((size_t)B * E * K * 4);
+        w.hgR[1] = (float*)take((size_t)B * E * K * 4);
+        for (int l = 1; l < p.h_L; ++l) w.hgP[l - 1] = (float*)take((size_t)B * E * ccsd_hl(p, l).wc * 4);
+    }
     w.net_x = (float*)take((size_t)B * p.N * p.F * 4);
     w.net_adj = (float*)take((size_t)B * p.N * p.N * 4);
     w.net_r = (float*)take(p.is_cc ? (size_t)B * E * K * 4 : 0);
@@ -549,7 +567,8 @@ static int launch_r2(const ccsd_plan* pl, int B, const float* rank2, const float
 static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* rank2, Workspace& w, void* stream, const P0Fuse* fuse = nullptr) {
     const PlanD& p = pl->h;
     if (p.h_L < 1) return CCSD_OK;
-    if (p.h_L > 2) {
+    w.hg_rank2 = rank2;
+    if (p.h_L > 2 && !pl->h_general) {
         // more than two hodge layers: k_xa's general layer loop consumes the factors only the fused rank-2 kernel produces
         // (plan creation guarantees it exists); its ScoreNetworkF output lands in the net_r scratch, which every caller
         // of launch_p overwrites afterwards
@@ -619,13 +638,22 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
         const int kchunk = ((nslab + S - 1) / S) * T_BK;
         S = (p.K + kchunk - 1) / kchunk;
         g.z = S;
-        CCSD_LAUNCH(k_gemm_p, g, dim3(CCSD_NTHREADS), 0, stream, rank2, (const float*)pl->w, S > 1 ? w.psplit : w.P1, rows, p.E, p.K, h.wc,
+        float* P1 = pl->h_general ? w.hgP[0] : w.P1;
+        CCSD_LAUNCH(k_gemm_p, g, dim3(CCSD_NTHREADS), 0, stream, rank2, (const float*)pl->w, S > 1 ? w.psplit : P1, rows, p.E, p.K, h.wc,
                     h.wcat, 1, h0.mval, h0.cin, (const float*)w.acoef, (const unsigned long long*)w.offbits,
                     (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, kchunk);
         LAUNCH_CHECK();
         if (S > 1) {
             const long long n = (long long)rows * h.wc;
-            CCSD_LAUNCH(k_sum_splits, dim3(grid_for(n, 256)), dim3(CCSD_NTHREADS), 0, stream, (const float*)w.psplit, w.P1, n, S);
+            CCSD_LAUNCH(k_sum_splits, dim3(grid_for(n, 256)), dim3(CCSD_NTHREADS), 0, stream, (const float*)w.psplit, P1, n, S);
+            LAUNCH_CHECK();
+        }
+        if (pl->h_general) {
+            // R_1 = fl fr mlp_value_0(a_c o rank2), materialised for the layers behind it (launch_xa goes on from here)
+            const int cw = p.E > 128 ? 32 : 64;
+            CCSD_LAUNCH(k_hodge_value, dim3((p.K + cw - 1) / cw, B), dim3(CCSD_NTHREADS), (size_t)p.E * cw * 4, stream, rank2, (const float*)nullptr, 0,
+                        (const float*)w.acoef, (const float*)pl->w, h0.mval, h0.cin, w.hgR[0], p.E, p.K, cw,
+                        (const unsigned long long*)w.offbits, (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells);
             LAUNCH_CHECK();
         }
     }
@@ -657,6 +685,34 @@ static int launch_xa(const ccsd_plan* pl, int B, XaArgs& xa, NoiseArgs& na, Work
                                                          (const unsigned char*)pl->edges, XA_, na)
     int variant = xa_variant(pl->h);
     if ((variant == XA_PLAIN9 || variant == XA_BAKED9) && xa_threads != 256) variant = XA_PLAIN;      // (they have their 256 threads compiled in)
+    if (pl->h_general) {
+        // general hodge stack: layer l >= 2 projects R_l = fl fr mlp_value_(l-1)(cat_c H^(l-1)_c R_(l-1)).  H^(l-1) is the dense output of
+        // layer l - 2 inside k_xa: a launch that stops behind it dumps it, k_hodge_value forms R_l, k_gemm_p projects it -- then the next
+        // layer, and at last the full launch with every P_l delivered.  (launch_p left P_0, P_1 and R_1.)
+        const PlanD& p = pl->h;
+        if (variant != XA_GEN) return set_err(CCSD_ERR_RUNTIME, "general hodge stack needs k_xa<., XA_GEN>");
+        xa.pdirect = 1;
+        for (int l = 1; l < p.h_L; ++l) xa.Pd[l - 1] = w.hgP[l - 1];
+        const int rows = B * p.E;
+        for (int l = 2; l < p.h_L; ++l) {
+            XaArgs pre = xa;
+            pre.hdump_layer = l - 1; pre.hdump = w.hgH; pre.hdump_stride = (int)w.hg_hstride;
+            if (pl->h.chan_global) XA_GO(true, XA_GEN, pre, xblk, xlds, stream); else XA_GO(false, XA_GEN, pre, xblk, xlds, stream);
+            LAUNCH_CHECK();
+            const HodgeLayerD& hp = ccsd_hl(p, l - 1);
+            const HodgeLayerD& h = ccsd_hl(p, l);
+            float* Rl = w.hgR[(l - 1) & 1];
+            const int cw = p.E > 128 ? 32 : 64;
+            CCSD_LAUNCH(k_hodge_value, dim3((p.K + cw - 1) / cw, B), dim3(CCSD_NTHREADS), (size_t)p.E * cw * 4, stream, (const float*)w.hgR[(l - 2) & 1],
+                        (const float*)w.hgH, (int)w.hg_hstride, (const float*)nullptr, (const float*)pl->w, hp.mval, hp.cin, Rl, p.E, p.K, cw,
+                        (const unsigned long long*)w.offbits, (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells);
+            LAUNCH_CHECK();
+            CCSD_LAUNCH(k_gemm_p, dim3((h.wc + T_BN - 1) / T_BN, (rows + T_BM - 1) / T_BM, 1), dim3(CCSD_NTHREADS), 0, stream, (const float*)Rl,
+                        (const float*)pl->w, w.hgP[l - 1], rows, p.E, p.K, h.wc, h.wcat, 0, h.mval, h.cin, (const float*)nullptr,
+                        (const unsigned long long*)w.offbits, (const unsigned char*)pl->edges, (const unsigned long long*)pl->cells, p.K);
+            LAUNCH_CHECK();
+        }
+    }
     if (pl->h.chan_global) {
         if (variant == XA_HB) XA_GO(true, XA_HB, xa, xblk, xlds, stream);
         else if (variant == XA_GMH) XA_GO(true, XA_GMH, xa, xblk, xlds, stream);

@@ -546,6 +546,54 @@ __global__ void k_edgecoef(const float* __restrict__ adj, float* __restrict__ ac
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_hodge_value: the rank-2 features a HodgeAdjAttentionLayer hands to the next one, materialised (general hodge stack: more than
+// two layers with a non-affine mlp_value):
+//   Rout[b][e][k] = fl[e] * mlp_value(cat_c V_c[e][k]) * fr[k],   V_c = H_c . Rin[b]       (hodge_attention.py:98, 322-323; cc_utils.py:594-615)
+// H: the layer's dense hodge adjacency [B][hstride] as [cin][E][E] (k_xa's dump), or nullptr for layer 0, whose hodge adjacency is the
+// diagonal acoef[b][c][e] (k_edgecoef): V_c = a_c[e] Rin[e][k] -- the expression of k_gemm_p's layer-1 loader, bit for bit.
+// grid (ceil(K / cw), B), cw = 64 columns (32 when E > 128); one workgroup holds the [E][cw] column slab of Rin in LDS (dynamic: E cw floats).
+// A wave works on one edge row (two) at a time with its lanes on the columns: H_c[e][.] is wave-uniform, the slab reads conflict-free.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hodge_value(const float* __restrict__ Rin, const float* __restrict__ H, int hstride,
+                                                     const float* __restrict__ acoef, const float* __restrict__ W, MlpD mval, int cin,
+                                                     float* __restrict__ Rout, int E, int K, int cw,
+                                                     const unsigned long long* __restrict__ offbits,
+                                                     const unsigned char* __restrict__ edges,
+                                                     const unsigned long long* __restrict__ cells) {
+    CCSD_DYN_SMEM(Rs);                                   // [E][cw]
+    __shared__ float s_mv[CCSD_MAXLIN * CCSD_HWBLK];
+    const int b = blockIdx.y, k0 = blockIdx.x * cw, sh = cw == 64 ? 6 : 5;
+    const float* Rb = Rin + (size_t)b * E * K;
+    stage_mlp_blocks(mval, W, s_mv, (int)threadIdx.x, (int)blockDim.x);
+    for (int idx = threadIdx.x; idx < E * cw; idx += blockDim.x) {
+        const int e = idx >> sh, kk = idx & (cw - 1);
+        Rs[idx] = k0 + kk < K ? Rb[(size_t)e * K + k0 + kk] : 0.f;
+    }
+    __syncthreads();
+    const unsigned long long off = offbits[b];
+    for (int idx = threadIdx.x; idx < E * cw; idx += blockDim.x) {
+        const int e = idx >> sh, kk = idx & (cw - 1), k = k0 + kk;
+        if (k >= K) continue;
+        float in[CCSD_SMALLW], out[CCSD_SMALLW];
+#pragma unroll
+        for (int c = 0; c < CCSD_SMALLW; ++c) {
+            float v = 0.f;
+            if (c < cin) {
+                if (H) {
+                    const float* Hr = H + (size_t)b * hstride + ((size_t)c * E + e) * E;
+                    for (int e2 = 0; e2 < E; ++e2) v = fmaf(Hr[e2], Rs[e2 * cw + kk], v);
+                } else {
+                    v = acoef[((size_t)b * cin + c) * E + e] * Rs[idx];
+                }
+            }
+            in[c] = v;
+        }
+        small_mlp_lds<CCSD_SMALLW>(s_mv, mval.n, in, out);
+        Rout[((size_t)b * E + e) * K + k] = edge_on(off, edges, e) * out[0] * cell_on(off, cells, k);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_hf_score: ScoreNetworkF.  Tile (edge rows m0.., cell columns n0..) of  H.F  on MFMA, then per
 // element the channel MLP stack of ScoreNetwork_F.py:198-217 and one of three fused epilogues.
 // grid xcd_grid(B, ceil(K/64) ceil(E/64))

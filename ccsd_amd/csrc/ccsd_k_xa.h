@@ -48,6 +48,12 @@ struct XaArgs {
     CorrFuse cf;
     int prio_mode;                        // 0: priority = dispatch rank (default); 1: none; 2-4: diagnostic variants (CCSD_XA_PRIO)
     int stagger_mask, stagger_sleep;      // diagnostic (CCSD_XA_STAGGER): workgroups with (blockIdx.x & mask) != 0 start sleep x 64 cycles late
+    // general hodge stack (h_L > 2 with a non-affine mlp_value; XA_GEN only, launch_xa drives it): the projections of the layers >= 1 come
+    // materialised, Pd[l - 1] = R_l Wcat_l as [B * E][wc_l]; a launch with hdump_layer = s > 0 stops behind the dense hodge adjacency
+    // H^s (the output of layer s - 1), writes it to hdump [B][hdump_stride] as [cout][E][E] and returns
+    const float* Pd[CCSD_MAXHL + CCSD_MAXHLX - 1];
+    int pdirect, hdump_layer, hdump_stride;
+    float* hdump;
 };
 
 // fused Langevin corrector apply for x and adj held in LDS (same expressions as k_langevin_apply)
@@ -880,6 +886,11 @@ __global__ __launch_bounds__((VAR == XA_PLAIN9 || VAR == XA_BAKED9 || !XA_4WAVES
                 };
                 dense_att(h0, s_hw, bufA, p.a_cinit);
                 __syncthreads();
+                auto dump_h = [&](const float* Hs, int cout) {
+                    float* dst = xa.hdump + (size_t)b * xa.hdump_stride;
+                    for (int t = tid; t < cout * E * E; t += nth) dst[t] = Hs[t];
+                };
+                if (xa.hdump_layer == 1) { dump_h(bufA, h0.cout); return; }
                 float* Hin = bufA;
                 float* Hnext = bufB;
                 int hd0 = p.a_cinit + h0.cout;
@@ -896,12 +907,17 @@ __global__ __launch_bounds__((VAR == XA_PLAIN9 || VAR == XA_BAKED9 || !XA_4WAVES
                         for (int e2 = 0; e2 < E; ++e2) sdeg += Hc[e2 * E];
                         s_deg[t] = 1.0f / sqrtf(fmaxf(sdeg, 1.f));
                     }
-                    if (l + 1 < p.h_L)                                                  // M_l, for the layers still to come
+                    if (xa.pdirect) {                                                   // P_l as delivered (general hodge stack)
+                        const float* Pl = xa.Pd[l - 1] + (size_t)b * E * wc;
+                        for (int t = tid; t < E * wc; t += nth) sX0[t] = Pl[t];
+                    }
+                    if (!xa.pdirect && l + 1 < p.h_L)                                   // M_l, for the layers still to come
                         for (int t = tid; t < E * E; t += nth) {
                             float m = 0.f;
                             for (int c = 0; c < h.cin; ++c) m = fmaf(w[h.mval.w[0] + c], Hin[(size_t)c * E * E + t], m);
                             s_M[(l - 1) * E * E + t] = m;
                         }
+                    if (!xa.pdirect)
                     for (int t = tid; t < E * wc; t += nth) {                           // X_1
                         const int e = t / wc, n = t - e * wc;
                         sX0[t] = fmaf(s_p1c[e], Qb[(size_t)e * p.h_pw + n], s_p1c[E + e] * ub[n]);
@@ -909,7 +925,7 @@ __global__ __launch_bounds__((VAR == XA_PLAIN9 || VAR == XA_BAKED9 || !XA_4WAVES
                     __syncthreads();
                     float* X = sX0;
                     float* Xn = sX0 + E * wc;
-                    for (int j = 1; j < l; ++j) {                                       // X_{j+1} = fl (M_j X_j + b_j u_l)
+                    for (int j = 1; j < l && !xa.pdirect; ++j) {                        // X_{j+1} = fl (M_j X_j + b_j u_l)
                         const float* Mj = s_M + (j - 1) * E * E;
                         const float bj = w[ccsd_hl(p, j).mval.b[0]];
                         for (int task = wave_id; task < mtE * ntw; task += n_waves) {
@@ -942,6 +958,7 @@ __global__ __launch_bounds__((VAR == XA_PLAIN9 || VAR == XA_BAKED9 || !XA_4WAVES
                     const float* hw = s_hw + l * p.hw_stride;
                     if (l + 1 < p.h_L) {
                         dense_att(h, hw, Hnext, hd0);
+                        if (xa.hdump_layer == l + 1) { __syncthreads(); dump_h(Hnext, h.cout); return; }
                         float* th = Hin; Hin = Hnext; Hnext = th;
                     } else {
                         // the last layer: only the diagonal of its output is used (hodgedual_to_adj, cc_utils.py:1571)

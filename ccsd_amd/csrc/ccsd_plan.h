@@ -9,7 +9,7 @@
 #define CCSD_MAXLIN 4     // linears per MLP
 #define CCSD_MAXL 8       // attention layers / GCN depth
 #define CCSD_MAXHL 2      // hodge layers in the hot part of the plan (PlanD::hl); CCSD_MAXHLX more behind it (PlanD::hlx)
-#define CCSD_MAXHLX 2
+#define CCSD_MAXHLX 6
 #define CCSD_MAXFL 4      // HodgeNetworkLayers in ScoreNetworkF
 #define CCSD_MAXCN 4      // channels [F, HF, H^2 F, H^3 F] of ScoreNetworkF's input (cnum, cc_utils.py:961-979)
 #define CCSD_SMALLW 8     // widest per-thread MLP in the hodge branch
@@ -361,7 +361,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     } else if (c->a_is_cc_net) {
         if (!c->is_cc) { pb.fail(CCSD_ERR_INVALID, "ScoreNetworkA_CC is only for combinatorial complexes"); return 0; }
         if (c->h_num_layers < 1 || c->h_num_layers > CCSD_MAXHL + CCSD_MAXHLX) {
-            pb.fail(CCSD_ERR_UNSUPPORTED, "HIP path supports 1 to 4 HodgeAdjAttentionLayers"); return 0; }
+            pb.fail(CCSD_ERR_UNSUPPORTED, "HIP path supports 1 to 8 HodgeAdjAttentionLayers"); return 0; }
         p->h_L = c->h_num_layers;
         int hch = c->a_c_init;
         for (int l = 0; l < p->h_L; ++l) {
@@ -395,9 +395,6 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
             if (ccsd_hl(*p, l).wcatT != ccsd_hl(*p, 1).wcatT + p->h_pw * ((K + 31) & ~31)) { pb.fail(CCSD_ERR_RUNTIME, "Wcat^T blocks not consecutive"); return 0; }
             p->h_pw += l == p->h_L - 1 ? ccsd_hl(*p, l).wc : pad16(ccsd_hl(*p, l).wc);
         }
-        if (p->h_L > 2)
-            for (int l = 0; l < p->h_L - 1; ++l)
-                if (ccsd_hl(*p, l).mval.n != 1) { pb.fail(CCSD_ERR_UNSUPPORTED, "more than two HodgeAdjAttentionLayers need num_linears_h == 1"); return 0; }
     }
     p->a_fdim = p->a_nch_graph + p->a_nch_hodge;
     p->a_fin = pb.mlp(3, p->a_fdim, 2 * p->a_fdim, 1);

@@ -745,6 +745,70 @@ def case_kat_cnum(lib, device):
         assert_close(eng.score(2, x, adj, rank2, flags), g[f"{tag}/out"], f"kat cnum {tag}")
 
 
+def case_kat_hodge_general(lib, device):
+    """ScoreNetworkA_CC with three / four HodgeAdjAttentionLayers whose mlp_value is a true MLP (num_linears_h = 2, 3) against the
+    reference constructor's outputs: the general hodge stack -- k_xa<., XA_GEN> launches that stop behind a dense hodge adjacency and
+    dump it, k_hodge_value materialises R_l, k_gemm_p projects it, the last launch takes every P_l as delivered.  Also: the same
+    route forced (CCSD_HODGE_GENERAL) on the num_linears_h = 1 plans of kat_hodge_layers must agree with their goldens, and a
+    sampler (Reverse + Langevin, in-library loop and step-wise) against the oracle."""
+    from oracle import ccsd_oracle as O
+
+    g = load_golden("kat_hodge_general.npz")
+    meta = json.loads(str(g["meta"]))
+    for tag, params in meta.items():
+        flags, x, adj, rank2 = (torch.from_numpy(g[f"{tag}/{k}"]).to(device) for k in ("flags", "x", "adj", "rank2"))
+        sd = {k[len(tag) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}/w/")}
+        N, Fd = params["max_node_num"], params["max_feat_num"]
+        eng = PCEngine(None, None, params, sd, None, None, N=N, F=Fd, is_cc=True, d_min=params["d_min"], d_max=params["d_max"],
+                       device=device, lib=lib)
+        assert_close(eng.score(1, x, adj, rank2, flags), g[f"{tag}/out"], f"kat hodge general {tag}")
+    # the affine plans of kat_hodge_layers through the general route
+    gl = load_golden("kat_hodge_layers.npz")
+    ml = json.loads(str(gl["meta"]))
+    os.environ["CCSD_HODGE_GENERAL"] = "1"
+    try:
+        for tag, params in ml.items():
+            flags, x, adj, rank2 = (torch.from_numpy(gl[f"{tag}/{k}"]).to(device) for k in ("flags", "x", "adj", "rank2"))
+            sd = {k[len(tag) + 3:]: torch.from_numpy(gl[k]) for k in gl.files if k.startswith(f"{tag}/w/")}
+            N, Fd = params["max_node_num"], params["max_feat_num"]
+            eng = PCEngine(None, None, params, sd, None, None, N=N, F=Fd, is_cc=True, d_min=params["d_min"], d_max=params["d_max"],
+                           device=device, lib=lib)
+            assert_close(eng.score(1, x, adj, rank2, flags), gl[f"{tag}/out"], f"kat hodge layers {tag} through the general route")
+    finally:
+        del os.environ["CCSD_HODGE_GENERAL"]
+    # a sampler: the X / F networks are the small reference-built ones of kat_small_models (N = 5, F = 10, d 3..4)
+    tag = "G3_n5"
+    pa = meta[tag]
+    sda = {k[len(tag) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}/w/")}
+    gs = load_golden("kat_small_models.npz")
+    ms = json.loads(str(gs["meta"]))
+    sds = lambda t: {k[len(t) + 3:]: torch.from_numpy(gs[k]) for k in gs.files if k.startswith(f"{t}/w/")}
+    prm = {"x": ms["x"], "adj": pa, "rank2": ms["rank2"]}
+    wts = {"x": sds("x"), "adj": sda, "rank2": sds("rank2")}
+    names = ["x", "adj", "rank2"]
+    N, Fd, d_min, d_max, B = 5, 10, 3, 4, 3
+    flags = torch.from_numpy(g[f"{tag}/flags"])
+    sde_cfg = dict(type="VE", beta_min=0.1, beta_max=1.0, num_scales=3)
+    for n_steps in (1, 2):      # (1: ccsd_sampler_run's loop; 2: driven step by step)
+        kw = dict(shape_x=(B, N, Fd), shape_adj=(B, N, N), predictor="Reverse", corrector="Langevin", snr=0.2, scale_eps=0.7,
+                  n_steps=n_steps, probability_flow=False, continuous=True, denoise=True, eps=1e-4, is_cc=True,
+                  shape_rank2=(B, *rank2_dim(N, d_min, d_max)), d_min=d_min, d_max=d_max)
+        models = [loader.load_model_from_ckpt(prm[p], wts[p], device) for p in names]
+        fn = solver.get_pc_sampler(device=device, rng="torch_cpu", lib=lib, sde_x=loader.load_sde(sde_cfg), sde_adj=loader.load_sde(sde_cfg),
+                                   sde_rank2=loader.load_sde(sde_cfg), **kw)
+        torch.manual_seed(78)
+        got = fn(*models, flags.to(device))
+        wo = {p: {k: v.clone().requires_grad_(True) for k, v in wts[p].items()} for p in names}
+        nets = [(lambda x_, a_, r_, f_, p=p: O.run_network(prm[p], wo[p], x_, a_, r_, f_)) for p in names]
+        ofn = O.get_pc_sampler(n_diff_steps=3, keep_traj=False, sde_x=O.load_sde(sde_cfg), sde_adj=O.load_sde(sde_cfg),
+                               sde_rank2=O.load_sde(sde_cfg), **kw)
+        torch.manual_seed(78)
+        with torch.no_grad():
+            want = ofn(*nets, flags)
+        for p, g_, w_ in zip(names, got, want):
+            assert_close(g_, w_, f"general hodge stack, Reverse + Langevin n_steps={n_steps}, {p}")
+
+
 def case_kat_hodge_layers(lib, device):
     """ScoreNetworkA_CC with three / four HodgeAdjAttentionLayers (num_layers_h = 3, 4; num_linears_h = 1) against the reference
     constructor's outputs (no shipped checkpoint has more than two): k_r2 hands over the adjacency-independent factors of every

@@ -140,6 +140,10 @@ def test_kat_hodge_layers_three_and_four(lib):
     pc.case_kat_hodge_layers(lib, DEV)
 
 
+def test_kat_hodge_general_stack(lib):
+    pc.case_kat_hodge_general(lib, DEV)
+
+
 def test_production_loop_vs_oracle(lib):
     """ccsd_sampler_run (Philox in the kernels, fused Langevin apply) against the oracle fed with the exported draws; the GPU
     twin runs the BASELINE batch."""

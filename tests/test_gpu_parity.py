@@ -279,6 +279,10 @@ def test_kat_hodge_layers_three_and_four(lib):
     pc.case_kat_hodge_layers(lib, DEV)
 
 
+def test_kat_hodge_general_stack(lib):
+    pc.case_kat_hodge_general(lib, DEV)
+
+
 def test_production_loop_vs_oracle_qm9_full_batch(lib):
     """What bench.py times, at the BASELINE batch (B = 1024, realistic node-count mix): ccsd_sampler_run with in-kernel Philox
     and the Langevin apply fused into the predictor launches, eight PC steps (seven merged k_r2 launches), against the oracle

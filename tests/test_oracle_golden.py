@@ -250,6 +250,18 @@ def test_kat_hodge_layers_three_and_four():
         _close(out.numpy(), g[f"{tag}/out"], tag)
 
 
+def test_kat_hodge_general_mlp_value():
+    """three / four HodgeAdjAttentionLayers with num_linears_h = 2, 3 (non-affine mlp_value behind a dense hodge layer)."""
+    g = load_golden("kat_hodge_general.npz")
+    meta = json.loads(str(g["meta"]))
+    for tag, params in meta.items():
+        flags, x, adj, rank2 = (torch.from_numpy(g[f"{tag}/{k}"]) for k in ("flags", "x", "adj", "rank2"))
+        w = {k[len(tag) + 3:]: torch.from_numpy(g[k]).requires_grad_(True) for k in g.files if k.startswith(f"{tag}/w/")}
+        with torch.no_grad():
+            out = O.run_network(params, w, x, adj, rank2, flags)
+        _close(out.numpy(), g[f"{tag}/out"], tag)
+
+
 def test_zinc5b_substitute_networks_and_sampler():
     """SURVEY 8(d) substitute 5b (N = 38 CC, d_min = d_max = 3, zinc250k_CC.yaml hyper-parameters, reference-initialised
     weights): forwards and a 3-scale sampler run."""

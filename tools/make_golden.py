@@ -562,6 +562,51 @@ def kat_hodge_layers():
     print("kat_hodge_layers", {k: (v.shape, float(np.abs(v).max())) for k, v in out.items() if k.endswith("/out")})
 
 
+def kat_hodge_general():
+    """ScoreNetworkA_CC with three and four HodgeAdjAttentionLayers whose mlp_value / mlp_attention are true MLPs (num_linears_h = 2, 3:
+    ELU between the Linears, hodge_attention.py:245-252), built by the reference's constructor: the rank-2 features of layer l >= 2,
+    R_l = mask_rank2(mlp_value(cat_c H_c R_(l-1))) (hodge_attention.py:98, 322-323), are no longer an affine image of rank2 and must be
+    materialised.  N = 5 (E = 10, K = 15), N = 6 (E = 15, K = 35), the qm9_CC geometry N = 9, d 3..9 (E = 36, K = 466) and N = 12, d 3..4
+    (E = 66, K = 715)."""
+    from ccsd.src.models.ScoreNetwork_A_CC import ScoreNetworkA_CC
+
+    out, meta = {}, {}
+    base = dict(nhid=4, num_layers=2, num_linears=2, c_init=2, c_hid=2, c_final=2, adim=2, num_heads=2, conv="GCN",
+                conv_hodge="HCN", use_bn=False, is_cc=True)
+    cases = {
+        "G3_n5": (5, 10, 3, 4, dict(nhid_h=2, num_layers_h=3, num_linears_h=2, c_hid_h=2, c_final_h=2, adim_h=2, num_heads_h=2), [5, 4, 3]),
+        "G4_n6": (6, 2, 3, 4, dict(nhid_h=4, num_layers_h=4, num_linears_h=2, c_hid_h=3, c_final_h=2, adim_h=4, num_heads_h=2), [6, 4]),
+        "G3_n9": (9, 4, 3, 9, dict(nhid_h=4, num_layers_h=3, num_linears_h=3, c_hid_h=4, c_final_h=2, adim_h=4, num_heads_h=2), [9, 6]),
+        # E = 66 > 64 (the ENZYMES_small_CC geometry): no fused rank-2 kernel, so the single-Linear stack takes the general route too
+        "G3_n12": (12, 3, 3, 4, dict(nhid_h=4, num_layers_h=3, num_linears_h=2, c_hid_h=2, c_final_h=2, adim_h=4, num_heads_h=2), [12, 8]),
+        "A3_n12": (12, 3, 3, 4, dict(nhid_h=4, num_layers_h=3, num_linears_h=1, c_hid_h=2, c_final_h=2, adim_h=4, num_heads_h=2), [12, 7]),
+        # more than four layers (single Linears, and true MLPs)
+        "A5_n5": (5, 10, 3, 4, dict(nhid_h=2, num_layers_h=5, num_linears_h=1, c_hid_h=2, c_final_h=2, adim_h=2, num_heads_h=2), [5, 3]),
+        "G6_n6": (6, 2, 3, 4, dict(nhid_h=4, num_layers_h=6, num_linears_h=2, c_hid_h=2, c_final_h=3, adim_h=4, num_heads_h=2), [6, 5]),
+    }
+    torch.manual_seed(2718)
+    for tag, (N, Fd, dmin, dmax, hp, counts) in cases.items():
+        prm = dict(base, **hp, max_feat_num=Fd, max_node_num=N, d_min=dmin, d_max=dmax)
+        m = ScoreNetworkA_CC(**prm)
+        for k, p_ in m.named_parameters():
+            if k.endswith("bias"):
+                p_.data.normal_(0, 0.2)
+        m.eval()
+        B = len(counts)
+        flags = make_flags(B, N, counts)
+        x, adj, rank2 = masked_state(58, B, N, Fd, True, dmin, dmax, flags, 0.5)
+        for k, v in (("flags", flags), ("x", x), ("adj", adj), ("rank2", rank2)):
+            out[f"{tag}/{k}"] = v.numpy()
+        with torch.no_grad():
+            for k, v in m.state_dict().items():
+                out[f"{tag}/w/{k}"] = v.numpy()
+            out[f"{tag}/out"] = m(x, adj, rank2, flags).numpy()
+        meta[tag] = dict(prm, model_type="ScoreNetworkA_CC")
+    out["meta"] = json.dumps(meta)
+    np.savez_compressed(os.path.join(GOLD, "kat_hodge_general.npz"), **out)
+    print("kat_hodge_general", {k: (v.shape, float(np.abs(v).max())) for k, v in out.items() if k.endswith("/out")})
+
+
 def reference_variant_status():
     """What the reference itself does with the two config switches no shipped config sets: use_bn=True (layers.py:219-224,
     262-275: BatchNorm1d(hidden) applied to (B, N, hidden) / (B, N, N, hidden) activations) and conv_hodge="MLP"
@@ -810,6 +855,8 @@ def main():
         kat_cnum()
     if not only or "hlayers" in only:
         kat_hodge_layers()
+    if not only or "hgeneral" in only:
+        kat_hodge_general()
     if not only or "gmh" in only:
         kat_gmh_models()
     if not only or "base" in only:
