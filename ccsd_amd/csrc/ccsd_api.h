@@ -104,6 +104,7 @@ struct ccsd_plan {
     int opt_xa_prio = 0;                                       // CCSD_XA_PRIO (diagnostic: k_xa issue-priority scheme)
     int opt_xa_stagger_mask = 0, opt_xa_stagger_sleep = 0;     // CCSD_XA_STAGGER="mask,sleep" (diagnostic)
     int opt_no_merge = 0;                                      // CCSD_NO_MERGE (diagnostic: separate norms / predictor k_r2 launches)
+    int opt_no_h_full = 0;                                     // CCSD_NO_H_FULL (diagnostic: k_gemm_h's 64 x 64 tiles for the community_small geometry too)
     int opt_no_tiled_fuse = 0;                                 // CCSD_NO_TILED_FUSE (diagnostic: k_noise_norm / k_langevin_apply as launches of their own on the tiled path)
     int opt_r2_masked = 1;                                     // CCSD_NO_R2_MASKED clears it (diagnostic: the loop's k_r2 launches re-mask rank2 in the Q_1 loader)
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
@@ -274,6 +275,7 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     pl->opt_no_merge = getenv("CCSD_NO_MERGE") != nullptr;
     pl->opt_r2_masked = getenv("CCSD_NO_R2_MASKED") == nullptr;
     pl->opt_no_tiled_fuse = getenv("CCSD_NO_TILED_FUSE") != nullptr;
+    pl->opt_no_h_full = getenv("CCSD_NO_H_FULL") != nullptr;
     if (const char* pr = getenv("CCSD_XA_PRIO")) pl->opt_xa_prio = atoi(pr);
     if (const char* sg = getenv("CCSD_XA_STAGGER")) sscanf(sg, "%d,%d", &pl->opt_xa_stagger_mask, &pl->opt_xa_stagger_sleep);
     if (const char* sg = getenv("CCSD_R2_STAGGER")) sscanf(sg, "%d,%d", &pl->opt_r2_stagger_mask, &pl->opt_r2_stagger_sleep);
@@ -543,9 +545,17 @@ static int launch_h(const ccsd_plan* pl, int B, const float* rank2, Workspace& w
     const int nth_ = (p.E + T_BM - 1) / T_BM;
     dim3 g(xcd_grid(B, nth_ * (nth_ + 1) / 2));
     prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_H, stream);
+#ifndef CCSD_EMU
+    // community_small geometry, at least one complex per CU: one workgroup per complex, F streamed once (k_gemm_h_full; bit-identical)
+    if (p.E == 190 && p.K == 1140 && p.geo_off != 1 && B >= 256 && !pl->opt_no_h_full)
+        hipLaunchKernelGGL((k_gemm_h_full<190, 1140>), dim3(B), dim3(256), 0, (hipStream_t)stream, rank2, w.H, p.f_hmask);
+    else
+#endif
+    {
 #define H_GO(EC_, KC_) CCSD_LAUNCH((k_gemm_h<EC_, KC_>), g, dim3(CCSD_NTHREADS), 0, stream, rank2, w.H, p.E, p.K, p.f_hmask, B)
     GEO_EK(p, H_GO);
 #undef H_GO
+    }
     prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_H, stream);
     LAUNCH_CHECK();
     for (int j = 2; j < p.f_cnum; ++j) {       // H^j = H^(j-1) . H  (pow_tensor_cc, cc_utils.py:972-977)

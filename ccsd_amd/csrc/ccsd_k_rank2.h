@@ -189,6 +189,134 @@ __global__ __launch_bounds__(256) void k_gemm_h(const float* __restrict__ rank2,
     });
 }
 
+#ifndef CCSD_EMU
+// ---------------------------------------------------------------------------------------------
+// k_gemm_h_full<EC, KC>: H[b] = (F[b] F[b]^T) * hodge_mask with ONE workgroup per complex -- the 12 x 12 grid of 16 x 16 sub-tiles of a
+// 192-row block (E <= 192: the community_small geometry, E = 190), upper triangle only (78 sub-tiles), mirrored on store.
+// Why: k_gemm_h's six 64 x 64 tiles of a complex each stream their two row slabs of F, and with ~250 workgroups in flight per XCD one
+// k step of all of them touches as much as the 4 MB L2 holds -- the sibling tiles miss: 1268 MB of HBM traffic per launch against
+// 443 MB of F + 74 MB of H (r04_pmc_community_small_CC.json), 4.2 TB/s, i.e. the kernel is HBM-bound on re-reads.  Here a k slab of F
+// ([192][32], 30 KB) is staged ONCE per complex and every sub-tile takes both its operands from it: traffic = F once + H.
+// Sub-tile (i, j), i <= j: A rows 16 i .., B rows 16 j .. of the same slab; k order and operand slots as in k_gemm_h (blocks of 16
+// ascending, step j of a block = slot 4 kq + j) => bit-identical results.  Waves: 0 / 1 the triangles of rows 0-5 / 6-11 (less one
+// sub-tile each), 2 / 3 the rows 0-2 / 3-5 of the off-diagonal 6 x 6 block plus the sub-tile given up by wave 0 / 1, whose fragments
+// they hold anyway: 20 / 20 / 19 / 19 sub-tiles.  LDS: two slabs (one barrier per slab); B complexes = B workgroups, two per CU.
+// ---------------------------------------------------------------------------------------------
+template <int EC, int KC>
+__global__ __launch_bounds__(256, 2) void k_gemm_h_full(const float* __restrict__ rank2, float* __restrict__ H, int zero_diag) {
+    static_assert(EC > 96 && EC <= 192 && (KC & 3) == 0, "one 192-row block, 16-byte rows");
+    constexpr int E = EC, K = KC, NS = (K + H_BK - 1) / H_BK, SLAB = 192 * H_LD;
+    __shared__ __align__(16) float Fs[2 * SLAB];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = wave_index(), lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const float* Fb = rank2 + (size_t)b * E * K;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    // thread -> (row r0 + 32 u, 4-float column group c4) of the 192 x 32 slab, u < 6
+    const int r0 = tid >> 3, c4 = (tid & 7) * 4;
+    float4 rg[6];
+    auto ldg = [&](int s) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int row = r0 + 32 * u, k = s * H_BK + c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < E && k < K) v = *reinterpret_cast<const float4*>(Fb + (size_t)row * K + k);       // (K a multiple of 4: whole groups)
+            rg[u] = v;
+        }
+    };
+    auto sts = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) *reinterpret_cast<float4*>(Fs + buf * SLAB + (r0 + 32 * u) * H_LD + c4) = rg[u];
+    };
+    f32x4 acc[21];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool tri = wave < 2;
+    const int tb = tri ? 6 * wave : 3 * (wave - 2);        // first row tile of the wave's triangle / rectangle
+    // the sub-tile a triangle wave gives up, taken by the rectangle wave that holds its fragments: (0, 1) -> wave 2, (6, 7) -> wave 3
+    ldg(0);
+    sts(0);
+    __syncthreads();
+    for (int s = 0; s < NS; ++s) {
+        const float* S = Fs + (s & 1) * SLAB;
+        if (s + 1 < NS) ldg(s + 1);
+#pragma unroll
+        for (int t = 0; t < H_BK / 16; ++t) {
+            auto frag = [&](int rt) { return *reinterpret_cast<const float4*>(S + (16 * rt + l15) * H_LD + 16 * t + 4 * kq); };
+            if (tri) {
+                float4 f[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) f[i] = frag(tb + i);
+                int a = 0;
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = i; j < 6; ++j) {
+                        if (!(i == 0 && j == 1)) {                         // (given to the rectangle wave)
+                            const float av[4] = {f[i].x, f[i].y, f[i].z, f[i].w}, bv[4] = {f[j].x, f[j].y, f[j].z, f[j].w};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], acc[a], 0, 0, 0);
+                        }
+                        ++a;
+                    }
+            } else {
+                float4 fa[3], fb[6];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) fa[i] = frag(tb + i);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) fb[j] = frag(6 + j);
+                int a = 0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const float av[4] = {fa[i].x, fa[i].y, fa[i].z, fa[i].w}, bv[4] = {fb[j].x, fb[j].y, fb[j].z, fb[j].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], acc[a], 0, 0, 0);
+                        ++a;
+                    }
+                // the extra sub-tile: wave 2 -> (0, 1) = fa[0] x fa[1]; wave 3 -> (6, 7) = fb[0] x fb[1]
+                const float4 xa = wave == 2 ? fa[0] : fb[0], xb = wave == 2 ? fa[1] : fb[1];
+                const float av[4] = {xa.x, xa.y, xa.z, xa.w}, bv[4] = {xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[18] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], acc[18], 0, 0, 0);
+            }
+        }
+        if (s + 1 < NS) sts((s + 1) & 1);
+        __syncthreads();
+    }
+    float* Hb = H + (size_t)b * E * E;
+    auto store = [&](int ri, int cj, const f32x4& v) {
+        const int n = 16 * cj + l15;
+        if (n >= E) return;
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const int m = 16 * ri + 4 * kq + s2;
+            if (m < E) {
+                const float hv = (zero_diag && m == n) ? 0.f : v[s2];
+                Hb[(size_t)m * E + n] = hv;
+                Hb[(size_t)n * E + m] = hv;
+            }
+        }
+    };
+    if (tri) {
+        int a = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) {
+                if (!(i == 0 && j == 1)) store(tb + i, tb + j, acc[a]);
+                ++a;
+            }
+    } else {
+        int a = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { store(tb + i, 6 + j, acc[a]); ++a; }
+        if (wave == 2) store(0, 1, acc[18]); else store(6, 7, acc[18]);
+    }
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // k_gemm_p: P[r][c] = sum_k A(r,k) * Wcat[k][c]   over the flattened rows r = b*E + e.
 // layer 0: A = rank2 as given                               (DenseHCNConv out = rank2 @ W, hodge_layers.py:185)
