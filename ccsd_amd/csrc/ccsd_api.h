@@ -466,7 +466,7 @@ static Workspace carve_ws(const ccsd_plan* pl, int B, void* base) {
     w.Kp = p.is_cc ? (p.K + 3) & ~3 : 0; w.Ep = p.is_cc ? (p.E + 3) & ~3 : 0;
     w.mfr = (unsigned char*)take((size_t)B * w.Kp);
     w.mfl = (unsigned char*)take((size_t)B * w.Ep);
-    w.H = (float*)take(p.is_cc ? (size_t)B * E * E * 4 * (p.f_cnum > 2 ? p.f_cnum - 1 : 1) : 0);   // H, H^2, ... (cnum > 2: one slab per power)
+    w.H = (float*)take(p.is_cc ? (size_t)B * E * h_ld((int)E) * 4 * (p.f_cnum > 2 ? p.f_cnum - 1 : 1) : 0);   // H, H^2, ... (cnum > 2: one slab per power)
     w.P0 = (float*)take(p.h_L > 0 ? (size_t)B * E * p.hl[0].wc * 4 : 0);
     w.P1 = (float*)take(p.h_L > 1 ? (size_t)B * E * p.h_pw * 4 : 0);
     w.U1 = (float*)take(p.h_L > 1 ? (size_t)B * p.h_pw * 4 : 0);
@@ -559,7 +559,7 @@ static int launch_h(const ccsd_plan* pl, int B, const float* rank2, Workspace& w
     prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_H, stream);
     LAUNCH_CHECK();
     for (int j = 2; j < p.f_cnum; ++j) {       // H^j = H^(j-1) . H  (pow_tensor_cc, cc_utils.py:972-977)
-        const size_t slab = (size_t)B * p.E * p.E;
+        const size_t slab = (size_t)B * p.E * h_ld(p.E);
         const int nt = (p.E + 15) / 16, per = CCSD_NTHREADS >= 64 ? CCSD_NTHREADS / 64 : 1;
         CCSD_LAUNCH(k_gemm_pow, dim3((nt * nt + per - 1) / per, 1, B), dim3(CCSD_NTHREADS), 0, stream,
                     (const float*)(w.H + (size_t)(j - 2) * slab), (const float*)w.H, w.H + (size_t)(j - 1) * slab, p.E);

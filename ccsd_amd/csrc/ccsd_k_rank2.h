@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256) void k_gemm_h(const float* __restrict__ rank2,
         }
     }
     {
-        float* Hb = H + (size_t)b * E * E;
+        const int ldH = h_ld(E);
+        float* Hb = H + (size_t)b * E * ldH;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -165,15 +166,16 @@ __global__ __launch_bounds__(256) void k_gemm_h(const float* __restrict__ rank2,
                     const int m = m0 + wm + 16 * i + 4 * kq + s2;
                     if (m < E) {
                         const float hv = (zero_diag && m == n) ? 0.f : acc.a[i][j][s2];
-                        Hb[(size_t)m * E + n] = hv;
-                        Hb[(size_t)n * E + m] = hv;                          // mirror (diagonal tiles: their lower sub-tiles)
+                        Hb[(size_t)m * ldH + n] = hv;
+                        Hb[(size_t)n * ldH + m] = hv;                        // mirror (diagonal tiles: their lower sub-tiles)
                     }
                 }
             }
     }
     return;
 #endif
-    float* Hb = H + (size_t)b * E * E;
+    const int ldH = h_ld(E);
+    float* Hb = H + (size_t)b * E * ldH;
     tile_foreach4(acc, [&](int ml, int nl, const float* v) {
         const int n = n0 + nl;
         if (n >= E) return;
@@ -182,8 +184,8 @@ __global__ __launch_bounds__(256) void k_gemm_h(const float* __restrict__ rank2,
             const int m = m0 + ml + s;
             if (m < E) {
                 const float hv = (zero_diag && m == n) ? 0.f : v[s];
-                Hb[(size_t)m * E + n] = hv;
-                if (tx != ty) Hb[(size_t)n * E + m] = hv;
+                Hb[(size_t)m * ldH + n] = hv;
+                if (tx != ty) Hb[(size_t)n * ldH + m] = hv;
             }
         }
     });
@@ -283,7 +285,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h_full(const float* __restrict_
         if (s + 1 < NS) sts((s + 1) & 1);
         __syncthreads();
     }
-    float* Hb = H + (size_t)b * E * E;
+    constexpr int ldH = (E + 3) & ~3;                    // == h_ld(E)
+    float* Hb = H + (size_t)b * E * ldH;
     auto store = [&](int ri, int cj, const f32x4& v) {
         const int n = 16 * cj + l15;
         if (n >= E) return;
@@ -292,8 +295,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h_full(const float* __restrict_
             const int m = 16 * ri + 4 * kq + s2;
             if (m < E) {
                 const float hv = (zero_diag && m == n) ? 0.f : v[s2];
-                Hb[(size_t)m * E + n] = hv;
-                Hb[(size_t)n * E + m] = hv;
+                Hb[(size_t)m * ldH + n] = hv;
+                Hb[(size_t)n * ldH + m] = hv;
             }
         }
     };
@@ -631,15 +634,16 @@ __global__ __launch_bounds__(256) void k_gemm_pow(const float* __restrict__ Hp, 
 #else
     const int wave = wave_index(), nw = blockDim.x >> 6;
 #endif
-    const float* A = Hp + (size_t)b * E * E;
-    const float* Bm = H1 + (size_t)b * E * E;
-    float* C = Hn + (size_t)b * E * E;
+    const int ldH = h_ld(E);
+    const float* A = Hp + (size_t)b * E * ldH;
+    const float* Bm = H1 + (size_t)b * E * ldH;
+    float* C = Hn + (size_t)b * E * ldH;
     for (int tile = blockIdx.x * nw + wave; tile < nt * nt; tile += gridDim.x * nw) {
         const int ti = tile / nt, tj = tile - ti * nt;
         wave_tile<8>(16 * ti, 16 * tj, (E + 3) >> 2,
-                     [&](int r, int k) { const float v = A[(size_t)(r < E ? r : E - 1) * E + (k < E ? k : E - 1)]; return (r < E && k < E) ? v : 0.f; },
-                     [&](int k, int c) { const float v = Bm[(size_t)(k < E ? k : E - 1) * E + (c < E ? c : E - 1)]; return (k < E && c < E) ? v : 0.f; },
-                     [&](int r, int c, float acc) { if (r < E && c < E) C[(size_t)r * E + c] = acc; });
+                     [&](int r, int k) { const float v = A[(size_t)(r < E ? r : E - 1) * ldH + (k < E ? k : E - 1)]; return (r < E && k < E) ? v : 0.f; },
+                     [&](int k, int c) { const float v = Bm[(size_t)(k < E ? k : E - 1) * ldH + (c < E ? c : E - 1)]; return (k < E && c < E) ? v : 0.f; },
+                     [&](int r, int c, float acc) { if (r < E && c < E) C[(size_t)r * ldH + c] = acc; });
     }
 }
 
@@ -754,14 +758,15 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
     for (int jp = 0; jp < NP; ++jp) {
     if (jp >= npow) break;
     TileAcc& acc = accs[jp];
-    const float* Hb = H + ((size_t)jp * B + b) * E * E;
+    const int ldH = h_ld(E);
+    const float* Hb = H + ((size_t)jp * B + b) * E * ldH;
 #ifdef CCSD_EMU
     static float As[T_BK * T_LD], Bs[T_BK * T_LD];
     {
         for (int k0 = 0; k0 < E; k0 += T_BK) {
             for (int idx = threadIdx.x; idx < T_BM * T_BK; idx += blockDim.x) {
                 const int r = idx / T_BK, kk = idx % T_BK, k = k0 + kk, row = m0 + r;
-                As[kk * T_LD + r] = (row < E && k < E) ? Hb[(size_t)row * E + k] : 0.f;
+                As[kk * T_LD + r] = (row < E && k < E) ? Hb[(size_t)row * ldH + k] : 0.f;
             }
             for (int idx = threadIdx.x; idx < T_BK * T_BN; idx += blockDim.x) {
                 const int kk = idx / T_BN, c = idx % T_BN, k = k0 + kk, col = n0 + c;
@@ -779,7 +784,7 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
     // contraction slab: 32 wide; 64 in the instances with a compile-time E (half as many barriers and global round trips per tile --
     // the contraction over E is short: 190 for community_small)
     constexpr int HBK = EC ? 64 : H_BK, HLD = HBK + 8;       // (HLD == 8 mod 32: conflict-free ds_read_b128 fragments)
-    constexpr int RPP = 256 / HBK, NA = T_BM / RPP, NB = HBK / 16;
+    constexpr int NA = T_BM * HBK / 4 / 256, NB = HBK / 16, AG = HBK / 4;   // A slab: NA 16-byte groups per thread, AG groups per row
     __shared__ __align__(16) float As[T_BM * HLD];
     __shared__ __align__(16) float Bs[HBK * BLD];
     {
@@ -787,18 +792,25 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
         const int tid = threadIdx.x, wave = wave_index(), lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
         const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
         const bool vec = (K & 3) == 0;
-        // A slab 64 x HBK: thread -> (row ar + RPP u, column ak), u < NA (scalar: E is not 16-byte friendly in general)
-        const int ar = tid / HBK, ak = tid % HBK;
+        // A slab 64 x HBK: thread -> (row ar + (256 / AG) u, 16-byte column group ak), u < NA -- the rows of H are padded to whole groups
+        // in the workspace (h_ld); components beyond E are masked
+        const int ar = tid / AG, ak = (tid % AG) * 4;
         // B slab HBK x 64: thread -> (k row bk + 16u, 4-float column group bc4), u < NB
         const int bk = tid >> 4, bc4 = (tid & 15) * 4;
-        float ra[NA];
+        float4 ra[NA];
         float4 rb[NB];
         auto load_slab = [&](int k0) {
 #pragma unroll
             for (int u = 0; u < NA; ++u) {
-                const int row = m0 + ar + RPP * u, k = k0 + ak;
-                const float v = Hb[(size_t)(row < E ? row : E - 1) * E + (k < E ? k : E - 1)];
-                ra[u] = (row < E && k < E) ? v : 0.f;
+                const int row = m0 + ar + (256 / AG) * u, k = k0 + ak;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < E && k < E) {
+                    v = *reinterpret_cast<const float4*>(Hb + (size_t)row * ldH + k);
+                    if (k + 1 >= E) v.y = 0.f;
+                    if (k + 2 >= E) v.z = 0.f;
+                    if (k + 3 >= E) v.w = 0.f;
+                }
+                ra[u] = v;
             }
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
@@ -818,7 +830,7 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
         for (int k0 = 0; k0 < E; k0 += HBK) {
             __syncthreads();
 #pragma unroll
-            for (int u = 0; u < NA; ++u) As[(ar + RPP * u) * HLD + ak] = ra[u];
+            for (int u = 0; u < NA; ++u) *reinterpret_cast<float4*>(As + (ar + (256 / AG) * u) * HLD + ak) = ra[u];
 #pragma unroll
             for (int u = 0; u < NB; ++u) *reinterpret_cast<float4*>(Bs + (bk + 16 * u) * BLD + bc4) = rb[u];
             __syncthreads();

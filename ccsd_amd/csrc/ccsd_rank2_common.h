@@ -14,6 +14,10 @@ CCSD_DEV float cell_on(unsigned long long off, const unsigned long long* __restr
 // The masks flags_left[e] * flags_right[k] of the four consecutive elements of flat group (e, k) .. of a sample's (E, K) block from
 // the byte tables of k_masktab (rows mfr + b Kp, mfl + b Ep): with K a multiple of 4 the group lies inside one row and k is a
 // multiple of 4 -- one 32-bit word of mfr and one byte of mfl; otherwise byte by byte across the row end.
+// row stride of the Hodge Laplacian buffers H, H^2, ... in the workspace (k_gemm_h / k_gemm_h_full / k_gemm_pow write, k_hf_score reads):
+// E rounded up to whole 16-byte groups, so that k_hf_score stages its rows of H with 16-byte loads (E = 190 -> 192; the pad columns
+// are never written and never used: the loader masks them)
+static inline __host__ __device__ int h_ld(int E) { return (E + 3) & ~3; }
 struct MaskTab { const unsigned char* mfr; const unsigned char* mfl; int Kp, Ep; };
 CCSD_DEV void group_masks(const MaskTab& mt, int b, int E, int K, int e, int k, float* m) {
     const unsigned char* fr = mt.mfr + (size_t)b * mt.Kp;
