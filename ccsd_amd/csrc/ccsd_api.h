@@ -104,6 +104,8 @@ struct ccsd_plan {
     int opt_xa_prio = 0;                                       // CCSD_XA_PRIO (diagnostic: k_xa issue-priority scheme)
     int opt_xa_stagger_mask = 0, opt_xa_stagger_sleep = 0;     // CCSD_XA_STAGGER="mask,sleep" (diagnostic)
     int opt_no_merge = 0;                                      // CCSD_NO_MERGE (diagnostic: separate norms / predictor k_r2 launches)
+    int opt_hp_full_norms = 0;                                 // CCSD_HP_FULL_NORMS (diagnostic: k_hp_full in the norms pass too)
+    int opt_no_hp_full = 0;                                    // CCSD_NO_HP_FULL (diagnostic: k_gemm_p0<., ., 1 / 2> + k_gemm_h_full instead of the one fused pass)
     int opt_no_h_full = 0;                                     // CCSD_NO_H_FULL (diagnostic: k_gemm_h's 64 x 64 tiles for the community_small geometry too)
     int opt_no_tiled_fuse = 0;                                 // CCSD_NO_TILED_FUSE (diagnostic: k_noise_norm / k_langevin_apply as launches of their own on the tiled path)
     int opt_r2_masked = 1;                                     // CCSD_NO_R2_MASKED clears it (diagnostic: the loop's k_r2 launches re-mask rank2 in the Q_1 loader)
@@ -276,6 +278,8 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     pl->opt_r2_masked = getenv("CCSD_NO_R2_MASKED") == nullptr;
     pl->opt_no_tiled_fuse = getenv("CCSD_NO_TILED_FUSE") != nullptr;
     pl->opt_no_h_full = getenv("CCSD_NO_H_FULL") != nullptr;
+    pl->opt_no_hp_full = getenv("CCSD_NO_HP_FULL") != nullptr;
+    pl->opt_hp_full_norms = getenv("CCSD_HP_FULL_NORMS") != nullptr;
     if (const char* pr = getenv("CCSD_XA_PRIO")) pl->opt_xa_prio = atoi(pr);
     if (const char* sg = getenv("CCSD_XA_STAGGER")) sscanf(sg, "%d,%d", &pl->opt_xa_stagger_mask, &pl->opt_xa_stagger_sleep);
     if (const char* sg = getenv("CCSD_R2_STAGGER")) sscanf(sg, "%d,%d", &pl->opt_r2_stagger_mask, &pl->opt_r2_stagger_sleep);
@@ -406,6 +410,11 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     if (pl->fused_r2 && pl->r2_lds > 64 * 1024) {
         PC(rt_set_max_dyn_smem(r2_kernel(pl), pl->r2_lds));
     }
+    if (pl->h.is_cc && pl->h.E == 190 && pl->h.K == 1140) {      // k_hp_full: 66.6 KB of dynamic LDS
+        const size_t lds = (size_t)(2 * 192 * H_LD + 2 * 16 * H_LD) * 4;
+        PC(rt_set_max_dyn_smem((const void*)k_hp_full<190, 1140, 1>, lds));
+        PC(rt_set_max_dyn_smem((const void*)k_hp_full<190, 1140, 2>, lds));
+    }
 #endif
 #undef PC
     if (const char* path = getenv("CCSD_DUMP_PLAN")) {     // tools/bake_plan.py: the plan's architecture bytes as a C header
@@ -453,6 +462,7 @@ struct Workspace {
     float *hgH, *hgR[2], *hgP[CCSD_MAXHL + CCSD_MAXHLX - 1];   // general hodge stack: dumped H^l, R_l (two alternating), P_l of the layers >= 1
     size_t hg_hstride;
     const float* hg_rank2;          // (the rank2 launch_p saw: launch_xa continues from it)
+    int h_done;                     // H of this pass is already in w.H (k_hp_full produced it beside P_0): launch_h returns at once
     int p1_raw;     // who filled P1 last: k_r2 with the raw factors (1, see k_r2) or k_gemm_p with the finished projections (0)
     size_t bytes;
 };
@@ -538,10 +548,18 @@ static int launch_flagbits(const ccsd_plan* pl, int B, const float* flags, Works
     return CCSD_OK;
 }
 
+static inline bool tiled_fuse_ok(const ccsd_plan* pl);
+// one fused pass per half-step (k_hp_full) instead of k_gemm_p0<., ., 1 / 2> + k_gemm_h_full
+static inline bool hp_full_ok(const ccsd_plan* pl, int B) {
+    const PlanD& p = pl->h;
+    return tiled_fuse_ok(pl) && p.E == 190 && p.K == 1140 && p.geo_off != 1 && B >= 256 && p.hl[0].wc <= 16 && p.f_cnum == 2 &&
+           !pl->opt_no_h_full && !pl->opt_no_hp_full;
+}
 // H = F F^T (ScoreNetworkF) from `rank2`
 static int launch_h(const ccsd_plan* pl, int B, const float* rank2, Workspace& w, void* stream) {
     const PlanD& p = pl->h;
     if (!p.is_cc || p.f_cnum < 2) return CCSD_OK;
+    if (w.h_done) { w.h_done = 0; return CCSD_OK; }
     const int nth_ = (p.E + T_BM - 1) / T_BM;
     dim3 g(xcd_grid(B, nth_ * (nth_ + 1) / 2));
     prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_H, stream);
@@ -589,6 +607,27 @@ static int launch_p(const ccsd_plan* pl, int B, const float* adj, const float* r
     }
     w.p1_raw = 0;
     const int rows = B * p.E;
+#ifndef CCSD_EMU
+    // community_small geometry, at least one complex per CU, the corrector's work riding on the pass (modes 1 / 2): ONE kernel streams
+    // the block once and leaves P_0, H and the noise norm / the corrected state (k_hp_full; P_0 and H bit-identical to the two-kernel
+    // route); the launch_h that follows in the caller finds H done
+    // (mode 1 -- the norms pass, whose only extra is the noise norm -- is slower fused: 370 us against 129 + 213, the eight waves of the one
+    // workgroup a CU holds run in lockstep; CCSD_HP_FULL_NORMS turns it on for A/B)
+    if (fuse && (fuse->mode == 2 || (fuse->mode == 1 && pl->opt_hp_full_norms)) && hp_full_ok(pl, B)) {
+        const HodgeLayerD& h = p.hl[0];
+        const float* WT = (const float*)pl->wp + h.wcatT;
+        const size_t lds = (size_t)(2 * 192 * H_LD + 2 * 16 * H_LD) * 4;
+        prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_H, stream);
+        if (fuse->mode == 1)
+            hipLaunchKernelGGL((k_hp_full<190, 1140, 1>), dim3(B), dim3(512), lds, (hipStream_t)stream, rank2, WT, w.H, w.P0, h.wc, p.f_hmask, *fuse);
+        else
+            hipLaunchKernelGGL((k_hp_full<190, 1140, 2>), dim3(B), dim3(512), lds, (hipStream_t)stream, rank2, WT, w.H, w.P0, h.wc, p.f_hmask, *fuse);
+        prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_H, stream);
+        LAUNCH_CHECK();
+        w.h_done = p.f_cnum == 2;            // (more powers: k_gemm_pow needs launch_h's loop -- not this geometry's shipped network)
+        return CCSD_OK;
+    }
+#endif
     {
         const HodgeLayerD& h = p.hl[0];
         dim3 g((h.wc + T_BN - 1) / T_BN, (rows + T_BM - 1) / T_BM, 1);

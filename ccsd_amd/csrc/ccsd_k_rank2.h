@@ -466,6 +466,194 @@ __global__ void k_p0_fuse_ew(const float* __restrict__ rank2, P0Fuse pf, int row
     }
 }
 #ifndef CCSD_EMU
+#ifndef CCSD_EMU
+// ---------------------------------------------------------------------------------------------
+// k_hp_full<EC, KC, MODE>: ONE pass over a complex's rank2 block per half-step on the tiled path (community_small geometry, one hodge
+// layer, wc <= 16: tiled_fuse_ok + the geometry): what k_gemm_p0<1, KC, MODE> and k_gemm_h_full<EC, KC> do in two --
+//   * the Langevin corrector's element-wise work where the block streams through registers (P0Fuse, as in k_gemm_p0):
+//     MODE 1 the noise norm of the corrector's draw per row (-> pf.zrow), MODE 2 the corrector apply (corrected rank2 -> pf.f1,
+//     in place over the raw scores it consumes); everything below sees the corrected block;
+//   * P_0 = F Wcat_0 (12 sub-tiles of 16 rows x 16 columns; WT = Wcat_0^T [16][Kp], a [16][32] slab of it staged beside F's);
+//   * H = (F F^T) * hodge_mask (78 upper-triangle sub-tiles, mirrored).
+// Per sub-tile the k order and operand slots of the kernels it replaces: P_0 and H are bit-identical to theirs.
+// 512 threads = 8 waves, two workgroups per CU (128 VGPRs).  Row tiles in four groups G0..G3 of three: waves 0-5 take one off-diagonal
+// 3 x 3 block (Ga, Gb) each (9 sub-tiles, 6 fragments), four of them also the three P_0 sub-tiles of a group they hold; waves 6 / 7 the
+// diagonal triangles of (G0, G1) / (G2, G3) (12 sub-tiles): 9 x 2 + 12 x 6 = 90.  LDS (dynamic): two F slabs [192][40] + two W slabs [16][40] = 66.6 KB.
+// grid: B workgroups.
+// ---------------------------------------------------------------------------------------------
+template <int EC, int KC, int MODE>
+__global__ __launch_bounds__(512, 2) void k_hp_full(const float* __restrict__ rank2, const float* __restrict__ WT, float* __restrict__ H,
+                                                    float* __restrict__ P, int wc, int zero_diag, P0Fuse pf) {
+    static_assert(EC > 144 && EC <= 192 && (KC & 3) == 0 && (MODE == 1 || MODE == 2), "one 192-row block, 16-byte rows");
+    constexpr int E = EC, K = KC, Kp = (KC + 31) & ~31, NS = Kp / H_BK, SLAB = 192 * H_LD, WSLAB = 16 * H_LD;
+    CCSD_DYN_SMEM(sm);
+    float* const Fs = sm;                         // [2][SLAB]
+    float* const Ws = sm + 2 * SLAB;              // [2][WSLAB]
+    const int b = blockIdx.x, tid = threadIdx.x, wave = wave_index(), lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const float* Fb = rank2 + (size_t)b * E * K;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    // thread -> (row r0 + 64 u, 4-float column group c4) of the 192 x 32 slab, u < 3; threads 0..127 also one group of the W slab
+    const int r0 = tid >> 3, c4 = (tid & 7) * 4;
+    float c1 = 0.f, c2 = 0.f, zacc[3] = {0.f, 0.f, 0.f};
+    if (MODE == 2) corr_coef(pf.cf, 2, &c1, &c2);
+    float4 rg[3], rn[3], rw;
+    auto ldg = [&](int s) {
+        const int k = s * H_BK + c4;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int row = r0 + 64 * u;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f), n = v;
+            if (row < E && k < K) {
+                v = *reinterpret_cast<const float4*>(Fb + (size_t)row * K + k);       // (K a multiple of 4: whole groups)
+                if (MODE == 2) n = *reinterpret_cast<const float4*>(pf.net + ((size_t)b * E + row) * K + k);
+            }
+            rg[u] = v; rn[u] = n;
+        }
+        if (tid < 128) rw = *reinterpret_cast<const float4*>(WT + (size_t)r0 * Kp + k);   // (rows 0..15 of Wcat_0^T, zero-padded to Kp)
+    };
+    // the corrector's work on the slab in registers (same expressions as k_gemm_p0's), then the slab goes to LDS
+    auto sts = [&](int s, int buf) {
+        const int k = s * H_BK + c4;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int row = r0 + 64 * u;
+            if (row < E && k < K) {
+                float z[4], m[4];
+                philox_normal4(pf.seed, pf.draw, pf.b_off + b, (unsigned)((row * K + k) >> 2), z);
+                group_masks(pf.mt, b, E, K, row, k, m);
+                if (MODE == 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float zz = z[j] * m[j]; zacc[u] = fmaf(zz, zz, zacc[u]); }
+                } else {
+                    float4& v = rg[u];
+                    const float4 n = rn[u];
+                    v.x = fmaf(c2, z[0] * m[0], fmaf(c1, n.x, v.x)); v.y = fmaf(c2, z[1] * m[1], fmaf(c1, n.y, v.y));
+                    v.z = fmaf(c2, z[2] * m[2], fmaf(c1, n.z, v.z)); v.w = fmaf(c2, z[3] * m[3], fmaf(c1, n.w, v.w));
+                    *reinterpret_cast<float4*>(pf.f1 + ((size_t)b * E + row) * K + k) = v;
+                }
+            }
+            *reinterpret_cast<float4*>(Fs + buf * SLAB + row * H_LD + c4) = rg[u];
+        }
+        if (tid < 128) *reinterpret_cast<float4*>(Ws + buf * WSLAB + r0 * H_LD + c4) = rw;
+    };
+    f32x4 acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // waves 0..5: off-diagonal block (Ga, Gb) = (0,1) (0,2) (0,3) (1,2) (1,3) (2,3); their P_0 row tiles: one of Ga's, one of Gb's
+    const bool offd = wave < 6;
+    const int ga = wave < 3 ? 0 : wave < 5 ? 1 : 2, gb = wave < 3 ? wave + 1 : wave < 5 ? wave - 1 : 3;
+    // P_0 (12 sub-tiles): a whole group per wave -- G0 with wave 0, G1 with wave 3, G2 with wave 5 (their Ga), G3 with wave 4 (its Gb)
+    const bool pA = wave == 0 || wave == 3 || wave == 5, pB = wave == 4;
+    const int d0 = wave == 6 ? 0 : 6;                      // waves 6 / 7: the triangles of row tiles d0 .. d0 + 2 and d0 + 3 .. d0 + 5
+    ldg(0);
+    sts(0, 0);
+    __syncthreads();
+    for (int s = 0; s < NS; ++s) {
+        const float* S = Fs + (s & 1) * SLAB;
+        const float* W = Ws + (s & 1) * WSLAB;
+        if (s + 1 < NS) ldg(s + 1);
+#pragma unroll
+        for (int t = 0; t < H_BK / 16; ++t) {
+            auto frag = [&](int rt) { return *reinterpret_cast<const float4*>(S + (16 * rt + l15) * H_LD + 16 * t + 4 * kq); };
+            if (offd) {
+                float4 fa[3], fb[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { fa[i] = frag(3 * ga + i); fb[i] = frag(3 * gb + i); }
+                const float4 wq = *reinterpret_cast<const float4*>(W + l15 * H_LD + 16 * t + 4 * kq);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const float av[4] = {fa[i].x, fa[i].y, fa[i].z, fa[i].w}, bv[4] = {fb[j].x, fb[j].y, fb[j].z, fb[j].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[3 * i + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], acc[3 * i + j], 0, 0, 0);
+                    }
+                if (pA || pB) {
+                    const float wv[4] = {wq.x, wq.y, wq.z, wq.w};
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const float4 x = pA ? fa[i] : fb[i];
+                        const float av[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[9 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], wv[q], acc[9 + i], 0, 0, 0);
+                    }
+                }
+            } else {
+                float4 f[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) f[i] = frag(d0 + i);
+                int a = 0;
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = i; j < 3; ++j) {
+                            const float4 &fi = f[3 * g + i], &fj = f[3 * g + j];
+                            const float av[4] = {fi.x, fi.y, fi.z, fi.w}, bv[4] = {fj.x, fj.y, fj.z, fj.w};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], acc[a], 0, 0, 0);
+                            ++a;
+                        }
+            }
+        }
+        if (s + 1 < NS) sts(s + 1, (s + 1) & 1);
+        __syncthreads();
+    }
+    if (MODE == 1) {
+        // a row's eight column groups sit in eight consecutive lanes: fixed butterfly, lane 0 of the group stores (as k_gemm_p0)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            float v = zacc[u];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+            const int row = r0 + 64 * u;
+            if ((tid & 7) == 0 && row < E) pf.zrow[(size_t)b * E + row] = v;
+        }
+    }
+    constexpr int ldH = (E + 3) & ~3;                    // == h_ld(E)
+    float* Hb = H + (size_t)b * E * ldH;
+    auto store = [&](int ri, int cj, const f32x4& v) {
+        const int n = 16 * cj + l15;
+        if (n >= E) return;
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const int m = 16 * ri + 4 * kq + s2;
+            if (m < E) {
+                const float hv = (zero_diag && m == n) ? 0.f : v[s2];
+                Hb[(size_t)m * ldH + n] = hv;
+                Hb[(size_t)n * ldH + m] = hv;
+            }
+        }
+    };
+    auto store_p = [&](int ri, const f32x4& v) {
+        if (l15 >= wc) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 16 * ri + 4 * kq + r;
+            if (m < E) P[((size_t)b * E + m) * wc + l15] = v[r];
+        }
+    };
+    if (offd) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) store(3 * ga + i, 3 * gb + j, acc[3 * i + j]);
+        if (pA || pB) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) store_p(3 * (pA ? ga : gb) + i, acc[9 + i]);
+        }
+    } else {
+        int a = 0;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = i; j < 3; ++j) { store(d0 + 3 * g + i, d0 + 3 * g + j, acc[a]); ++a; }
+    }
+}
+#endif
+
 template <int NT, int KC = 0, int MODE = 0>          // KC: K as a compile-time constant (0: the argument); Kp follows; MODE: P0Fuse::mode
 __global__ __launch_bounds__(256) void k_gemm_p0(const float* __restrict__ rank2, const float* __restrict__ WT, float* __restrict__ P,
                                                  int rows, int K_, int Kp_, int wc, P0Fuse pf) {
