@@ -3,7 +3,7 @@
 bench line's launch time belongs to; for k_xa the norms and predictor launches differ by a few percent either way)"""
 import csv, glob, sys, collections, json, os
 
-KNAMES = ("k_xa", "k_r2", "k_hf_score", "k_gemm_h", "k_gemm_p", "k_langevin_apply", "k_noise_norm", "k_s4_apply", "k_ew1")
+KNAMES = ("k_xa", "k_r2", "k_hf_score", "k_hp_full", "k_gemm_h", "k_gemm_p", "k_langevin_apply", "k_noise_norm", "k_s4_apply", "k_ew1")
 out = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[1:]:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
