@@ -940,6 +940,12 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
     // behind each other in the workspace (k_gemm_h, k_gemm_pow); the F slabs are re-read per power (cnum > 2 only)
     const int npow = p.f_cnum - 1;
     TileAcc accs[NP];
+    // the state values the epilogue needs (specialised epilogue, below): requested beside the LAST contraction slab, so that they are
+    // in registers when the MFMAs end instead of costing an HBM / L2 round trip after them
+    float fpre[2][2][4];
+    unsigned char frpre[2];          // flags_right bytes of the wave's two column sub-tiles
+    unsigned flpre[2];               // flags_left bytes of its two row groups (four rows each)
+    constexpr bool FPRE = AFFINE && NP == 1;
 #pragma unroll
     for (int jp = 0; jp < NP; ++jp) tile_zero(accs[jp]);
 #pragma unroll
@@ -1023,6 +1029,23 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
             for (int u = 0; u < NB; ++u) *reinterpret_cast<float4*>(Bs + (bk + 16 * u) * BLD + bc4) = rb[u];
             __syncthreads();
             if (k0 + HBK < E) load_slab(k0 + HBK);
+            else if (FPRE) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int e0 = m0 + wm + 16 * i + 4 * kq, k = n0 + wn + 16 * j + l15;
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2)
+                            fpre[i][j][s2] = (k < K && e0 + s2 < E) ? Fb[(size_t)(e0 + s2) * K + k] : 0.f;
+                    }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int k = n0 + wn + 16 * q + l15, e0 = m0 + wm + 16 * q + 4 * kq;
+                    frpre[q] = k < K ? mt.mfr[(size_t)b * mt.Kp + k] : (unsigned char)0;
+                    flpre[q] = e0 < E ? *reinterpret_cast<const unsigned*>(mt.mfl + (size_t)b * mt.Ep + e0) : 0u;   // (e0 a multiple of 4, rows padded to Ep)
+                }
+            }
 #pragma unroll
             for (int t = 0; t < HBK / 16; ++t) {
                 const float4 a0 = *reinterpret_cast<const float4*>(As + (wm + l15) * HLD + 16 * t + 4 * kq);
@@ -1076,8 +1099,8 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
                     const int e0 = m0 + wm + 16 * i + 4 * kq, k = n0 + wn + 16 * j + l15;
                     if (k >= K || e0 >= E) continue;
                     const f32x4 hf = accs[0].a[i][j];
-                    const float fr = (float)frb[k];
-                    const unsigned fl4 = *reinterpret_cast<const unsigned*>(flb + e0);     // e0 is a multiple of 4, rows are padded to Ep
+                    const float fr = (float)frpre[j];                                       // (== frb[k], flb + e0: loaded beside the last slab)
+                    const unsigned fl4 = flpre[i];
                     const unsigned off = (unsigned)(e0 * K + k);
                     float z[4] = {0.f, 0.f, 0.f, 0.f};
                     if (ZS == 1) philox_normal4(na.seed, na.draw_r, na.b_off + b, (unsigned)((e0 >> 2) * K + k), z);
@@ -1086,7 +1109,7 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
                     for (int s2 = 0; s2 < 4; ++s2) {
                         if (s2 >= nr) break;
                         const unsigned g = off + (unsigned)(s2 * K);
-                        const float f = Fbb[g];
+                        const float f = fpre[i][j][s2];                                   // (== Fbb[g], loaded beside the last slab)
                         if (ZS == 2) z[s2] = zrb[g];
                         const float m = (float)((fl4 >> (8 * s2)) & 0xffu) * fr;          // flags_left * flags_right, cc_utils.py:590
                         float t = fmaf(fa, f, fgam);
