@@ -1174,8 +1174,9 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
         }
     });
     if (ep.mode == MODE_NORMS) {
-        const float tn = block_sum(s_net, red);
-        const float tz = block_sum(s_z, red);
+        float t2[2] = {s_net, s_z};
+        block_sums<2>(t2, red);                              // (one pair of barriers; each sum in block_sum's order)
+        const float tn = t2[0], tz = t2[1];
         if (threadIdx.x == 0) {
             const int nt = ncb * nrt;
             ep.part[((size_t)b * nt + tile) * 2 + 0] = tn;
