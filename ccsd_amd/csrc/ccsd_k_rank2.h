@@ -999,7 +999,7 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
                 const int row = m0 + ar + (256 / AG) * u, k = k0 + ak;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (row < E && k < E) {
-                    v = *reinterpret_cast<const float4*>(Hb + (size_t)row * ldH + k);
+                    v = *reinterpret_cast<const float4*>(Hb + (unsigned)(row * ldH + k));       // (uniform base + 32-bit offset: no 64-bit address arithmetic)
                     if (k + 1 >= E) v.y = 0.f;
                     if (k + 2 >= E) v.z = 0.f;
                     if (k + 3 >= E) v.w = 0.f;
@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
                 const int k = k0 + bk + 16 * u, col = n0 + bc4;
-                const float* src = Fb + (size_t)(k < E ? k : E - 1) * K;
+                const float* src = Fb + (unsigned)((k < E ? k : E - 1) * K);
                 float4 v;
                 if (vec && col + 3 < K) v = *reinterpret_cast<const float4*>(src + col);
                 else {
@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
                         const int e0 = m0 + wm + 16 * i + 4 * kq, k = n0 + wn + 16 * j + l15;
 #pragma unroll
                         for (int s2 = 0; s2 < 4; ++s2)
-                            fpre[i][j][s2] = (k < K && e0 + s2 < E) ? Fb[(size_t)(e0 + s2) * K + k] : 0.f;
+                            fpre[i][j][s2] = (k < K && e0 + s2 < E) ? Fb[(unsigned)((e0 + s2) * K + k)] : 0.f;
                     }
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
