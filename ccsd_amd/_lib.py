@@ -147,6 +147,11 @@ def get_library() -> Library:
     file is an error, never a fallback."""
     global _hip
     if _hip is None:
+        # torch first: its bundled HIP runtime (libamdhip64) must be the one in the process before libccsd_hip.so asks for that SONAME --
+        # loaded the other way round (library, then torch) the two copies do not share their device state and the library's first
+        # hipMalloc reports "no ROCm-capable device is detected" (seen with __graft_entry__.build() called ahead of any torch import)
+        import torch  # noqa: F401
+
         path = os.environ.get("CCSD_LIB_PATH") or HIP_LIB_PATH
         if not os.path.exists(path):
             raise CcsdError(
