@@ -192,6 +192,21 @@ class PCEngine:
         self.lib.check(self.lib.ccsd_sampler_run(self.handle, B, _ptr(flags), seed, sample_offset, first_step, last,
                                                  C.byref(s), C.byref(sc), C.byref(r), _ptr(traj), ws, n, self._stream()))
 
+    def init_and_run(self, flags, state, scratch, result, seed: int = 0, sample_offset: int = 0, first_step: int = 0,
+                     last_step: Optional[int] = None, traj: Optional[torch.Tensor] = None):
+        """init_state (in-kernel Philox prior) followed by run, with every argument of both calls prepared BEFORE the first one is
+        issued: the two C calls go out back to back, so the GPU is not left idle between the prior draw and the loop's first
+        launches while Python checks shapes and builds structs (a 20-step call is ~5 ms: ~25 us of that gap is 0.5 %)."""
+        B = flags.shape[0]
+        s, sc, r = self._state(*state, B), self._state(*scratch, B, "scratch"), self._state(*result, B, "result")
+        ws, n = self._workspace(B)
+        last = self.diff_steps if last_step is None else last_step
+        fp, tp, stream, lib, h = _ptr(flags), _ptr(traj), self._stream(), self.lib, self.handle
+        rc0 = lib.ccsd_init_state(h, B, fp, None, seed, sample_offset, C.byref(s), stream)
+        rc1 = lib.ccsd_sampler_run(h, B, fp, seed, sample_offset, first_step, last, C.byref(s), C.byref(sc), C.byref(r), tp, ws, n, stream) if rc0 == 0 else 0
+        lib.check(rc0)
+        lib.check(rc1)
+
     def profile_kernel(self, name: Optional[str]):
         """Add a kernel to the set timed with HIP events on the launch stream (None clears the set)."""
         self.lib.check(self.lib.ccsd_profile_kernel(self.handle, -1 if name is None else _lib.KERNEL_IDS[name]))

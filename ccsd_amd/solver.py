@@ -143,7 +143,6 @@ def get_pc_sampler(sde_x: SDE, sde_adj: SDE, shape_x: Sequence[int], shape_adj: 
         diff_traj: List[List[torch.Tensor]] = []
         with torch.no_grad():
             if rng == "philox":
-                eng.init_state(flags, state, None, the_seed, offset)
                 traj = None
                 if keep_traj:
                     per = sum(s[1] * s[2] for s in shapes[:nt])
@@ -151,12 +150,14 @@ def get_pc_sampler(sde_x: SDE, sde_adj: SDE, shape_x: Sequence[int], shape_adj: 
                 # the single C call covers n_steps == 1; more inner Langevin steps (solver.py:1131-1137) and the exact
                 # multi-GPU mode are driven step by step (same kernels, Philox noise generated in them)
                 stepwise = group is not None or (corrector == "Langevin" and n_steps != 1 and not s4)
+                if last == 0 or stepwise:
+                    eng.init_state(flags, state, None, the_seed, offset)
                 if last == 0:
                     for dst, src in zip(result, state):
                         if dst is not None:
                             dst.copy_(src)
                 elif not stepwise:
-                    eng.run(flags, state, scratch, result, the_seed, offset, 0, last, traj)
+                    eng.init_and_run(flags, state, scratch, result, the_seed, offset, 0, last, traj)   # (prior draw + loop, back to back)
                 else:
                     traj = None
                     _stepwise(eng, flags, state, scratch, result, None, the_seed, offset, last, diff_traj, keep_traj, group)
