@@ -975,9 +975,10 @@ __global__ __launch_bounds__(256) void k_hf_score(const PlanD* __restrict__ plan
     // permutation (row stride 68: 4 * 68 == 16 mod 32 keeps the four kq groups on disjoint banks).  Next slab's global
     // loads are issued before the MFMAs of the current one.
     constexpr int BLD = 68;
-    // contraction slab: 32 wide; 64 in the instances with a compile-time E (half as many barriers and global round trips per tile --
-    // the contraction over E is short: 190 for community_small)
-    constexpr int HBK = EC ? 64 : H_BK, HLD = HBK + 8;       // (HLD == 8 mod 32: conflict-free ds_read_b128 fragments)
+    // contraction slab: 32 wide.  (64 in the compile-time-E instances was right while the kernel sat at 102 VGPRs / four workgroups per CU --
+    // half as many barriers; since the epilogue's inputs are requested beside the last slab it needs 72, and the 19 KB of LDS of the
+    // 32-wide slab let more workgroups cover a tile's first-slab latency and epilogue: 541 -> 501 us; 16 wide: 520)
+    constexpr int HBK = H_BK, HLD = HBK + 8;       // (HLD == 8 mod 32: conflict-free ds_read_b128 fragments)
     constexpr int NA = T_BM * HBK / 4 / 256, NB = HBK / 16, AG = HBK / 4;   // A slab: NA 16-byte groups per thread, AG groups per row
     __shared__ __align__(16) float As[T_BM * HLD];
     __shared__ __align__(16) float Bs[HBK * BLD];
