@@ -862,6 +862,51 @@ def case_kat_hodge_layers(lib, device):
         assert_close(g_, w_, f"three hodge layers, Reverse + Langevin n_steps=2, {p}")
 
 
+def case_env_switches_bitwise(lib, device, switches, B=512, steps=2, name="ccsd_community_small_CC", counts=(20, 12, 16, 18, 14, 20),
+                              predictor="Euler", corrector="Langevin", snr=0.05, scale_eps=0.7):
+    """Instances of the SAME arithmetic selected by plan switches (read from the environment at plan creation) must agree BIT FOR
+    BIT: the production loop and the three scores with no switch set against every entry of `switches` (dicts of environment
+    variables).  Used for the one-workgroup-per-complex rank-2 kernels of the community_small geometry (k_gemm_h_full, k_hp_full)
+    against the tile kernels they replace."""
+    meta, parts = load_ckpt_np(name)
+    cfg, is_cc = meta["config"], meta["is_cc"]
+    N, Fd = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
+    names = ["x", "adj"] + (["rank2"] if is_cc else [])
+    flags = make_flags(B, N, list(counts)).to(device)
+    kw = dict(shape_x=(B, N, Fd), shape_adj=(B, N, N), predictor=predictor, corrector=corrector, snr=snr, scale_eps=scale_eps, n_steps=1,
+              probability_flow=False, continuous=True, denoise=True, eps=1e-4)
+    if is_cc:
+        d_min, d_max = cfg["data"]["d_min"], cfg["data"]["d_max"]
+        kw.update(is_cc=True, shape_rank2=(B, *rank2_dim(N, d_min, d_max)), d_min=d_min, d_max=d_max)
+    sd = [loader.load_sde(cfg["sde"][p]) for p in names]
+    ms = [loader.load_model_from_ckpt(meta[f"params_{p}"], parts[p], device) for p in names]
+    skw = dict(sde_x=sd[0], sde_adj=sd[1])
+    if is_cc:
+        skw["sde_rank2"] = sd[2]
+    outs = []
+    for env in [{}] + list(switches):
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            fn = solver.get_pc_sampler(device=device, rng="philox", seed=11, max_steps=steps, lib=lib, **skw, **kw)
+            res = fn(*ms, flags)
+            eng = fn.engine()
+            st = eng.alloc_state(B)
+            eng.init_state(flags, st, None, 3, 0)
+            scores = [eng.score(t, st[0], st[1], st[2] if is_cc else None, flags).clone() for t in range(len(names))]
+            outs.append([r.clone() for r in res[:len(names)]] + scores)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    for env, o in zip(switches, outs[1:]):
+        for k, (a, b) in enumerate(zip(outs[0], o)):
+            assert torch.isfinite(a).all()
+            assert torch.equal(a, b), f"{name} tensor {k}: default plan != plan with {env} (max diff {(a - b).abs().max().item():.3e})"
+
+
 def case_geometry_instances_bitwise(lib, device, B=64, steps=3, name="ccsd_qm9_CC", counts=(9, 9, 8, 7, 9, 5, 9, 3, 6, 9, 2, 9), expect=(4, 0),
                                     predictor="Reverse", snr=0.2, corrector="Langevin", scale_eps=0.7, no_bake=False):
     """The kernel instances with compile-time geometry or a compile-time plan (k_xa XA_PLAIN9 / XA_BAKED*, k_r2 QM9, the (E, K)

@@ -363,6 +363,12 @@ def test_zinc5b_production_loop_vs_oracle(lib):
     pc.case_zinc5b_production_loop(lib, DEV)
 
 
+def test_one_workgroup_per_complex_kernels_bitwise(lib):
+    """community_small_CC at B = 512: k_gemm_h_full / k_hp_full (one workgroup per complex, F streamed once) against the 64 x 64 tile
+    kernels and the two-kernel predictor pass they replace, and the norms-pass form of k_hp_full (off by default) -- bit for bit."""
+    pc.case_env_switches_bitwise(lib, DEV, [{"CCSD_NO_HP_FULL": "1"}, {"CCSD_NO_H_FULL": "1"}, {"CCSD_HP_FULL_NORMS": "1"}])
+
+
 def test_geometry_instances_match_runtime_geometry_bitwise(lib):
     """k_xa<false, XA_PLAIN9> / k_r2<3, 1, true, false, QM9> == the run-time-geometry instances, bit for bit (production loop + scores)."""
     # the geometry-only instances k_xa<false, XA_PLAIN9> / k_r2<3, 1, true, false, 1> (CCSD_NO_BAKE keeps the plan off the baked ones)
