@@ -355,6 +355,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not time the kernels with HIP events")
     ap.add_argument("--event-stride", type=int, default=17, help="bracket every n-th launch of a kernel with HIP events (odd: a kernel's norms / predictor launches alternate)")
+    ap.add_argument("--split-bf16", type=int, default=0, choices=[0, 3],
+                    help="EXPERIMENT, never the default: 3 = split-precision (bf16 x 3, fp32 accumulate) MFMA contraction in k_gemm_h_full "
+                         "(community_small geometry; CCSD_SPLIT_BF16).  The line then says dtype \"f32 + bf16x3 (experiment: ...)\"")
     ap.add_argument("--emulate", action="store_true",
                     help="TEST ONLY: run the product code over the host emulation of the kernels on the CPU with gloo (exercises the launcher / "
                          "sharding / reporting path on a GPU-less box; the numbers mean nothing)")
@@ -373,6 +376,10 @@ def main():
 
 def _main(real_stdout):
     args = parse_args()
+    if args.split_bf16:
+        os.environ["CCSD_SPLIT_BF16"] = str(args.split_bf16)      # (a plan switch: read when the engine creates its plan)
+    else:
+        os.environ.pop("CCSD_SPLIT_BF16", None)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # self-launch: N fresh rank processes, started before this process has made any GPU call (it never makes one)
         from ccsd_amd.distributed import launch_workers
@@ -539,7 +546,8 @@ def _main(real_stdout):
         line = {
             "metric": "sampled complexes/sec at 1000 PC steps, QM9_CC batch=1024, 1/2/4/8 GPU",
             "value": value, "unit": "complexes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_steps_run": warm_run,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if not args.split_bf16 else "f32 + bf16x3 (experiment: H = F F^T of the norms pass as three bf16 MFMA terms, fp32 accumulate)",
             "data": f"synthetic (node-count histogram flags, Philox N(0,1) prior/noise; shipped {wl['ckpt']} weights)",
             "config": {"workload": wl["desc"].format(B=B), "global_batch": total,
                        "parallelism": f"batch-sharded x{world}, per-shard Langevin norms, all-gather at end",

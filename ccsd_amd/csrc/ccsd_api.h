@@ -106,6 +106,9 @@ struct ccsd_plan {
     int opt_no_merge = 0;                                      // CCSD_NO_MERGE (diagnostic: separate norms / predictor k_r2 launches)
     int opt_hp_full_norms = 0;                                 // CCSD_HP_FULL_NORMS (diagnostic: k_hp_full in the norms pass too)
     int opt_no_hp_full = 0;                                    // CCSD_NO_HP_FULL (diagnostic: k_gemm_p0<., ., 1 / 2> + k_gemm_h_full instead of the one fused pass)
+    // EXPERIMENT, never the default (CCSD_SPLIT_BF16=3): split-precision ("bf16 x 3") MFMA contraction in k_gemm_h_full, the norms pass's
+    // H = F F^T of the community_small geometry (split_frag / split_mma, ccsd_k_rank2.h); results are NOT bit-identical to fp32
+    int opt_split_bf16 = 0;
     int opt_no_h_full = 0;                                     // CCSD_NO_H_FULL (diagnostic: k_gemm_h's 64 x 64 tiles for the community_small geometry too)
     int opt_no_tiled_fuse = 0;                                 // CCSD_NO_TILED_FUSE (diagnostic: k_noise_norm / k_langevin_apply as launches of their own on the tiled path)
     int opt_r2_masked = 1;                                     // CCSD_NO_R2_MASKED clears it (diagnostic: the loop's k_r2 launches re-mask rank2 in the Q_1 loader)
@@ -278,6 +281,7 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     pl->opt_r2_masked = getenv("CCSD_NO_R2_MASKED") == nullptr;
     pl->opt_no_tiled_fuse = getenv("CCSD_NO_TILED_FUSE") != nullptr;
     pl->opt_no_h_full = getenv("CCSD_NO_H_FULL") != nullptr;
+    if (const char* sp = getenv("CCSD_SPLIT_BF16")) pl->opt_split_bf16 = atoi(sp) == 3 ? 3 : 0;
     pl->opt_no_hp_full = getenv("CCSD_NO_HP_FULL") != nullptr;
     pl->opt_hp_full_norms = getenv("CCSD_HP_FULL_NORMS") != nullptr;
     if (const char* pr = getenv("CCSD_XA_PRIO")) pl->opt_xa_prio = atoi(pr);
@@ -565,9 +569,10 @@ static int launch_h(const ccsd_plan* pl, int B, const float* rank2, Workspace& w
     prof_mark(const_cast<ccsd_plan*>(pl), KID_GEMM_H, stream);
 #ifndef CCSD_EMU
     // community_small geometry, at least one complex per CU: one workgroup per complex, F streamed once (k_gemm_h_full; bit-identical)
-    if (p.E == 190 && p.K == 1140 && p.geo_off != 1 && B >= 256 && !pl->opt_no_h_full)
-        hipLaunchKernelGGL((k_gemm_h_full<190, 1140>), dim3(B), dim3(256), 0, (hipStream_t)stream, rank2, w.H, p.f_hmask);
-    else
+    if (p.E == 190 && p.K == 1140 && p.geo_off != 1 && B >= 256 && !pl->opt_no_h_full) {
+        if (pl->opt_split_bf16 == 3) hipLaunchKernelGGL((k_gemm_h_full<190, 1140, 2>), dim3(B), dim3(256), 0, (hipStream_t)stream, rank2, w.H, p.f_hmask);
+        else hipLaunchKernelGGL((k_gemm_h_full<190, 1140>), dim3(B), dim3(256), 0, (hipStream_t)stream, rank2, w.H, p.f_hmask);
+    } else
 #endif
     {
 #define H_GO(EC_, KC_) CCSD_LAUNCH((k_gemm_h<EC_, KC_>), g, dim3(CCSD_NTHREADS), 0, stream, rank2, w.H, p.E, p.K, p.f_hmask, B)

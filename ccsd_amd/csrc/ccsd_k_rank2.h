@@ -204,7 +204,60 @@ __global__ __launch_bounds__(256) void k_gemm_h(const float* __restrict__ rank2,
 // sub-tile each), 2 / 3 the rows 0-2 / 3-5 of the off-diagonal 6 x 6 block plus the sub-tile given up by wave 0 / 1, whose fragments
 // they hold anyway: 20 / 20 / 19 / 19 sub-tiles.  LDS: two slabs (one barrier per slab); B complexes = B workgroups, two per CU.
 // ---------------------------------------------------------------------------------------------
-template <int EC, int KC>
+// ---- EXPERIMENT (plan option CCSD_SPLIT_BF16 = 3 | 6, never the default): split-precision contraction on the bf16 matrix pipe.
+// An fp32 operand is cut into bf16 pieces: h = its top 16 bits (truncation: exact), then l = bf16(x - h) (round to nearest) -- SPLIT 2,
+// |x - h - l| <= 2^-16 |x| -- or m = the top 16 bits of x - h and l = bf16(x - h - m) -- SPLIT 3, <= 2^-24 |x|, i.e. every bit of x.
+// A product a b is then the fp32-accumulated sum of h_a h_b + h_a l_b + l_a h_b (three v_mfma_f32_16x16x32_bf16, 16 cycles each for 32 k
+// against eight fp32 MFMAs of 32 cycles: "bf16 x 3", dropped terms <= (2^-14 + 2^-15) |a b|) or of the six terms down to m_a m_b
+// ("bf16 x 6", dropped terms <= 2^-21 |a b|: fp32-grade).  The lane's eight k values of a 32-wide slab are its two 16-byte fragments.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int SPLIT>
+struct SplitFrag { bf16x8 h, m, l; };
+template <int SPLIT>
+CCSD_DEV SplitFrag<SPLIT> split_frag(const float4& a, const float4& b) {
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned hw[4], mw[4];
+    float r[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned u0 = __float_as_uint(x[2 * i]), u1 = __float_as_uint(x[2 * i + 1]);
+        hw[i] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+        r[2 * i] = x[2 * i] - __uint_as_float(u0 & 0xffff0000u);
+        r[2 * i + 1] = x[2 * i + 1] - __uint_as_float(u1 & 0xffff0000u);
+    }
+    SplitFrag<SPLIT> f;
+    __builtin_memcpy(&f.h, hw, 16);
+    if (SPLIT == 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned u0 = __float_as_uint(r[2 * i]), u1 = __float_as_uint(r[2 * i + 1]);
+            mw[i] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+            r[2 * i] = r[2 * i] - __uint_as_float(u0 & 0xffff0000u);
+            r[2 * i + 1] = r[2 * i + 1] - __uint_as_float(u1 & 0xffff0000u);
+        }
+        __builtin_memcpy(&f.m, mw, 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f.l[i] = (__bf16)r[i];
+    return f;
+}
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+template <int SPLIT>
+CCSD_DEV f32x4_ split_mma(const SplitFrag<SPLIT>& a, const SplitFrag<SPLIT>& b, f32x4_ c) {      // (small terms first)
+    if (SPLIT == 3) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.m, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.h, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.m, c, 0, 0, 0);
+    } else {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, c, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, c, 0, 0, 0);
+}
+
+template <int EC, int KC, int SPLIT = 0>        // SPLIT: 0 exact fp32 (the product path); 2 / 3: the split-precision experiment above
 __global__ __launch_bounds__(256, 2) void k_gemm_h_full(const float* __restrict__ rank2, float* __restrict__ H, int zero_diag) {
     static_assert(EC > 96 && EC <= 192 && (KC & 3) == 0, "one 192-row block, 16-byte rows");
     constexpr int E = EC, K = KC, NS = (K + H_BK - 1) / H_BK, SLAB = 192 * H_LD;
@@ -240,6 +293,39 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h_full(const float* __restrict_
     for (int s = 0; s < NS; ++s) {
         const float* S = Fs + (s & 1) * SLAB;
         if (s + 1 < NS) ldg(s + 1);
+        if constexpr (SPLIT != 0) {
+            static_assert(H_BK == 32, "one 32-wide bf16 MFMA per slab and term");
+            auto sfrag = [&](int rt) {
+                const float* q = S + (16 * rt + l15) * H_LD + 4 * kq;
+                return split_frag<SPLIT>(*reinterpret_cast<const float4*>(q), *reinterpret_cast<const float4*>(q + 16));
+            };
+            if (tri) {
+                SplitFrag<SPLIT> f[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) f[i] = sfrag(tb + i);
+                int a = 0;
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = i; j < 6; ++j) {
+                        if (!(i == 0 && j == 1)) acc[a] = split_mma<SPLIT>(f[i], f[j], acc[a]);
+                        ++a;
+                    }
+            } else {
+                SplitFrag<SPLIT> fa[3], fb[6];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) fa[i] = sfrag(tb + i);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) fb[j] = sfrag(6 + j);
+                int a = 0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) { acc[a] = split_mma<SPLIT>(fa[i], fb[j], acc[a]); ++a; }
+                if (wave == 2) acc[18] = split_mma<SPLIT>(fa[0], fa[1], acc[18]);
+                else acc[18] = split_mma<SPLIT>(fb[0], fb[1], acc[18]);
+            }
+        } else {
 #pragma unroll
         for (int t = 0; t < H_BK / 16; ++t) {
             auto frag = [&](int rt) { return *reinterpret_cast<const float4*>(S + (16 * rt + l15) * H_LD + 16 * t + 4 * kq); };
@@ -281,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h_full(const float* __restrict_
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[18] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], acc[18], 0, 0, 0);
             }
+        }
         }
         if (s + 1 < NS) sts((s + 1) & 1);
         __syncthreads();

@@ -907,6 +907,44 @@ def case_env_switches_bitwise(lib, device, switches, B=512, steps=2, name="ccsd_
             assert torch.equal(a, b), f"{name} tensor {k}: default plan != plan with {env} (max diff {(a - b).abs().max().item():.3e})"
 
 
+def case_split_precision(lib, device, B=512, name="ccsd_community_small_CC", counts=(20, 12, 16, 18, 14, 20)):
+    meta, parts = load_ckpt_np(name)
+    cfg = meta["config"]
+    N, Fd = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
+    names = ["x", "adj", "rank2"]
+    flags = make_flags(B, N, list(counts)).to(device)
+    d_min, d_max = cfg["data"]["d_min"], cfg["data"]["d_max"]
+    kw = dict(shape_x=(B, N, Fd), shape_adj=(B, N, N), predictor="Euler", corrector="Langevin", snr=0.05, scale_eps=0.7, n_steps=1,
+              probability_flow=False, continuous=True, denoise=True, eps=1e-4, is_cc=True, shape_rank2=(B, *rank2_dim(N, d_min, d_max)),
+              d_min=d_min, d_max=d_max)
+    sd = [loader.load_sde(cfg["sde"][p]) for p in names]
+    ms = [loader.load_model_from_ckpt(meta[f"params_{p}"], parts[p], device) for p in names]
+    outs = []
+    saved = os.environ.pop("CCSD_SPLIT_BF16", None)
+    try:
+        for mode in (None, "3"):
+            if mode:
+                os.environ["CCSD_SPLIT_BF16"] = mode
+            fn = solver.get_pc_sampler(device=device, rng="philox", seed=11, max_steps=10, lib=lib, sde_x=sd[0], sde_adj=sd[1], sde_rank2=sd[2], **kw)
+            res = fn(*ms, flags)
+            eng = fn.engine()
+            st = eng.alloc_state(B)
+            eng.init_state(flags, st, None, 3, 0)
+            outs.append([r.clone() for r in res[:3]] + [eng.score(2, st[0], st[1], st[2], flags).clone()])
+            os.environ.pop("CCSD_SPLIT_BF16", None)
+    finally:
+        os.environ.pop("CCSD_SPLIT_BF16", None)
+        if saved is not None:
+            os.environ["CCSD_SPLIT_BF16"] = saved
+    exact, split = outs
+    sc = (exact[3] - split[3]).abs().max().item() / exact[3].abs().max().item()
+    assert 0 < sc <= 2e-5, f"split-precision rank-2 score: relative difference {sc:.3e} (0 would mean the switch selected nothing)"
+    for nm, a, b in zip(names, exact[:3], split[:3]):
+        assert torch.isfinite(b).all()
+        d = (a - b).abs().max().item() / max(a.abs().max().item(), 1e-6)
+        assert d <= RTOL, f"split-precision trajectory, {nm}: {d:.3e} > {RTOL}"
+
+
 def case_geometry_instances_bitwise(lib, device, B=64, steps=3, name="ccsd_qm9_CC", counts=(9, 9, 8, 7, 9, 5, 9, 3, 6, 9, 2, 9), expect=(4, 0),
                                     predictor="Reverse", snr=0.2, corrector="Langevin", scale_eps=0.7, no_bake=False):
     """The kernel instances with compile-time geometry or a compile-time plan (k_xa XA_PLAIN9 / XA_BAKED*, k_r2 QM9, the (E, K)

@@ -369,6 +369,14 @@ def test_one_workgroup_per_complex_kernels_bitwise(lib):
     pc.case_env_switches_bitwise(lib, DEV, [{"CCSD_NO_HP_FULL": "1"}, {"CCSD_NO_H_FULL": "1"}, {"CCSD_HP_FULL_NORMS": "1"}])
 
 
+def test_split_precision_experiment_error_bound(lib):
+    """EXPERIMENT (CCSD_SPLIT_BF16=3, never the default): H = F F^T of the norms pass as three bf16 MFMA terms with fp32 accumulation
+    (k_gemm_h_full<., ., 2>).  Per product the dropped terms are <= (2^-14 + 2^-15) |a b| (split_frag, ccsd_k_rank2.h); measured on
+    community_small_CC at B = 512: the rank-2 score moves by a few 1e-6 of its scale.  Held here to 2e-5 (score) and to the parity
+    tolerance 1e-4 on a 10-step trajectory against the exact-fp32 plan."""
+    pc.case_split_precision(lib, DEV)
+
+
 def test_geometry_instances_match_runtime_geometry_bitwise(lib):
     """k_xa<false, XA_PLAIN9> / k_r2<3, 1, true, false, QM9> == the run-time-geometry instances, bit for bit (production loop + scores)."""
     # the geometry-only instances k_xa<false, XA_PLAIN9> / k_r2<3, 1, true, false, 1> (CCSD_NO_BAKE keeps the plan off the baked ones)
