@@ -26,6 +26,8 @@ else
     python3 bench.py --batch 2500 --steps 200 --no-cpu-baseline 2> /dev/null > gpurun_out/${tag}_batch2500_bench.json && echo "qm9_CC at the shipped YAML's chunk (2500) done"
     # BASELINE configs[1] with its roofline and CPU-baseline legs (the other workloads: kernel-trace summaries only)
     python3 bench.py --workload community_small_CC --steps 60 --warmup 5 2> /dev/null > gpurun_out/${tag}_community_small_CC_full_bench.json && echo "community_small_CC (roofline + cpu baseline) done"
+    # the split-precision experiment (never the default): its own labelled line
+    python3 bench.py --workload community_small_CC --steps 60 --warmup 5 --no-cpu-baseline --split-bf16 3 2> /dev/null > gpurun_out/${tag}_community_small_CC_bf16x3_bench.json && echo "community_small_CC, bf16 x 3 experiment done"
     for wl in community_small_CC zinc250k_CC_5b enzymes_small_CC qm9_Base_CC zinc250k community_small; do
         cd /tmp
         rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_$wl -o run -- python3 $R/bench.py --workload $wl --steps 30 --warmup 3 --no-cpu-baseline --no-kernel-events --warmup-seconds 0 > $R/gpurun_out/${tag}_${wl}_bench.json 2> $R/gpurun_out/${tag}_${wl}.err || echo "$wl failed"
