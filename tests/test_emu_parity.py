@@ -152,6 +152,14 @@ def test_production_loop_vs_oracle(lib):
                                       expect_fused=False)
 
 
+def test_production_loop_edge_flags(lib):
+    """Edge cases of the flags (init_flags can draw any node count 1..N; 0 = an EMPTY complex is what the masks make of a padded
+    batch slot): complexes with no node, one node (no edge, no cell), two nodes (one edge, no cell of rank 2) beside full ones, and a
+    batch of ONE -- the production loop against the oracle on the exported draws, and bit equality with the step-wise loop."""
+    pc.case_production_loop_vs_oracle("ccsd_qm9_CC", lib, DEV, 7, [0, 1, 2, 9, 3, 0, 9], 3, "Reverse", "Langevin", 0.2, 0.7, seed=31)
+    pc.case_production_loop_vs_oracle("ccsd_qm9_CC", lib, DEV, 1, [5], 2, "Reverse", "Langevin", 0.2, 0.7, seed=37)
+
+
 def test_fused_r2_serves_nonaffine_shapes(lib):
     pc.case_fused_r2_nonaffine_shapes(lib, DEV)
 
