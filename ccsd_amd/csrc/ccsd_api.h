@@ -348,8 +348,14 @@ extern "C" int ccsd_plan_create(const ccsd_config_t* cfg, const float* weights, 
     {
         std::vector<float> packed(pl->npacked + 4, 0.f);
         ccsd_pack_mlp(pl->h.x_fin, weights, packed.data());
-        for (int l = 0; l < pl->h.a_L; ++l) { ccsd_pack_mlp(pl->h.al[l].mlp, weights, packed.data()); ccsd_pack_qkv(pl->h.al[l], weights, packed.data()); ccsd_pack_mc(pl->h.al[l], weights, packed.data()); }
-        if (pl->h.x_gmh) for (int l = 0; l < pl->h.x_depth; ++l) { ccsd_pack_mlp(pl->h.gl[l].mlp, weights, packed.data()); ccsd_pack_qkv(pl->h.gl[l], weights, packed.data()); ccsd_pack_mc(pl->h.gl[l], weights, packed.data()); }
+        for (int l = 0; l < pl->h.a_L; ++l) {
+            ccsd_pack_mlp(pl->h.al[l].mlp, weights, packed.data()); ccsd_pack_mlp(pl->h.al[l].mc, weights, packed.data());
+            ccsd_pack_qkv(pl->h.al[l], weights, packed.data()); ccsd_pack_mc(pl->h.al[l], weights, packed.data());
+        }
+        if (pl->h.x_gmh) for (int l = 0; l < pl->h.x_depth; ++l) {
+            ccsd_pack_mlp(pl->h.gl[l].mlp, weights, packed.data()); ccsd_pack_mlp(pl->h.gl[l].mc, weights, packed.data());
+            ccsd_pack_qkv(pl->h.gl[l], weights, packed.data()); ccsd_pack_mc(pl->h.gl[l], weights, packed.data());
+        }
         if (pl->h.hb_L) ccsd_pack_mlp(pl->h.hb[0].mh, weights, packed.data());
         for (int l = 0; l < pl->h.hb_L; ++l) {   // transposed copies of the BaselineBlocks' weights
             const HodgeBaseD& h = pl->h.hb[l];

@@ -440,9 +440,14 @@ CCSD_DEV int mlp_maxw(const MlpD& m) {
 // round-robin over the waves of the workgroup.  The accumulation is a k-ordered fmaf chain, the
 // same as the emulation loop below.
 // ---------------------------------------------------------------------------------------------
+// (mlp_wt: the transposed copy of linear i of a non-chained MLP in the packed buffer, or nullptr -- MlpD, ccsd_plan.h)
+CCSD_DEV const float* mlp_wt(const MlpD& m, const float* wp, int i) { return (!m.chain && m.pb[0] == CCSD_MLP_WT) ? wp + m.pw[i] : nullptr; }
 template <int ACT>  // 0 none, 1 ELU
+// Wt (optional): the transposed zero-padded copy Wt[in][pad16(out)] of W -- the 16 lanes of a B-operand load then read 64 consecutive
+// bytes instead of one word from each of 16 rows of W (same values, same k order: bit-identical)
 CCSD_DEV void block_linear(float* Y, int ldy, const float* X, int ldx, const float* X2, int ksplit,
-                           const float* __restrict__ W, const float* __restrict__ bias, int in, int out, int rows) {
+                           const float* __restrict__ W, const float* __restrict__ bias, int in, int out, int rows,
+                           const float* __restrict__ Wt = nullptr) {
 #ifdef CCSD_EMU
     for (int o = 0; o < out; ++o)
         for (int m = 0; m < rows; ++m) {
@@ -461,6 +466,7 @@ CCSD_DEV void block_linear(float* Y, int ldy, const float* X, int ldx, const flo
         const int bn = n0 + l15;
         const int am = (m0 + l15 < rows) ? m0 + l15 : rows - 1;      // clamp: rows beyond `rows` are never stored
         const float* wr = W + (size_t)(bn < out ? bn : 0) * in;
+        const int outp = (out + 15) & ~15;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float nok = bn < out ? 1.f : 0.f;
         for (int s0 = 0; s0 < ks; s0 += 4) {   // weights come from L2: issue the loads of four k-steps before the MFMAs.
@@ -472,7 +478,7 @@ CCSD_DEV void block_linear(float* Y, int ldy, const float* X, int ldx, const flo
                 const int off = kc < ksplit ? kc * ldx : (kc - ksplit) * ldx;
                 const float* xb = kc < ksplit ? X : X2;
                 a[u] = xb[off + am];
-                bv[u] = wr[kc] * (k < in ? nok : 0.f);
+                bv[u] = (Wt ? Wt[kc * outp + bn] : wr[kc]) * (k < in ? nok : 0.f);        // (Wt: bn < outp always; its pad columns are zero)
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bv[u], acc, 0, 0, 0);

@@ -388,6 +388,7 @@ __global__ __launch_bounds__((VAR == XA_PLAIN9 || VAR == XA_BAKED9 || !XA_4WAVES
             __syncthreads();
         }
         }
+        stamp(xa.dbg, 26);                                            // (X-network: conv layers done, head starts; overwrites the HW_ID diagnostic of wave 0)
         const MlpD& m = p.x_fin;
         if (m.chain) {
             auto epx = [&](int row, int f, float v) { s_h1[f * ldn + row] = v; };
@@ -395,13 +396,14 @@ __global__ __launch_bounds__((VAR == XA_PLAIN9 || VAR == XA_BAKED9 || !XA_4WAVES
             if (m.chain == 2) mlp_chain<2, 3, 1>(m, wp, s_xcat, ldn, s_xcat, m.in, N, ident, epx);
             else mlp_chain<3, 6, 1>(m, wp, s_xcat, ldn, s_xcat, m.in, N, ident, epx);
         } else {
-            block_linear<1>(s_h1, ldn, s_xcat, ldn, s_xcat, m.in, wx + m.w[0], wx + m.b[0], m.in, m.hid, N);
+            block_linear<1>(s_h1, ldn, s_xcat, ldn, s_xcat, m.in, wx + m.w[0], wx + m.b[0], m.in, m.hid, N, mlp_wt(m, wp, 0));
             __syncthreads();
-            block_linear<1>(s_h2, ldn, s_h1, ldn, s_h1, m.hid, wx + m.w[1], wx + m.b[1], m.hid, m.hid, N);
+            block_linear<1>(s_h2, ldn, s_h1, ldn, s_h1, m.hid, wx + m.w[1], wx + m.b[1], m.hid, m.hid, N, mlp_wt(m, wp, 1));
             __syncthreads();
-            block_linear<0>(s_h1, ldn, s_h2, ldn, s_h2, m.hid, wx + m.w[2], wx + m.b[2], m.hid, m.out, N);
+            block_linear<0>(s_h1, ldn, s_h2, ldn, s_h2, m.hid, wx + m.w[2], wx + m.b[2], m.hid, m.out, N, mlp_wt(m, wp, 2));
         }
         __syncthreads();
+        stamp(xa.dbg, 27);                                            // (head done)
         for (int t = tid; t < N * F; t += nth) {
             int i, f;
             dF.divmod(t, i, f);
@@ -1179,11 +1181,11 @@ __global__ __launch_bounds__((VAR == XA_PLAIN9 || VAR == XA_BAKED9 || !XA_4WAVES
                 if (x_late && wave_id == n_waves - 1) (void)xnet_late_stage<NFIX>(2, p, w, wp, sm, xa, na, b);
                 stamp(xa.dbg, 11);
             } else {
-                block_linear<1>(f0, ldf, s_chan + p0, NN, s_chan + p0, m.in, wf + m.w[0], wf + m.b[0], m.in, m.hid, rows);
+                block_linear<1>(f0, ldf, s_chan + p0, NN, s_chan + p0, m.in, wf + m.w[0], wf + m.b[0], m.in, m.hid, rows, mlp_wt(m, wp, 0));
                 __syncthreads();
-                block_linear<1>(f1, ldf, f0, ldf, f0, m.hid, wf + m.w[1], wf + m.b[1], m.hid, m.hid, rows);
+                block_linear<1>(f1, ldf, f0, ldf, f0, m.hid, wf + m.w[1], wf + m.b[1], m.hid, m.hid, rows, mlp_wt(m, wp, 1));
                 __syncthreads();
-                block_linear<0>(f0, ldf, f1, ldf, f1, m.hid, wf + m.w[2], wf + m.b[2], m.hid, 1, rows);
+                block_linear<0>(f0, ldf, f1, ldf, f1, m.hid, wf + m.w[2], wf + m.b[2], m.hid, 1, rows, mlp_wt(m, wp, 2));
             }
             __syncthreads();
             stamp(xa.dbg, 15);

@@ -21,7 +21,10 @@ struct MlpD {
     int w[CCSD_MAXLIN], b[CCSD_MAXLIN];
     // register-resident chain (mlp_chain_tile): chain = index into CCSD_CHAIN_SHAPES (0: not chained, block_linear
     // path); offsets of the zero-padded copies Wp[16*to][16*ti], bp[16*to] of every linear in the packed weight buffer,
-    // padded to the chosen shape's tile counts
+    // padded to the chosen shape's tile counts.
+    // chain == 0 and pb[0] == CCSD_MLP_WT: pw[i] = offset of the TRANSPOSED zero-padded copy Wt_i[in][pad16(out)] of linear i in the packed
+    // buffer -- block_linear's B operands: the 16 lanes of a load read 64 consecutive bytes instead of one word from each of 16 rows of W
+    // (ScoreNetworkX's 107 -> 214 -> 214 -> 11 head on community_small: 174 k -> 81 k cycles of k_xa; PlanBuilder::transposed)
     int chain;
     int pw[CCSD_MAXLIN], pb[CCSD_MAXLIN];
 };
@@ -32,6 +35,7 @@ static const int CCSD_CHAIN_SHAPES[CCSD_NSHAPES][3] = {{0, 0, 0}, {1, 1, 1}, {2,
 #define CCSD_CHAIN_XFIN 0x24u
 #define CCSD_CHAIN_AFIN 0x78u
 static inline __host__ __device__ int pad16(int v) { return (v + 15) & ~15; }
+#define CCSD_MLP_WT 0x5754
 // dims of linear i of an MlpD
 static inline __host__ __device__ int mlp_in(const MlpD& m, int i) { return i == 0 ? m.in : m.hid; }
 static inline __host__ __device__ int mlp_out(const MlpD& m, int i) { return i == m.n - 1 ? m.out : m.hid; }
@@ -161,6 +165,11 @@ struct PlanBuilder {
     int pcur = 0;     // packed (chain) weight buffer
     // reserve padded copies of an MLP's linears for mlp_chain_tile
     void chainify(MlpD& m, unsigned allowed);
+    void transposed(MlpD& m) {          // (non-chained MLPs that run through block_linear; CCSD_NO_MLP_WT: diagnostic)
+        if (m.chain || getenv("CCSD_NO_MLP_WT")) return;
+        for (int i = 0; i < m.n; ++i) { m.pw[i] = pcur; pcur += (i == 0 ? m.in : m.hid) * (((i == m.n - 1 ? m.out : m.hid) + 15) & ~15); }
+        m.pb[0] = CCSD_MLP_WT;
+    }
     std::string err;
     int status = CCSD_OK;
     int take(int64_t n) {
@@ -207,6 +216,13 @@ static inline __host__ __device__ int ccsd_chain_widx(int o, int k, int ip) {
 }
 // zero-padded copies of a chain MLP's linears (torch layout [out][in]) into the packed buffer
 static inline void ccsd_pack_mlp(const MlpD& m, const float* w, float* packed) {
+    if (!m.chain && m.pb[0] == CCSD_MLP_WT) {       // transposed copies (block_linear)
+        for (int i = 0; i < m.n; ++i) {
+            const int in = mlp_in(m, i), out = mlp_out(m, i), op = pad16(out);
+            for (int k = 0; k < in; ++k)
+                for (int o = 0; o < out; ++o) packed[(size_t)m.pw[i] + (size_t)k * op + o] = w[(size_t)m.w[i] + (size_t)o * in + k];
+        }
+    }
     if (!m.chain) return;
     const int* sh = CCSD_CHAIN_SHAPES[m.chain];
     for (int i = 0; i < m.n; ++i) {
@@ -291,7 +307,9 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
         const int hid = 2 * (a.cin > a.cout ? a.cin : a.cout);
         a.mlp = pb.mlp(num_linears, 2 * a.cin, hid, a.cout);
         pb.chainify(a.mlp, CCSD_CHAIN_EDGE);
+        pb.transposed(a.mlp);
         a.mc = pb.mlp(2, a.cin * a.fout, hid, a.fout);
+        pb.transposed(a.mc);
         a.w_hi = pb.cur;
         a.mcs = (a.fout + 3) >> 2;
         a.mcp = pb.pcur;
@@ -316,6 +334,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     p->x_wlo = p->x_gw[0];
     p->x_fin = pb.mlp(3, p->x_fdim, 2 * p->x_fdim, F);
     pb.chainify(p->x_fin, CCSD_CHAIN_XFIN);
+    pb.transposed(p->x_fin);
     p->x_whi = pb.cur;
     // ---- ScoreNetworkA graph branch
     if (c->a_num_layers < 1 || c->a_num_layers > CCSD_MAXL) { pb.fail(CCSD_ERR_UNSUPPORTED, "a_num_layers out of range"); return 0; }
@@ -399,6 +418,7 @@ static inline size_t ccsd_build_plan(const ccsd_config_t* c, PlanD* p, PlanBuild
     p->a_fdim = p->a_nch_graph + p->a_nch_hodge;
     p->a_fin = pb.mlp(3, p->a_fdim, 2 * p->a_fdim, 1);
     pb.chainify(p->a_fin, CCSD_CHAIN_AFIN);
+    pb.transposed(p->a_fin);
     // ---- ScoreNetworkF
     if (c->is_cc) {
         if (c->f_num_layers < 1 || c->f_num_layers > CCSD_MAXFL) { pb.fail(CCSD_ERR_UNSUPPORTED, "f_num_layers out of range"); return 0; }

@@ -377,7 +377,8 @@ def test_zinc5b_production_loop_vs_oracle(lib):
 def test_one_workgroup_per_complex_kernels_bitwise(lib):
     """community_small_CC at B = 512: k_gemm_h_full / k_hp_full (one workgroup per complex, F streamed once) against the 64 x 64 tile
     kernels and the two-kernel predictor pass they replace, and the norms-pass form of k_hp_full (off by default) -- bit for bit."""
-    pc.case_env_switches_bitwise(lib, DEV, [{"CCSD_NO_HP_FULL": "1"}, {"CCSD_NO_H_FULL": "1"}, {"CCSD_HP_FULL_NORMS": "1"}])
+    pc.case_env_switches_bitwise(lib, DEV, [{"CCSD_NO_HP_FULL": "1"}, {"CCSD_NO_H_FULL": "1"}, {"CCSD_HP_FULL_NORMS": "1"},
+                                            {"CCSD_NO_MLP_WT": "1"}])       # (the last: the block_linear MLPs on the untransposed weights)
 
 
 def test_split_precision_experiment_error_bound(lib):

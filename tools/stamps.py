@@ -43,6 +43,7 @@ for k in sorted(lab):
 span = (d[:, 5].max() - d[:, 0].min())
 hs = [12, 16, 17, 18, 19, 20, 13]
 print("hodge: fill/hq0, dense pairs, deg, MFMA proj, diag att, scatter:", [int(np.median(x[:, hs[i + 1]] - x[:, hs[i]])) for i in range(6)])
+print("X-network: inputs + conv layers, head (final MLP), epilogue:", [int(np.median(x[:, b2] - x[:, a2])) for a2, b2 in ((0, 26), (26, 27), (27, 1))])
 print("final MLP: chain (wave 0)", int(np.median(x[:, 11] - x[:, 13])), " wait barrier", int(np.median(x[:, 15] - x[:, 11])), " epilogue", int(np.median(x[:, 14] - x[:, 15])))
 print("k_r2 first-start to last-end cycles:", span, " k_xa:", x[:, 14].max() - x[:, 0].min())
 for nm, v, s0, s1 in (("k_r2", d[:, :32], 0, 5), ("k_xa", x, 0, 14)):
