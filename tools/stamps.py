@@ -48,6 +48,8 @@ print("final MLP: chain (wave 0)", int(np.median(x[:, 11] - x[:, 13])), " wait b
 print("k_r2 first-start to last-end cycles:", span, " k_xa:", x[:, 14].max() - x[:, 0].min())
 for nm, v, s0, s1 in (("k_r2", d[:, :32], 0, 5), ("k_xa", x, 0, 14)):
     ok = v[:, s0] > 0
+    if not ok.any():
+        continue            # (a plan without the fused rank-2 kernel has no k_r2 stamps)
     cyc = float(v[ok, s1].max() - v[ok, s0].min())
     rt = float(v[ok, 31].max() - v[ok, 30].min()) / 100.0        # us (100 MHz counter)
     print(f"{nm}: span {cyc:.0f} cycles = {rt:.1f} us of real time -> shader clock {cyc / rt / 1000:.2f} GHz; per-workgroup median {np.median(v[:, s1] - v[:, s0]):.0f} cycles")
