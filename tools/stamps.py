@@ -9,11 +9,12 @@ from ccsd_amd.engine import PCEngine
 from tests.helpers import load_ckpt_np
 meta, parts = load_ckpt_np(os.environ.get("STAMPS_CKPT", "ccsd_qm9_CC"))   # STAMPS_CKPT=ccsd_qm9_Base_CC: the ablation checkpoint
 cfg = meta["config"]
-sdes = [loader.load_sde(cfg["sde"][p]) for p in ("x", "adj", "rank2")]
+is_cc = bool(meta.get("is_cc", True))
+sdes = [loader.load_sde(cfg["sde"][p]) for p in (("x", "adj", "rank2") if is_cc else ("x", "adj"))]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 Nn, Ff = cfg["data"]["max_node_num"], cfg["data"]["max_feat_num"]
-eng = PCEngine(meta["params_x"], parts["x"], meta["params_adj"], parts["adj"], meta["params_rank2"], parts["rank2"],
-               N=Nn, F=Ff, is_cc=True, d_min=cfg["data"]["d_min"], d_max=cfg["data"]["d_max"], sdes=sdes, predictor="Reverse",
+eng = PCEngine(meta["params_x"], parts["x"], meta["params_adj"], parts["adj"], meta.get("params_rank2") if is_cc else None, parts.get("rank2") if is_cc else None,
+               N=Nn, F=Ff, is_cc=is_cc, d_min=cfg["data"].get("d_min", 0) if is_cc else 0, d_max=cfg["data"].get("d_max", 0) if is_cc else 0, sdes=sdes, predictor="Reverse",
                corrector="Langevin", snr=0.2, scale_eps=0.7, n_steps=1, denoise=True, eps=1e-4, device="cuda:0", batch_hint=B)
 flags = (bench.hist_flags(B, 9, bench.QM9_HIST) if Nn == 9 else bench.hist_flags(B, Nn, {Nn: 3, Nn - 2: 2, Nn - 5: 1})).cuda()
 st, sc, rs = eng.alloc_state(B), eng.alloc_state(B), eng.alloc_state(B)
